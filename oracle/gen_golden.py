@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the COMPILED, UNMODIFIED reference -- TEST INFRASTRUCTURE.
+
+Run in the build container only (needs oracle/_ref/libsecedo_ref.so, i.e. /root/reference):
+
+    make -C oracle ref && python oracle/gen_golden.py
+
+Every fixture stores the flat input pileup, the call parameters and the reference's output
+matrix, so the tests need neither the reference nor this script's random generators.
+The pileup text files under tests/golden/data/ are data files of the reference's own test-suite
+(reference: tests/data/{ten_rows,six_cells,three_rows,one_row}.pileup, six_cells.pileup.group);
+they are parsed here by the reference's reader (util/pileup_reader.cpp) in a scratch directory.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import bindings as ob  # noqa: E402
+from secedo_amd.pileup import FlatPileup  # noqa: E402
+from tests.pileup_gen import from_rows, random_pileup  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+NORMS = ob.NORMALIZATIONS
+
+
+def save(name, p: FlatPileup, cases, **extra):
+    """cases: list of dicts(num_cells, mfl, g2p, eps, h, theta, T, norm) -> adds 'out'."""
+    arrays = dict(chr_locus_off=p.chr_locus_off, locus_pos=p.locus_pos,
+                  locus_entry_off=p.locus_entry_off, read_ids=p.read_ids, id_base=p.id_base)
+    params = []
+    for i, c in enumerate(cases):
+        out = ob.ref_compute(p, c["num_cells"], c["mfl"], c["g2p"], c["eps"], c["h"], c["theta"],
+                             c["T"], c["norm"])
+        arrays["out_%d" % i] = out
+        arrays["g2p_%d" % i] = np.asarray(c["g2p"], dtype=np.uint32)
+        params.append([c["num_cells"], c["mfl"], c["eps"], c["h"], c["theta"], c["T"],
+                       NORMS.index(c["norm"])])
+    arrays["params"] = np.asarray(params, dtype=np.float64)
+    for k, v in extra.items():
+        arrays[k] = np.asarray(v)
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s loci=%6d entries=%7d cases=%2d  %7.1f KB" % (
+        name, p.n_loci, p.n_entries, len(cases), os.path.getsize(path) / 1024))
+
+
+def case(n, mfl, T, norm, g2p=None, eps=0.01, h=0.5, theta=0.01):
+    return dict(num_cells=n, mfl=mfl, g2p=np.arange(n, dtype=np.uint32) if g2p is None else g2p,
+                eps=eps, h=h, theta=theta, T=T, norm=norm)
+
+
+def far_dummies(first_id, pos0, count, group=0, step=5000):
+    """`count` loci far downstream, each with one read of cell `group` (same cell => no pair):
+    they push the position past start + mfl so that earlier reads complete and get flushed."""
+    return [(pos0 + step * (k + 1), [(first_id + k, group, 0)]) for k in range(count)]
+
+
+def semantic_probes():
+    # SURVEY.md section 0 facts, 4 cells. Reads 1..4 at one locus; cells 0,1 'A', cells 2,3 'C'.
+    locus = (1000, [(1, 0, 0), (2, 1, 0), (3, 2, 1), (4, 3, 1)])
+    # (1) single-locus chromosome: nothing is ever flushed -> zero comparisons (fact 2)
+    save("probe_single_locus", from_rows([[locus]]),
+         [case(4, 1000, 1, n) for n in NORMS])
+    # (2) + far dummy loci of cell 0: reads complete; with T=1 four completed reads trigger a
+    # flush at the next locus; with T=2 eight are needed and are not reached (fact 3)
+    rows = [locus] + far_dummies(100, 1000, 3)
+    save("probe_flush_T1_vs_T2", from_rows([rows]),
+         [case(4, 1000, 1, n) for n in NORMS] + [case(4, 1000, 2, n) for n in NORMS])
+    # (3) two chromosomes: live reads are dropped at the chromosome end; `completed` carries over
+    rows2 = [(500, [(1, 0, 0), (2, 2, 1)]), (700, [(3, 1, 0), (4, 3, 1)])] + far_dummies(200, 700, 2)
+    save("probe_two_chromosomes", from_rows([rows, rows2]),
+         [case(4, 1000, 1, "ADD_MIN"), case(4, 1000, 2, "ADD_MIN"), case(4, 1000, 1, "EXPONENTIATE")])
+    # (4) multi-locus pair: reads 1 (cell 0) and 2 (cell 1) share one matching and one
+    # mismatching locus -> ONE joint (1,1) term, not (1,0)+(0,1) (fact 1)
+    rows = [(1000, [(1, 0, 0), (2, 1, 0)]), (1100, [(1, 0, 2), (2, 1, 3)])] + far_dummies(100, 1100, 4, group=2)
+    save("probe_multi_locus_pair", from_rows([rows]),
+         [case(4, 1000, 1, n) for n in NORMS])
+    # (5) paired-end duplicates (similarity_matrix.cpp:387-395): equal second base is ignored;
+    # a conflicting second base removes the position; a third entry is then appended again
+    rows = [(1000, [(1, 0, 0), (2, 1, 0), (1, 0, 0), (2, 1, 1), (3, 2, 0), (3, 2, 1), (3, 2, 2)]),
+            (1050, [(1, 0, 1), (2, 1, 1), (3, 2, 1)])] + far_dummies(100, 1050, 4, group=3)
+    save("probe_paired_end_rule", from_rows([rows]),
+         [case(4, 1000, 1, n) for n in NORMS])
+    # (6) read longer than max_fragment_length: flushed, then re-opened as a new read
+    rows = [(1000, [(1, 0, 0), (2, 1, 0)]), (1200, [(1, 0, 1), (5, 2, 1)]),
+            (1250, [(6, 2, 0)]), (1290, [(7, 2, 0)]), (1300, [(8, 2, 0)]),
+            (1400, [(1, 0, 2), (2, 1, 3), (9, 3, 2)]), (1500, [(1, 0, 0), (9, 3, 1)])] \
+        + far_dummies(100, 1500, 5, group=2, step=400)
+    save("probe_split_long_read", from_rows([rows]),
+         [case(4, 300, 1, "ADD_MIN"), case(4, 300, 2, "ADD_MIN"), case(4, 1000, 1, "ADD_MIN")])
+    # (7) group_id_to_pos remap: 6 group ids onto 3 matrix rows (same row => skipped pair)
+    rows = [(1000, [(1, 0, 0), (2, 1, 0), (3, 2, 1), (4, 3, 1), (5, 4, 2), (6, 5, 0)])] \
+        + far_dummies(100, 1000, 4, group=0)
+    g2p = np.asarray([0, 0, 1, 1, 2, 2], dtype=np.uint32)
+    save("probe_group_remap", from_rows([rows]), [case(3, 1000, 1, n, g2p=g2p) for n in NORMS])
+
+
+def kat_llr_table():
+    """D(x_s, x_d) = logP_diff - logP_same for small (x_s, x_d): 3 cells, reads of cells 0 and 1
+    share x_s matching and x_d mismatching loci, cell 2 stays empty, ADD_MIN:
+    D = M[0][2] - M[0][1] (both entries carry the same additive constant)."""
+    params = [(0.01, 0.5, 0.01), (0.01, 0.5, 0.001), (0.01, 0.15, 0.001), (0.01, 0.5, 0.05)]
+    combos = [(1, 0), (0, 1), (2, 0), (1, 1), (0, 2), (3, 1), (10, 0), (5, 5), (0, 8), (12, 3),
+              (20, 20), (30, 2)]
+    table = np.zeros((len(params), len(combos)), dtype=np.float64)
+    for pi, (eps, h, theta) in enumerate(params):
+        for ci, (xs, xd) in enumerate(combos):
+            rows = []
+            for k in range(xs + xd):
+                b1 = 0
+                b2 = 0 if k < xs else 1
+                rows.append((1000 + 3 * k, [(1, 0, b1), (2, 1, b2)]))
+            rows += far_dummies(100, 1000 + 3 * (xs + xd), 4, group=0)
+            p = from_rows([rows])
+            m = ob.ref_compute(p, 3, 1000, None, eps, h, theta, 1, "ADD_MIN")
+            table[pi, ci] = m[0, 2] - m[0, 1]
+    path = os.path.join(GOLDEN, "kat_llr_table.npz")
+    np.savez_compressed(path, params=np.asarray(params), combos=np.asarray(combos, dtype=np.uint32),
+                        table=table)
+    print("kat_llr_table: D(1,0)=%.15g D(0,1)=%.15g D(1,1)=%.15g (eps,h,theta)=(0.01,0.5,0.01)"
+          % (table[0, 0], table[0, 1], table[0, 3]))
+
+
+def reference_pileup_files():
+    data = os.path.join(GOLDEN, "data")
+    with tempfile.TemporaryDirectory() as tmp:
+        for f in os.listdir(data):
+            shutil.copy(os.path.join(data, f), tmp)
+
+        def read(name, merge_count=1, merge_file=""):
+            pos, off, rid, idb, ncell, mlen = ob.ref_read_pileup(
+                os.path.join(tmp, name), merge_count, merge_file)
+            return FlatPileup(np.asarray([0, len(pos)], dtype=np.uint32), pos, off, rid, idb), ncell, mlen
+
+        # ten_rows: real chr22 data, reads span several loci, 2208 cell ids -> identity grouping
+        p, _, mlen = read("ten_rows.pileup")
+        n = int((p.id_base >> 2).max()) + 1
+        save("ref_ten_rows", p,
+             [case(n, 1000, T, norm) for T in (1, 2) for norm in NORMS]
+             + [case(n, max(mlen, 2), 1, "ADD_MIN")], max_len=mlen)
+        # six_cells with merge_count=2 (3 groups) and with the .group file (2 groups)
+        p, _, _ = read("six_cells.pileup", merge_count=2)
+        save("ref_six_cells_merge2", p, [case(3, 1000, 1, norm) for norm in NORMS]
+             + [case(3, 50, 1, norm) for norm in NORMS])
+        p, _, _ = read("six_cells.pileup", merge_file=os.path.join(tmp, "six_cells.pileup.group"))
+        save("ref_six_cells_groupfile", p, [case(2, 1000, 1, norm) for norm in NORMS]
+             + [case(2, 50, 1, norm) for norm in NORMS])
+        p, _, _ = read("three_rows.pileup")
+        n = int((p.id_base >> 2).max()) + 1
+        save("ref_three_rows", p, [case(n, 1000, 1, norm) for norm in NORMS])
+
+
+def divide_clusters_shaped():
+    """Input shaped like the reference's only test that reaches the path
+    (tests/test_spectral_clustering.cpp:210-259): 100 cells, 5000 consecutive positions, all
+    read ids distinct, coverage per position uniform in 1..40, half of the positions split the
+    two 50-cell clones, 5% base errors; parameters of :201-207 (mfl 500, eps .01, h .5,
+    theta .05, T 4, ADD_MIN). The test's own generator uses libstdc++-specific distributions
+    and asserts labels only, so the input here is drawn with numpy and stored."""
+    rng = np.random.default_rng(20240607)
+    n_cells, n_pos = 100, 5000
+    pos, off, rid, idb = [], [0], [], []
+    next_id = 0
+    for x in range(n_pos):
+        cov = rng.integers(1, 41)
+        significant = rng.random() < 0.5
+        for cell in range(n_cells):
+            if rng.integers(1, 41) <= cov:
+                base = (0 if cell < n_cells // 2 else 1) if significant else 2
+                if rng.random() < 0.05:
+                    base = int(rng.integers(0, 4))
+                rid.append(next_id)
+                next_id += 1
+                idb.append((cell << 2) | base)
+        pos.append(x)
+        off.append(len(rid))
+    p = FlatPileup(np.asarray([0, n_pos], dtype=np.uint32), np.asarray(pos, dtype=np.uint32),
+                   np.asarray(off, dtype=np.uint64), np.asarray(rid, dtype=np.uint32),
+                   np.asarray(idb, dtype=np.uint32))
+    save("divide_clusters_shaped", p,
+         [case(n_cells, 500, 4, "ADD_MIN", theta=0.05), case(n_cells, 500, 1, "ADD_MIN", theta=0.05)])
+
+
+def random_cases():
+    # config 1 (BASELINE.json configs[0]): 64 cells x 2000 loci, 1 chromosome, sparse loci
+    p = random_pileup(101, 64, 1, 2000, 19, 2000)
+    save("config1_64cells", p, [case(64, 1000, T, "ADD_MIN") for T in (1, 4, 8)]
+         + [case(64, 1000, 8, "EXPONENTIATE"), case(64, 1000, 8, "SCALE_MAX_1")])
+    # clustered loci (most read pairs share >= 2 loci), duplicates/conflicts/triples, inserts,
+    # 2 chromosomes, reversed group map, flag-file rates
+    p = random_pileup(102, 40, 2, 500, 10, 250, dup_frac=0.05, triple_frac=0.3, skip_frac=0.2)
+    rev = np.arange(40, dtype=np.uint32)[::-1].copy()
+    save("clustered_40cells", p,
+         [case(40, 1000, T, norm, g2p=rev) for T in (1, 4) for norm in NORMS]
+         + [case(40, 300, T, "ADD_MIN", g2p=rev) for T in (1, 4)]
+         + [case(40, 1000, 8, "ADD_MIN", g2p=rev, h=0.15, theta=0.001)])
+    # very dense overlaps: long reads over tightly packed loci (x_s + x_d up to ~40)
+    p = random_pileup(103, 12, 1, 400, 6, 12, frag_min=200, frag_max=450, dup_frac=0.01)
+    save("dense_12cells", p, [case(12, 1000, 1, norm) for norm in NORMS]
+         + [case(12, 1000, 3, "ADD_MIN", theta=0.001)])
+
+
+def main():
+    if not ob.have_ref():
+        sys.exit("oracle/_ref/libsecedo_ref.so missing: run `make -C oracle ref` in the container")
+    os.makedirs(GOLDEN, exist_ok=True)
+    semantic_probes()
+    kat_llr_table()
+    reference_pileup_files()
+    divide_clusters_shaped()
+    random_cases()
+
+
+if __name__ == "__main__":
+    main()

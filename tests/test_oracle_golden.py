@@ -1,0 +1,52 @@
+"""The CPU oracle against the vectors generated from the compiled reference (CPU only)."""
+import numpy as np
+import pytest
+
+from oracle import bindings as ob
+from tests import golden_util as gu
+
+TOL = 1e-9  # norm-wise; the oracle actually lands at <= 1e-13
+
+
+@pytest.mark.parametrize("name", gu.fixture_names())
+def test_oracle_matches_reference_vectors(name):
+    p, cases = gu.load(name)
+    assert cases
+    for c in cases:
+        got = ob.oracle_compute(p, c["num_cells"], c["mfl"], c["g2p"], c["eps"], c["h"], c["theta"],
+                                c["T"], c["norm"])
+        ref = c["out"]
+        assert got.shape == ref.shape
+        assert gu.normwise_err(got, ref) <= 1e-12, (name, c["T"], c["norm"])
+        assert np.array_equal(got, got.T, equal_nan=True)
+        assert np.all(np.diag(got) == 0)
+
+
+def test_oracle_llr_kat_table():
+    """D(x_s,x_d) read off reference matrices vs the oracle's restated formulas."""
+    z = np.load(gu.GOLDEN + "/kat_llr_table.npz")
+    for pi, (eps, h, theta) in enumerate(z["params"]):
+        for ci, (xs, xd) in enumerate(z["combos"]):
+            d = ob.oracle_log_prob_diff(int(xs), int(xd), eps, h, theta) \
+                - ob.oracle_log_prob_same(int(xs), int(xd), eps, h, theta)
+            assert abs(d - z["table"][pi, ci]) <= 1e-12 * max(1.0, abs(d)), (eps, h, theta, xs, xd)
+
+
+def test_probe_facts():
+    """tail drop, thread-count dependence, joint multi-locus term."""
+    p, cases = gu.load("probe_single_locus")
+    assert np.all(cases[0]["out"] == 0)  # ADD_MIN of an all-zero D
+    assert np.all(cases[1]["out"][~np.eye(4, dtype=bool)] == 0.5)  # EXPONENTIATE
+    p, cases = gu.load("probe_flush_T1_vs_T2")
+    t1, t2 = cases[0]["out"], cases[3]["out"]
+    assert np.any(t1 != 0) and np.all(t2 == 0)
+    p, cases = gu.load("probe_multi_locus_pair")
+    expo = cases[1]["out"]
+    d01 = np.log(1.0 / expo[0, 1] - 1.0)
+    assert abs(d01 - 0.0171106405755368) < 1e-9  # D(1,1), not D(1,0)+D(0,1)
+
+
+def test_invalid_normalization():
+    p, cases = gu.load("probe_single_locus")
+    with pytest.raises(ValueError):
+        ob.oracle_compute(p, 4, 1000, None, 0.01, 0.5, 0.01, 1, "BOGUS")
