@@ -1,0 +1,162 @@
+/*
+ * secedo_simmat.h -- C-ABI of the MI355X similarity-matrix path.
+ *
+ * Drop-in boundary for the reference's
+ *     Matd computeSimilarityMatrix(pos_data, num_cells, max_fragment_length, group_id_to_pos,
+ *                                  mutation_rate, homozygous_rate, seq_error_rate, num_threads,
+ *                                  marker, normalization)
+ * (reference: similarity_matrix.hpp:51-60, implementation similarity_matrix.cpp:295-433, sole
+ * caller spectral_clustering.cpp:354-356). Plain pointers and sizes only; no C++ or torch types.
+ * include/secedo_simmat.hpp keeps the C++ signature on top of these entry points, and
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Flat pileup layout (replaces std::vector<std::vector<PosData>>, sequenced_data.hpp:11-47):
+ *   chr_locus_off[n_chr+1]  loci of chromosome c are [chr_locus_off[c], chr_locus_off[c+1])
+ *   locus_pos[L]            PosData::position                      (sequenced_data.hpp:26)
+ *   locus_entry_off[L+1]    entries of locus l are [off[l], off[l+1])
+ *   read_ids[E]             PosData::read_ids                      (sequenced_data.hpp:28)
+ *   id_base16[E]            PosData::group_ids_bases, group_id<<2|base in 16 bits (:29-37), OR
+ *   id_base32[E]            the same packing in 32 bits for more than 16383 groups
+ *                           (exactly one of the two pointers is non-NULL)
+ *
+ * Every function returns SECEDO_OK (0) or a negative SECEDO_E_* code; the message of the last
+ * error on the calling thread is available from secedo_simmat_last_error().
+ * There is no CPU fallback: without a usable HIP device every compute entry point fails with
+ * SECEDO_E_NO_DEVICE.
+ */
+#ifndef SECEDO_SIMMAT_H
+#define SECEDO_SIMMAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SECEDO_OK 0
+#define SECEDO_E_INVALID_ARG (-1)
+#define SECEDO_E_INVALID_NORMALIZATION (-2) /* reference: std::logic_error, similarity_matrix.cpp:264 */
+#define SECEDO_E_NO_DEVICE (-3)
+#define SECEDO_E_HIP (-4)
+#define SECEDO_E_STATE (-5)
+#define SECEDO_E_LIMIT (-6)
+
+/* enum class Normalization (reference: similarity_matrix.hpp:9-17) */
+#define SECEDO_NORM_ADD_MIN 0
+#define SECEDO_NORM_EXPONENTIATE 1
+#define SECEDO_NORM_SCALE_MAX_1 2
+
+/* to_enum (reference: similarity_matrix.cpp:256-266): "ADD_MIN" | "EXPONENTIATE" | "SCALE_MAX_1"
+ * -> SECEDO_NORM_*, anything else -> SECEDO_E_INVALID_NORMALIZATION. */
+int secedo_simmat_normalization_from_string(const char *name);
+
+const char *secedo_simmat_last_error(void);
+const char *secedo_simmat_version(void);
+/* Number of HIP devices visible to this process (0 when there is none; never fails). */
+int secedo_simmat_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * One-shot entry point: host buffers in, host matrix out. This is what the C++ shim calls.
+ * Replaces computeSimilarityMatrix (similarity_matrix.cpp:295-433) including normalize
+ * (:271-293). `out` is caller-allocated, num_cells*num_cells doubles, row-major (the layout of
+ * Mat<double>, util/mat.hpp:17-37). num_threads is the reference's num_threads: it does not
+ * set any parallelism here, it is the semantic input of the flush rule (similarity_matrix.cpp:
+ * 354-356: a batch of completed reads is compared once 4*num_threads of them are complete).
+ * Uses device SECEDO_DEVICE (env, default 0).
+ * ---------------------------------------------------------------------------------------- */
+int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const uint32_t *locus_pos,
+                          const uint64_t *locus_entry_off, const uint32_t *read_ids,
+                          const uint16_t *id_base16, const uint32_t *id_base32,
+                          const uint32_t *group_id_to_pos, uint32_t n_groups, uint32_t num_cells,
+                          uint32_t max_fragment_length, double mutation_rate,
+                          double homozygous_rate, double seq_error_rate, uint32_t num_threads,
+                          int normalization, double *out);
+
+/* ------------------------------------------------------------------------------------------
+ * Staged interface (device-resident data, explicit stream, tile partition for multi-GPU).
+ *
+ *   create -> set_pileup -> prepare -> [accumulate -> finalize]* -> destroy
+ *
+ * prepare()    read assembly (similarity_matrix.cpp:376-403), flush schedule and tail rule
+ *              (:342-373, :407-408), packing into cell-block tiles, upload to HBM.
+ * accumulate() the pair enumeration of compare_with_reads (:189-243) + apply_updates (:246-254)
+ *              for the tiles [tile_begin, tile_end) into a tile-major int64 fixed-point
+ *              accumulator in HBM (d_acc, secedo_simmat_acc_elems() elements, device pointer).
+ *              Tiles outside the range are left untouched (zero them first: see zero_acc).
+ * finalize()   mat_diff - mat_same (:428) + normalize (:271-293): accumulator -> dense
+ *              num_cells x num_cells fp64 matrix in HBM (d_out, device pointer).
+ * `stream` is a hipStream_t (NULL = the default stream); calls only enqueue work unless noted.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct secedo_simmat secedo_simmat_t;
+
+int secedo_simmat_create(secedo_simmat_t **handle, int device_id);
+void secedo_simmat_destroy(secedo_simmat_t *handle);
+
+/* Borrows the host arrays until secedo_simmat_prepare() returns. */
+int secedo_simmat_set_pileup(secedo_simmat_t *handle, const uint32_t *chr_locus_off, uint32_t n_chr,
+                             const uint32_t *locus_pos, const uint64_t *locus_entry_off,
+                             const uint32_t *read_ids, const uint16_t *id_base16,
+                             const uint32_t *id_base32, const uint32_t *group_id_to_pos,
+                             uint32_t n_groups);
+
+/* Synchronous (host work + H2D). block_cells: cells per tile edge, 0 = choose (64 or 128). */
+int secedo_simmat_prepare(secedo_simmat_t *handle, uint32_t num_cells, uint32_t max_fragment_length,
+                          uint32_t num_threads, uint32_t block_cells);
+
+/* Geometry after prepare(). Tiles are the upper-triangular (I <= J) cell-block pairs. */
+uint32_t secedo_simmat_num_tiles(const secedo_simmat_t *handle);
+uint32_t secedo_simmat_block_cells(const secedo_simmat_t *handle);
+uint64_t secedo_simmat_acc_elems(const secedo_simmat_t *handle); /* num_tiles * block_cells^2 */
+/* Work counters of the prepared pileup: kept entries, live reads (segments), loci. */
+uint64_t secedo_simmat_num_entries(const secedo_simmat_t *handle);
+uint64_t secedo_simmat_num_reads(const secedo_simmat_t *handle);
+uint64_t secedo_simmat_num_loci(const secedo_simmat_t *handle);
+
+int secedo_simmat_zero_acc(secedo_simmat_t *handle, int64_t *d_acc, void *stream);
+int secedo_simmat_accumulate(secedo_simmat_t *handle, double mutation_rate, double homozygous_rate,
+                             double seq_error_rate, uint32_t tile_begin, uint32_t tile_end,
+                             int64_t *d_acc, void *stream);
+int secedo_simmat_finalize(secedo_simmat_t *handle, int normalization, const int64_t *d_acc,
+                           double *d_out, void *stream);
+/* Same as finalize with SECEDO_NORM_*, but writes the un-normalised D = logP_diff - logP_same
+ * (similarity_matrix.cpp:428), mirrored to both triangles, zero diagonal. For parity checks. */
+int secedo_simmat_finalize_raw(secedo_simmat_t *handle, const int64_t *d_acc, double *d_out,
+                               void *stream);
+
+/* Counters of the last accumulate() on this handle, read back after synchronising the stream:
+ * updates = (read pair, shared locus) incidences examined, read_pairs = pairs that contributed
+ * one log-likelihood-ratio term. Synchronises the device. */
+int secedo_simmat_last_counts(secedo_simmat_t *handle, uint64_t *updates, uint64_t *read_pairs);
+/* Device time of the accumulate kernel of the last accumulate() call, measured with hipEvents
+ * on the stream it ran on. Synchronises on the end event. */
+int secedo_simmat_last_accumulate_ms(secedo_simmat_t *handle, float *ms);
+
+/* log-likelihood ratio D(x_s, x_d) = log P(x_s,x_d | different) - log P(x_s,x_d | same) as the
+ * device tables hold it (closed form of similarity_matrix.cpp:117-170; host-only, no device). */
+double secedo_simmat_llr(uint32_t x_s, uint32_t x_d, double mutation_rate, double homozygous_rate,
+                         double seq_error_rate);
+
+/* ------------------------------------------------------------------------------------------
+ * SYNTH-v1 synthetic pileup generator: bench and test utility, host only.
+ * Call with all output pointers NULL to obtain the sizes, then again with buffers.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct secedo_synth_spec {
+    uint32_t num_cells;
+    uint32_t num_loci;
+    uint32_t num_chromosomes;
+    uint32_t gap_max;      /* locus gaps are 1 + rng % gap_max */
+    double new_frag_prob;  /* per cell and locus probability of a new fragment (p) */
+    uint32_t frag_min, frag_max;
+    double base_error;     /* i.i.d. sequencing error */
+    double mate_frac;      /* fraction of fragments with a second mate entry */
+    uint64_t seed;
+} secedo_synth_spec;
+
+int secedo_synth_generate(const secedo_synth_spec *spec, uint64_t *n_loci, uint64_t *n_entries,
+                          uint32_t *chr_locus_off, uint32_t *locus_pos, uint64_t *locus_entry_off,
+                          uint32_t *read_ids, uint32_t *id_base32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SECEDO_SIMMAT_H */

@@ -1,0 +1,8 @@
+"""secedo_amd -- MI355X-native similarity-matrix path of SECEDO (computeSimilarityMatrix).
+
+Only what the path needs: the HIP kernels + C-ABI (csrc/, include/secedo_simmat.h) and the
+host-side mirror of the reference interface (similarity_matrix.py).
+"""
+from .pileup import FlatPileup, PosData, flatten  # noqa: F401
+from .similarity_matrix import (InvalidNormalization, NORMALIZATIONS, SecedoError,  # noqa: F401
+                                SimilarityMatrixPlan, compute_similarity_matrix, llr, to_enum)

@@ -1,0 +1,377 @@
+// simmat_api.cpp -- implementation of the C-ABI declared in include/secedo_simmat.h.
+//
+// Host orchestration only: argument checks, host packing (pack_host.cpp), HBM buffers, kernel
+// launches (simmat_kernels.hip). There is deliberately no CPU compute path in here: if no HIP
+// device is usable the entry points fail with SECEDO_E_NO_DEVICE.
+#include "secedo_simmat.h"
+
+#include "llr_table.hpp"
+#include "pack_host.hpp"
+#include "simmat_kernels.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    return fail(SECEDO_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                        \
+    do {                                                     \
+        hipError_t e__ = (expr);                             \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr);  \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes && p) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&p, n ? n : 16);
+        if (e == hipSuccess) bytes = n ? n : 16;
+        return e;
+    }
+    template <class T>
+    hipError_t upload(const std::vector<T> &v) {
+        hipError_t e = ensure(v.size() * sizeof(T));
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    template <class T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
+}  // namespace
+
+struct secedo_simmat {
+    int device = 0;
+    secedo::FlatPileupView view;
+    bool have_pileup = false;
+    bool prepared = false;
+
+    // geometry
+    uint32_t num_cells = 0, block_cells = 0, num_blocks = 0, num_tiles = 0, num_loci = 0;
+    uint64_t num_entries = 0, num_reads = 0, pair_bound = 0;
+
+    // HBM
+    DevBuf blk_off, entry_a, entry_b, read_off, read_locus, read_base, tile_row, tile_col, lut,
+            counters, max_bits;
+    DevBuf own_acc, own_out;  // used by the one-shot entry point only
+
+    // LLR table of the last accumulate()
+    bool have_lut = false;
+    double lut_eps = 0, lut_h = 0, lut_theta = 0;
+    int scale_log2 = 44;
+    secedo::LlrModel model;
+
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool timed = false;
+};
+
+extern "C" {
+
+const char *secedo_simmat_last_error(void) { return g_last_error.c_str(); }
+
+const char *secedo_simmat_version(void) { return "secedo-simmat-mi355x 0.1 (gfx950)"; }
+
+int secedo_simmat_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int secedo_simmat_normalization_from_string(const char *name) {
+    if (name) {
+        if (!std::strcmp(name, "ADD_MIN")) return SECEDO_NORM_ADD_MIN;
+        if (!std::strcmp(name, "EXPONENTIATE")) return SECEDO_NORM_EXPONENTIATE;
+        if (!std::strcmp(name, "SCALE_MAX_1")) return SECEDO_NORM_SCALE_MAX_1;
+    }
+    return fail(SECEDO_E_INVALID_NORMALIZATION,
+                std::string("Invalid normalization: ") + (name ? name : "(null)"));
+}
+
+double secedo_simmat_llr(uint32_t x_s, uint32_t x_d, double eps, double h, double theta) {
+    return secedo::llr(secedo::make_llr_model(eps, h, theta), x_s, x_d);
+}
+
+int secedo_simmat_create(secedo_simmat_t **handle, int device_id) {
+    if (!handle) return fail(SECEDO_E_INVALID_ARG, "handle is null");
+    *handle = nullptr;
+    const int n = secedo_simmat_device_count();
+    if (n <= 0) return fail(SECEDO_E_NO_DEVICE, "no HIP device is visible: the similarity-matrix path has no CPU fallback");
+    if (device_id < 0 || device_id >= n) return fail(SECEDO_E_NO_DEVICE, "device id out of range");
+    HIP_TRY(hipSetDevice(device_id));
+    secedo_simmat *h = new (std::nothrow) secedo_simmat();
+    if (!h) return fail(SECEDO_E_LIMIT, "out of host memory");
+    h->device = device_id;
+    hipError_t e = hipEventCreate(&h->ev_begin);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_end);
+    if (e != hipSuccess) {
+        delete h;
+        return hip_fail(e, "hipEventCreate");
+    }
+    *handle = h;
+    return SECEDO_OK;
+}
+
+void secedo_simmat_destroy(secedo_simmat_t *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    delete h;
+}
+
+int secedo_simmat_set_pileup(secedo_simmat_t *h, const uint32_t *chr_locus_off, uint32_t n_chr,
+                             const uint32_t *locus_pos, const uint64_t *locus_entry_off,
+                             const uint32_t *read_ids, const uint16_t *id_base16,
+                             const uint32_t *id_base32, const uint32_t *group_id_to_pos,
+                             uint32_t n_groups) {
+    if (!h) return fail(SECEDO_E_INVALID_ARG, "handle is null");
+    if (!chr_locus_off || !locus_entry_off) return fail(SECEDO_E_INVALID_ARG, "null offset arrays");
+    if ((id_base16 != nullptr) == (id_base32 != nullptr))
+        return fail(SECEDO_E_INVALID_ARG, "exactly one of id_base16 / id_base32 must be given");
+    if (!group_id_to_pos && n_groups) return fail(SECEDO_E_INVALID_ARG, "group_id_to_pos is null");
+    h->view.chr_locus_off = chr_locus_off;
+    h->view.n_chr = n_chr;
+    h->view.locus_pos = locus_pos;
+    h->view.locus_entry_off = locus_entry_off;
+    h->view.read_ids = read_ids;
+    h->view.id_base16 = id_base16;
+    h->view.id_base32 = id_base32;
+    h->view.group_id_to_pos = group_id_to_pos;
+    h->view.n_groups = n_groups;
+    h->have_pileup = true;
+    h->prepared = false;
+    return SECEDO_OK;
+}
+
+int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_fragment_length,
+                          uint32_t num_threads, uint32_t block_cells) {
+    if (!h) return fail(SECEDO_E_INVALID_ARG, "handle is null");
+    if (!h->have_pileup) return fail(SECEDO_E_STATE, "set_pileup was not called");
+    if (block_cells == 0) block_cells = num_cells >= 4096 ? 128 : 64;
+    HIP_TRY(hipSetDevice(h->device));
+
+    secedo::PackedPileup pk;
+    const std::string err = secedo::pack_pileup(h->view, num_cells, max_fragment_length,
+                                                num_threads, block_cells, &pk);
+    h->have_pileup = false;  // the borrow ends here
+    if (!err.empty()) return fail(SECEDO_E_INVALID_ARG, err);
+
+    h->num_cells = num_cells;
+    h->block_cells = block_cells;
+    h->num_blocks = pk.num_blocks;
+    h->num_loci = pk.num_loci;
+    h->num_entries = pk.num_entries;
+    h->num_reads = pk.num_reads;
+    h->pair_bound = pk.pair_bound;
+    h->num_tiles = pk.num_blocks * (pk.num_blocks + 1) / 2;
+
+    std::vector<uint16_t> trow, tcol;
+    trow.reserve(h->num_tiles);
+    tcol.reserve(h->num_tiles);
+    for (uint32_t i = 0; i < pk.num_blocks; ++i) {
+        for (uint32_t j = i; j < pk.num_blocks; ++j) {
+            trow.push_back(static_cast<uint16_t>(i));
+            tcol.push_back(static_cast<uint16_t>(j));
+        }
+    }
+    HIP_TRY(h->blk_off.upload(pk.blk_off));
+    HIP_TRY(h->entry_a.upload(pk.entry_a));
+    HIP_TRY(h->entry_b.upload(pk.entry_b));
+    HIP_TRY(h->read_off.upload(pk.read_off));
+    HIP_TRY(h->read_locus.upload(pk.read_locus));
+    HIP_TRY(h->read_base.upload(pk.read_base));
+    HIP_TRY(h->tile_row.upload(trow));
+    HIP_TRY(h->tile_col.upload(tcol));
+    HIP_TRY(h->counters.ensure(2 * sizeof(unsigned long long)));
+    HIP_TRY(h->max_bits.ensure(sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->counters.p, 0, 2 * sizeof(unsigned long long)));
+    h->have_lut = false;
+    h->prepared = true;
+    h->timed = false;
+    return SECEDO_OK;
+}
+
+uint32_t secedo_simmat_num_tiles(const secedo_simmat_t *h) { return h ? h->num_tiles : 0; }
+uint32_t secedo_simmat_block_cells(const secedo_simmat_t *h) { return h ? h->block_cells : 0; }
+uint64_t secedo_simmat_acc_elems(const secedo_simmat_t *h) {
+    return h ? static_cast<uint64_t>(h->num_tiles) * h->block_cells * h->block_cells : 0;
+}
+uint64_t secedo_simmat_num_entries(const secedo_simmat_t *h) { return h ? h->num_entries : 0; }
+uint64_t secedo_simmat_num_reads(const secedo_simmat_t *h) { return h ? h->num_reads : 0; }
+uint64_t secedo_simmat_num_loci(const secedo_simmat_t *h) { return h ? h->num_loci : 0; }
+
+int secedo_simmat_zero_acc(secedo_simmat_t *h, int64_t *d_acc, void *stream) {
+    if (!h || !d_acc) return fail(SECEDO_E_INVALID_ARG, "null argument");
+    if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemsetAsync(d_acc, 0, secedo_simmat_acc_elems(h) * sizeof(int64_t),
+                           static_cast<hipStream_t>(stream)));
+    return SECEDO_OK;
+}
+
+int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double theta,
+                             uint32_t tile_begin, uint32_t tile_end, int64_t *d_acc, void *stream) {
+    if (!h || !d_acc) return fail(SECEDO_E_INVALID_ARG, "null argument");
+    if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
+    if (tile_begin > tile_end || tile_end > h->num_tiles)
+        return fail(SECEDO_E_INVALID_ARG, "tile range outside [0, num_tiles]");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    if (!h->have_lut || h->lut_eps != eps || h->lut_h != hr || h->lut_theta != theta) {
+        const secedo::LlrTable t = secedo::make_llr_table(eps, hr, theta, h->pair_bound);
+        HIP_TRY(h->lut.ensure(t.fixed.size() * sizeof(int64_t)));
+        // pageable-memory copy on the same stream: complete before it returns
+        HIP_TRY(hipMemcpyAsync(h->lut.p, t.fixed.data(), t.fixed.size() * sizeof(int64_t),
+                               hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        h->model = t.model;
+        h->scale_log2 = t.scale_log2;
+        h->lut_eps = eps;
+        h->lut_h = hr;
+        h->lut_theta = theta;
+        h->have_lut = true;
+    }
+
+    const uint32_t n_tiles = tile_end - tile_begin;
+    secedo::AccumulateArgs a;
+    a.blk_off = h->blk_off.as<uint32_t>();
+    a.stride = h->num_loci + 1;
+    a.num_loci = h->num_loci;
+    a.entry_a = h->entry_a.as<uint4>();
+    a.entry_b = h->entry_b.as<uint4>();
+    a.read_off = h->read_off.as<uint32_t>();
+    a.read_locus = h->read_locus.as<uint32_t>();
+    a.read_base = h->read_base.as<uint8_t>();
+    a.tile_row = h->tile_row.as<uint16_t>();
+    a.tile_col = h->tile_col.as<uint16_t>();
+    a.tile_begin = tile_begin;
+    // enough workgroups to fill 256 CUs several times over; a chunk is never shorter than 64 loci
+    uint32_t chunks = 1;
+    if (n_tiles && n_tiles < 2048) chunks = (2048 + n_tiles - 1) / n_tiles;
+    const uint32_t max_chunks = h->num_loci / 64 ? h->num_loci / 64 : 1;
+    if (chunks > max_chunks) chunks = max_chunks;
+    a.n_chunks = chunks;
+    a.chunk_loci = (h->num_loci + chunks - 1) / chunks;
+    if (a.chunk_loci == 0) a.chunk_loci = 1;
+    a.lut = h->lut.as<long long>();
+    a.model = secedo::LlrModelDev{h->model.ln_u1, h->model.ln_v1, h->model.ln_u2, h->model.ln_v2,
+                                  h->model.ln_w1, h->model.ln_z1, h->model.ln_w2, h->model.ln_z2};
+    a.scale_log2 = h->scale_log2;
+    a.acc = d_acc;
+    a.counters = h->counters.as<unsigned long long>();
+
+    HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(unsigned long long), s));
+    HIP_TRY(hipEventRecord(h->ev_begin, s));
+    HIP_TRY(secedo::launch_accumulate(a, h->block_cells, n_tiles, s));
+    HIP_TRY(hipEventRecord(h->ev_end, s));
+    h->timed = true;
+    return SECEDO_OK;
+}
+
+static int finalize_mode(secedo_simmat_t *h, int mode, const int64_t *d_acc, double *d_out, void *stream) {
+    if (!h || !d_acc || !d_out) return fail(SECEDO_E_INVALID_ARG, "null argument");
+    if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
+    if (!h->have_lut) return fail(SECEDO_E_STATE, "accumulate was not called");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(secedo::launch_finalize(d_acc, h->num_cells, h->num_blocks, h->block_cells, h->scale_log2,
+                                    mode, h->max_bits.as<unsigned long long>(), d_out,
+                                    static_cast<hipStream_t>(stream)));
+    return SECEDO_OK;
+}
+
+int secedo_simmat_finalize(secedo_simmat_t *h, int normalization, const int64_t *d_acc, double *d_out,
+                           void *stream) {
+    if (normalization < 0 || normalization > 2)
+        return fail(SECEDO_E_INVALID_NORMALIZATION, "Invalid normalization: " + std::to_string(normalization));
+    return finalize_mode(h, normalization, d_acc, d_out, stream);
+}
+
+int secedo_simmat_finalize_raw(secedo_simmat_t *h, const int64_t *d_acc, double *d_out, void *stream) {
+    return finalize_mode(h, 3, d_acc, d_out, stream);
+}
+
+int secedo_simmat_last_counts(secedo_simmat_t *h, uint64_t *updates, uint64_t *read_pairs) {
+    if (!h) return fail(SECEDO_E_INVALID_ARG, "handle is null");
+    if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long c[2] = {0, 0};
+    HIP_TRY(hipMemcpy(c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+    if (updates) *updates = c[0];
+    if (read_pairs) *read_pairs = c[1];
+    return SECEDO_OK;
+}
+
+int secedo_simmat_last_accumulate_ms(secedo_simmat_t *h, float *ms) {
+    if (!h || !ms) return fail(SECEDO_E_INVALID_ARG, "null argument");
+    if (!h->timed) return fail(SECEDO_E_STATE, "accumulate was not called");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventSynchronize(h->ev_end));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev_begin, h->ev_end));
+    return SECEDO_OK;
+}
+
+int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const uint32_t *locus_pos,
+                          const uint64_t *locus_entry_off, const uint32_t *read_ids,
+                          const uint16_t *id_base16, const uint32_t *id_base32,
+                          const uint32_t *group_id_to_pos, uint32_t n_groups, uint32_t num_cells,
+                          uint32_t max_fragment_length, double mutation_rate, double homozygous_rate,
+                          double seq_error_rate, uint32_t num_threads, int normalization, double *out) {
+    if (normalization < 0 || normalization > 2)
+        return fail(SECEDO_E_INVALID_NORMALIZATION, "Invalid normalization: " + std::to_string(normalization));
+    if (!out) return fail(SECEDO_E_INVALID_ARG, "out is null");
+    int device = 0;
+    if (const char *env = std::getenv("SECEDO_DEVICE")) device = std::atoi(env);
+    secedo_simmat_t *h = nullptr;
+    int rc = secedo_simmat_create(&h, device);
+    if (rc != SECEDO_OK) return rc;
+    struct Guard {
+        secedo_simmat_t *h;
+        ~Guard() { secedo_simmat_destroy(h); }
+    } guard{h};
+    rc = secedo_simmat_set_pileup(h, chr_locus_off, n_chr, locus_pos, locus_entry_off, read_ids,
+                                  id_base16, id_base32, group_id_to_pos, n_groups);
+    if (rc != SECEDO_OK) return rc;
+    rc = secedo_simmat_prepare(h, num_cells, max_fragment_length, num_threads, 0);
+    if (rc != SECEDO_OK) return rc;
+    HIP_TRY(h->own_acc.ensure(secedo_simmat_acc_elems(h) * sizeof(int64_t)));
+    const size_t out_bytes = static_cast<size_t>(num_cells) * num_cells * sizeof(double);
+    HIP_TRY(h->own_out.ensure(out_bytes));
+    rc = secedo_simmat_zero_acc(h, h->own_acc.as<int64_t>(), nullptr);
+    if (rc != SECEDO_OK) return rc;
+    rc = secedo_simmat_accumulate(h, mutation_rate, homozygous_rate, seq_error_rate, 0,
+                                  secedo_simmat_num_tiles(h), h->own_acc.as<int64_t>(), nullptr);
+    if (rc != SECEDO_OK) return rc;
+    rc = secedo_simmat_finalize(h, normalization, h->own_acc.as<int64_t>(), h->own_out.as<double>(), nullptr);
+    if (rc != SECEDO_OK) return rc;
+    HIP_TRY(hipMemcpy(out, h->own_out.p, out_bytes, hipMemcpyDeviceToHost));
+    return SECEDO_OK;
+}
+
+}  // extern "C"

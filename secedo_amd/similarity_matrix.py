@@ -1,0 +1,206 @@
+"""Host-side mirror of the reference's similarity-matrix interface, on top of the C-ABI.
+
+``compute_similarity_matrix`` keeps the name, argument order, argument meaning and error
+behaviour of the reference's ``computeSimilarityMatrix`` (reference: similarity_matrix.hpp:51-60);
+``SimilarityMatrixPlan`` exposes the staged device-resident interface (prepare once, accumulate a
+tile range, finalize) that bench.py and the multi-GPU driver use. All arithmetic happens in
+libsecedo_simmat.so on the GPU; this module only moves arrays and pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import InvalidNormalization, SecedoError  # noqa: F401  (re-exported)
+from .pileup import FlatPileup, PosData, flatten
+
+NORMALIZATIONS = ("ADD_MIN", "EXPONENTIATE", "SCALE_MAX_1")  # similarity_matrix.hpp:9-17
+
+
+def to_enum(normalization: str) -> int:
+    """reference: to_enum, similarity_matrix.cpp:256-266."""
+    if not isinstance(normalization, str):
+        raise InvalidNormalization("Invalid normalization: %r" % (normalization,))
+    rc = _lib.lib().secedo_simmat_normalization_from_string(normalization.encode())
+    if rc < 0:
+        raise InvalidNormalization("Invalid normalization: " + normalization)
+    return rc
+
+
+def _as_flat(pos_data) -> FlatPileup:
+    if isinstance(pos_data, FlatPileup):
+        return pos_data
+    return flatten(pos_data)
+
+
+def _id_arrays(p: FlatPileup):
+    """(id_base16, id_base32): the reference's u16 packing when every id fits 14 bits."""
+    if p.n_entries == 0 or int(p.id_base.max()) <= 0xFFFF:
+        return np.ascontiguousarray(p.id_base.astype(np.uint16)), None
+    return None, p.id_base
+
+
+def compute_similarity_matrix(pos_data: Union[FlatPileup, Sequence[Sequence[PosData]]],
+                              num_cells: int,
+                              max_fragment_length: int,
+                              group_id_to_pos: Optional[Sequence[int]],
+                              mutation_rate: float,
+                              homozygous_rate: float,
+                              seq_error_rate: float,
+                              num_threads: int,
+                              marker: str = "",
+                              normalization: str = "ADD_MIN") -> np.ndarray:
+    """num_cells x num_cells float64 similarity matrix (symmetric, zero diagonal).
+
+    Same contract as the reference function: ``num_threads`` is the reference's thread count and
+    matters only through the flush threshold 4*num_threads (similarity_matrix.cpp:354-356);
+    ``marker`` is unused there (similarity_matrix.cpp:303) and here; an unknown ``normalization``
+    raises InvalidNormalization (std::logic_error in the reference, :264).
+    """
+    del marker
+    norm = to_enum(normalization)
+    p = _as_flat(pos_data)
+    g2p = np.arange(num_cells, dtype=np.uint32) if group_id_to_pos is None \
+        else np.ascontiguousarray(group_id_to_pos, dtype=np.uint32)
+    id16, id32 = _id_arrays(p)
+    out = np.empty((num_cells, num_cells), dtype=np.float64)
+    rc = _lib.lib().secedo_simmat_compute(
+        _lib.ptr(p.chr_locus_off), p.n_chr, _lib.ptr(p.locus_pos), _lib.ptr(p.locus_entry_off),
+        _lib.ptr(p.read_ids), _lib.ptr(id16), _lib.ptr(id32), _lib.ptr(g2p), len(g2p), num_cells,
+        max_fragment_length, mutation_rate, homozygous_rate, seq_error_rate, num_threads, norm,
+        _lib.ptr(out))
+    _lib.check(rc)
+    return out
+
+
+def llr(x_s: int, x_d: int, mutation_rate: float, homozygous_rate: float,
+        seq_error_rate: float) -> float:
+    """D(x_s, x_d) = log P_diff - log P_same as the device tables hold it (host-only)."""
+    return float(_lib.lib().secedo_simmat_llr(x_s, x_d, mutation_rate, homozygous_rate, seq_error_rate))
+
+
+class SimilarityMatrixPlan:
+    """Staged interface: device-resident packed pileup, explicit stream, tile ranges.
+
+    Device memory for the accumulator and the output matrix comes from torch (plumbing only);
+    the kernels run on torch's current stream.
+    """
+
+    def __init__(self, device: int = 0):
+        import torch
+        self._torch = torch
+        self.device = device
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().secedo_simmat_create(C.byref(self._h), device))
+        self.num_cells = 0
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            _lib.lib().secedo_simmat_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- prepare ---------------------------------------------------------------------------
+    def prepare(self, pos_data, num_cells, max_fragment_length, group_id_to_pos=None,
+                num_threads=8, block_cells=0):
+        p = _as_flat(pos_data)
+        g2p = np.arange(num_cells, dtype=np.uint32) if group_id_to_pos is None \
+            else np.ascontiguousarray(group_id_to_pos, dtype=np.uint32)
+        id16, id32 = _id_arrays(p)
+        L = _lib.lib()
+        _lib.check(L.secedo_simmat_set_pileup(
+            self._h, _lib.ptr(p.chr_locus_off), p.n_chr, _lib.ptr(p.locus_pos),
+            _lib.ptr(p.locus_entry_off), _lib.ptr(p.read_ids), _lib.ptr(id16), _lib.ptr(id32),
+            _lib.ptr(g2p), len(g2p)))
+        _lib.check(L.secedo_simmat_prepare(self._h, num_cells, max_fragment_length, num_threads,
+                                           block_cells))
+        self.num_cells = num_cells
+        return self
+
+    @property
+    def num_tiles(self) -> int:
+        return int(_lib.lib().secedo_simmat_num_tiles(self._h))
+
+    @property
+    def block_cells(self) -> int:
+        return int(_lib.lib().secedo_simmat_block_cells(self._h))
+
+    @property
+    def acc_elems(self) -> int:
+        return int(_lib.lib().secedo_simmat_acc_elems(self._h))
+
+    @property
+    def num_entries(self) -> int:
+        return int(_lib.lib().secedo_simmat_num_entries(self._h))
+
+    @property
+    def num_reads(self) -> int:
+        return int(_lib.lib().secedo_simmat_num_reads(self._h))
+
+    @property
+    def num_loci(self) -> int:
+        return int(_lib.lib().secedo_simmat_num_loci(self._h))
+
+    # -- device work -----------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def new_acc(self, pad_tiles_to: int = 1):
+        """int64 accumulator tensor; padded to a multiple of pad_tiles_to tiles (all-gather)."""
+        b2 = self.block_cells ** 2
+        tiles = -(-self.num_tiles // pad_tiles_to) * pad_tiles_to
+        return self._torch.zeros(tiles * b2, dtype=self._torch.int64, device="cuda:%d" % self.device)
+
+    def zero_acc(self, acc):
+        _lib.check(_lib.lib().secedo_simmat_zero_acc(self._h, C.c_void_p(acc.data_ptr()), self._stream()))
+
+    def accumulate(self, acc, mutation_rate, homozygous_rate, seq_error_rate, tile_begin=0,
+                   tile_end=None):
+        tile_end = self.num_tiles if tile_end is None else tile_end
+        assert acc.dtype == self._torch.int64 and acc.is_contiguous() and acc.numel() >= self.acc_elems
+        _lib.check(_lib.lib().secedo_simmat_accumulate(
+            self._h, mutation_rate, homozygous_rate, seq_error_rate, tile_begin, tile_end,
+            C.c_void_p(acc.data_ptr()), self._stream()))
+
+    def finalize(self, acc, normalization="ADD_MIN", out=None):
+        norm = to_enum(normalization)
+        if out is None:
+            out = self._torch.empty((self.num_cells, self.num_cells), dtype=self._torch.float64,
+                                    device="cuda:%d" % self.device)
+        assert out.dtype == self._torch.float64 and out.is_contiguous()
+        _lib.check(_lib.lib().secedo_simmat_finalize(
+            self._h, norm, C.c_void_p(acc.data_ptr()), C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def finalize_raw(self, acc, out=None):
+        if out is None:
+            out = self._torch.empty((self.num_cells, self.num_cells), dtype=self._torch.float64,
+                                    device="cuda:%d" % self.device)
+        _lib.check(_lib.lib().secedo_simmat_finalize_raw(
+            self._h, C.c_void_p(acc.data_ptr()), C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def last_counts(self):
+        u, r = C.c_uint64(), C.c_uint64()
+        _lib.check(_lib.lib().secedo_simmat_last_counts(self._h, C.byref(u), C.byref(r)))
+        return int(u.value), int(r.value)
+
+    def last_accumulate_ms(self) -> float:
+        ms = C.c_float()
+        _lib.check(_lib.lib().secedo_simmat_last_accumulate_ms(self._h, C.byref(ms)))
+        return float(ms.value)

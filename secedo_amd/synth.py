@@ -1,0 +1,41 @@
+"""SYNTH-v1 synthetic pileups through the library's generator."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .pileup import FlatPileup
+
+# name -> (cells, loci, chromosomes, gap_max, new-fragment probability)
+CONFIGS = {
+    "C1": (64, 2000, 1, 2000, 0.30),
+    "C2": (1000, 50_000, 22, 30_000, 0.05),
+    "C3": (8000, 100_000, 22, 30_000, 0.03),
+    "C5": (32000, 200_000, 22, 30_000, 0.01),
+}
+
+
+def synth_pileup(num_cells, num_loci, num_chromosomes=1, gap_max=30000, new_frag_prob=0.05,
+                 frag_min=50, frag_max=600, base_error=0.01, mate_frac=0.01, seed=42) -> FlatPileup:
+    spec = _lib.SynthSpec(num_cells, num_loci, num_chromosomes, gap_max, new_frag_prob, frag_min,
+                          frag_max, base_error, mate_frac, seed)
+    nl, ne = C.c_uint64(), C.c_uint64()
+    L = _lib.lib()
+    _lib.check(L.secedo_synth_generate(C.byref(spec), C.byref(nl), C.byref(ne), None, None, None,
+                                       None, None))
+    chr_off = np.zeros(max(num_chromosomes, 1) + 1, dtype=np.uint32)
+    pos = np.zeros(nl.value, dtype=np.uint32)
+    off = np.zeros(nl.value + 1, dtype=np.uint64)
+    rid = np.zeros(ne.value, dtype=np.uint32)
+    idb = np.zeros(ne.value, dtype=np.uint32)
+    _lib.check(L.secedo_synth_generate(C.byref(spec), C.byref(nl), C.byref(ne), _lib.ptr(chr_off),
+                                       _lib.ptr(pos), _lib.ptr(off), _lib.ptr(rid), _lib.ptr(idb)))
+    return FlatPileup(chr_off, pos, off, rid, idb)
+
+
+def synth_config(name: str, clustered: bool = False, seed: int = 42) -> FlatPileup:
+    """One of the SURVEY.md 8d configurations; clustered=True uses gap_max=300 (~2.8 loci/read)."""
+    cells, loci, chrs, gap, p = CONFIGS[name]
+    return synth_pileup(cells, loci, chrs, 300 if clustered else gap, p, seed=seed)

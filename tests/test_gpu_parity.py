@@ -1,0 +1,116 @@
+"""Parity of the HIP path (through the C-ABI) against the reference vectors and the CPU oracle.
+
+Tolerance: norm-wise max|got-ref| <= 1e-9 * max|ref| (BASELINE.json north_star);
+symmetry and the zero diagonal must be exact. The integer work counters (updates, read pairs) must
+match the oracle's exactly.
+"""
+import numpy as np
+import pytest
+
+import secedo_amd
+from oracle import bindings as ob
+from tests import golden_util as gu
+from tests.pileup_gen import from_rows, random_pileup
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def hip(p, c, norm=None):
+    return secedo_amd.compute_similarity_matrix(p, c["num_cells"], c["mfl"], c["g2p"], c["eps"], c["h"],
+                                                c["theta"], c["T"], "", norm or c["norm"])
+
+
+@pytest.mark.parametrize("name", gu.fixture_names())
+def test_hip_matches_reference_vectors(name):
+    p, cases = gu.load(name)
+    for c in cases:
+        got = hip(p, c)
+        err = gu.normwise_err(got, c["out"])
+        assert err <= TOL, (name, c["T"], c["norm"], c["mfl"], err)
+        assert np.array_equal(got, got.T, equal_nan=True)
+        assert np.all(np.diag(got) == 0)
+
+
+RANDOM = [
+    # seed, cells, chr, loci, cov, gap_max, mfl, T, frag_max
+    (21, 24, 2, 300, 8, 250, 1000, 1, 600),
+    (22, 24, 2, 300, 8, 250, 200, 2, 600),      # reads longer than mfl: split at flush
+    (23, 100, 1, 800, 20, 3000, 1000, 8, 600),  # two cell blocks of 64
+    (24, 200, 3, 400, 30, 120, 1000, 4, 600),   # four blocks, clustered loci
+    (25, 16, 1, 300, 6, 9, 1000, 1, 500),       # > 32 loci per read: window overflow path
+    (26, 70, 2, 200, 10, 5, 1000, 2, 900),      # > 64 shared loci: beyond the LLR table
+]
+
+
+@pytest.mark.parametrize("seed,n,nchr,L,cov,gap,mfl,T,fmax", RANDOM)
+def test_hip_matches_oracle_random(seed, n, nchr, L, cov, gap, mfl, T, fmax):
+    p = random_pileup(seed, n, nchr, L, cov, gap, frag_max=fmax, dup_frac=0.05, triple_frac=0.3,
+                      skip_frac=0.15, n_groups=n + 7)
+    rng = np.random.default_rng(seed)
+    g2p = rng.integers(0, n, size=n + 7).astype(np.uint32)
+    for norm in secedo_amd.NORMALIZATIONS:
+        got = secedo_amd.compute_similarity_matrix(p, n, mfl, g2p, 0.01, 0.5, 0.02, T, "", norm)
+        ref = ob.oracle_compute(p, n, mfl, g2p, 0.01, 0.5, 0.02, T, norm)
+        assert gu.normwise_err(got, ref) <= TOL, (norm, gu.normwise_err(got, ref))
+        assert np.array_equal(got, got.T, equal_nan=True)
+
+
+def test_counters_and_raw_matrix():
+    """Staged interface: exact work counters, pre-normalisation D, block sizes 64 and 128."""
+    import torch
+    n = 150
+    p = random_pileup(31, n, 2, 500, 25, 200, dup_frac=0.03)
+    ref, raw = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 4, "ADD_MIN", want_raw=True)
+    u_ref, pairs_ref = ob.oracle_last_updates(), ob.oracle_last_read_pairs()
+    for block in (64, 128):
+        with secedo_amd.SimilarityMatrixPlan(0) as plan:
+            plan.prepare(p, n, 1000, None, 4, block_cells=block)
+            assert plan.block_cells == block
+            acc = plan.new_acc()
+            plan.accumulate(acc, 0.01, 0.5, 0.01)
+            d = plan.finalize_raw(acc).cpu().numpy()
+            m = plan.finalize(acc, "ADD_MIN").cpu().numpy()
+            u, pairs = plan.last_counts()
+        assert (u, pairs) == (u_ref, pairs_ref)
+        assert gu.normwise_err(d, raw) <= TOL
+        assert gu.normwise_err(m, ref) <= TOL
+
+
+def test_tile_ranges_compose_bitwise():
+    """Accumulating the tiles in two separate launches gives bit-identical accumulators."""
+    import torch
+    n = 300
+    p = random_pileup(32, n, 1, 400, 40, 1500)
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        plan.prepare(p, n, 1000, None, 8, block_cells=64)
+        nt = plan.num_tiles
+        a = plan.new_acc()
+        plan.accumulate(a, 0.01, 0.5, 0.01)
+        b = plan.new_acc()
+        plan.accumulate(b, 0.01, 0.5, 0.01, 0, nt // 3)
+        plan.accumulate(b, 0.01, 0.5, 0.01, nt // 3, nt)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        # and a second full run reproduces the first bit for bit (integer accumulation)
+        c = plan.new_acc()
+        plan.accumulate(c, 0.01, 0.5, 0.01)
+        torch.cuda.synchronize()
+        assert torch.equal(a, c)
+
+
+def test_edge_inputs():
+    # empty pileup, empty chromosome, single cell
+    empty = from_rows([[]])
+    got = secedo_amd.compute_similarity_matrix(empty, 5, 1000, None, 0.01, 0.5, 0.01, 1, "", "EXPONENTIATE")
+    exp = np.full((5, 5), 0.5)
+    np.fill_diagonal(exp, 0)
+    assert np.array_equal(got, exp)
+    got = secedo_amd.compute_similarity_matrix(empty, 1, 1000, None, 0.01, 0.5, 0.01, 1, "", "ADD_MIN")
+    assert got.shape == (1, 1) and got[0, 0] == 0
+    with pytest.raises(secedo_amd.InvalidNormalization):
+        secedo_amd.compute_similarity_matrix(empty, 5, 1000, None, 0.01, 0.5, 0.01, 1, "", "bogus")
+    # a group id that maps outside the matrix is an argument error, not a crash
+    p = from_rows([[(10, [(1, 0, 0), (2, 9, 1)])]])
+    with pytest.raises(secedo_amd.SecedoError):
+        secedo_amd.compute_similarity_matrix(p, 2, 1000, np.arange(10, dtype=np.uint32), 0.01, 0.5, 0.01, 1)
