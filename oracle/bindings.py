@@ -48,6 +48,8 @@ def _load_oracle():
             f.argtypes = [C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_uint32]
         lib.oracle_normalize.restype = C.c_int
         lib.oracle_normalize.argtypes = [C.c_int, _f64p, C.c_uint32]
+        lib.oracle_set_exact_binomials.restype = None
+        lib.oracle_set_exact_binomials.argtypes = [C.c_int]
         lib.oracle_last_updates.restype = C.c_uint64
         lib.oracle_last_read_pairs.restype = C.c_uint64
         _oracle = lib
@@ -108,6 +110,11 @@ def oracle_compute(p, num_cells, max_fragment_length, group_id_to_pos=None, muta
     if rc != 0:
         raise RuntimeError("oracle_simmat_compute failed: %d" % rc)
     return (out, raw) if want_raw else out
+
+
+def set_exact_binomials(on: bool) -> None:
+    """See simmat_oracle.h: reference formula without the u64 binomial wrap (x_s + x_d > ~48)."""
+    _load_oracle().oracle_set_exact_binomials(1 if on else 0)
 
 
 def oracle_last_updates() -> int:

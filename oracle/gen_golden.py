@@ -202,21 +202,23 @@ def random_cases():
          [case(40, 1000, T, norm, g2p=rev) for T in (1, 4) for norm in NORMS]
          + [case(40, 300, T, "ADD_MIN", g2p=rev) for T in (1, 4)]
          + [case(40, 1000, 8, "ADD_MIN", g2p=rev, h=0.15, theta=0.001)])
-    # very dense overlaps: long reads over tightly packed loci (x_s + x_d up to ~40)
-    p = random_pileup(103, 12, 1, 400, 6, 12, frag_min=200, frag_max=450, dup_frac=0.01)
+    # very dense overlaps: long reads over tightly packed loci, up to 46 loci per read (beyond one
+    # 32-locus window) but x_s + x_d < 48, where the reference's u64 binomial products still hold
+    # (oracle/simmat_oracle.c, oracle_set_exact_binomials)
+    p = random_pileup(103, 12, 1, 400, 6, 12, frag_min=120, frag_max=260, dup_frac=0.01)
     save("dense_12cells", p, [case(12, 1000, 1, norm) for norm in NORMS]
          + [case(12, 1000, 3, "ADD_MIN", theta=0.001)])
 
 
 def main():
+    only = set(sys.argv[1:])
     if not ob.have_ref():
         sys.exit("oracle/_ref/libsecedo_ref.so missing: run `make -C oracle ref` in the container")
     os.makedirs(GOLDEN, exist_ok=True)
-    semantic_probes()
-    kat_llr_table()
-    reference_pileup_files()
-    divide_clusters_shaped()
-    random_cases()
+    for fn in (semantic_probes, kat_llr_table, reference_pileup_files, divide_clusters_shaped,
+               random_cases):
+        if not only or fn.__name__ in only:
+            fn()
 
 
 if __name__ == "__main__":

@@ -28,7 +28,16 @@ typedef struct {
     double *hh, *eps, *half;                   /* h^k, eps^k, 0.5^k */
     double *pss_pds, *psd_pdd;                 /* (p_ss+p_ds)^k, (p_sd+p_dd)^k */
     uint64_t **comb;                           /* Pascal triangle, u64 wrap-around kept */
+    long double **combl;                       /* the same triangle without the wrap (see below) */
 } Tables;
+
+/* The reference's u64 binomials and their u64 products wrap once x_s + x_d reaches about 48
+ * (e.g. D(50,3) is off by 3e-6, D(60,4) by 0.11): its output there is an artefact of the wrap, not
+ * the value of its own formula. oracle_set_exact_binomials(1) evaluates the SAME nested sums with a
+ * long-double Pascal triangle, i.e. the reference formula in exact arithmetic; the default (0)
+ * reproduces the reference bit for bit. Tests that push x_s + x_d beyond the wrap use mode 1. */
+static _Thread_local int g_exact_binomials = 0;
+void oracle_set_exact_binomials(int on) { g_exact_binomials = on; }
 
 static double *pow_table(double base, uint32_t size) {
     /* similarity_matrix.cpp:53-65 start each table as {1, x}; :85-94 extend by
@@ -83,14 +92,22 @@ static void tables_init(Tables *t, double epsilon, double h, double theta, uint3
         }
         t->comb[p] = row;
     }
+    t->combl = (long double **)malloc(sizeof(long double *) * t->size);
+    for (uint32_t p = 0; p < t->size; ++p) {
+        t->combl[p] = (long double *)malloc(sizeof(long double) * (p + 1));
+        t->combl[p][0] = 1;
+        t->combl[p][p] = 1;
+        for (uint32_t i = 1; i < p; ++i) t->combl[p][i] = t->combl[p - 1][i - 1] + t->combl[p - 1][i];
+    }
 }
 
 static void tables_free(Tables *t) {
     free(t->p_ss); free(t->p_sd); free(t->p_ds); free(t->p_dd);
     free(t->one_h_eps); free(t->one_h_eps2); free(t->h_eps2);
     free(t->hh); free(t->eps); free(t->half); free(t->pss_pds); free(t->psd_pdd);
-    for (uint32_t p = 0; p < t->size; ++p) free(t->comb[p]);
+    for (uint32_t p = 0; p < t->size; ++p) { free(t->comb[p]); free(t->combl[p]); }
     free(t->comb);
+    free(t->combl);
 }
 
 /* similarity_matrix.cpp:153-170 (without the memo: the callers memoise). The factor
@@ -100,13 +117,15 @@ static double eval_log_prob_same(uint32_t x_s, uint32_t x_d, const Tables *c) {
     double p = 0;
     for (uint32_t k = 0; k <= x_s; ++k) {
         for (uint32_t l = 0; l <= x_d; ++l) {
-            uint64_t binom = c->comb[x_s][k] * c->comb[x_d][l];
+            const double binom = g_exact_binomials
+                    ? (double)(c->combl[x_s][k] * c->combl[x_d][l])
+                    : (double)(c->comb[x_s][k] * c->comb[x_d][l]);
             p += binom * c->one_h_eps2[k + l] * 0.5
                     * (c->p_ss[k] * c->p_sd[l] + c->p_ds[k] * c->p_dd[l])
                     * c->h_eps2[x_s + x_d - k - l] * c->p_ss[x_s - k] * c->p_sd[x_d - l];
         }
     }
-    p *= c->comb[x_s + x_d][x_s];
+    p *= g_exact_binomials ? (double)c->combl[x_s + x_d][x_s] : (double)c->comb[x_s + x_d][x_s];
     return log(p);
 }
 
@@ -118,8 +137,11 @@ static double eval_log_prob_diff(uint32_t x_s, uint32_t x_d, const Tables *c) {
         for (uint32_t l = 0; l <= x_d; ++l) {
             for (uint32_t p = 0; p <= x_s - k; ++p) {
                 for (uint32_t q = 0; q <= x_d - l; ++q) {
-                    uint64_t binom = c->comb[x_s][k] * c->comb[x_d][l] * c->comb[x_s - k][p]
-                            * c->comb[x_d - l][q];
+                    const double binom = g_exact_binomials
+                            ? (double)(c->combl[x_s][k] * c->combl[x_d][l] * c->combl[x_s - k][p]
+                                       * c->combl[x_d - l][q])
+                            : (double)(c->comb[x_s][k] * c->comb[x_d][l] * c->comb[x_s - k][p]
+                                       * c->comb[x_d - l][q]);
                     uint32_t rest = x_s + x_d - k - l - p - q;
                     prob += binom * c->one_h_eps[k + l] * 0.5
                             * (c->p_ss[k] * c->p_sd[l] + c->p_ds[k] * c->p_dd[l])
@@ -129,7 +151,7 @@ static double eval_log_prob_diff(uint32_t x_s, uint32_t x_d, const Tables *c) {
             }
         }
     }
-    prob *= c->comb[x_s + x_d][x_s];
+    prob *= g_exact_binomials ? (double)c->combl[x_s + x_d][x_s] : (double)c->comb[x_s + x_d][x_s];
     return log(prob);
 }
 

@@ -64,6 +64,12 @@ double oracle_log_prob_same(uint32_t x_s, uint32_t x_d, double mutation_rate,
 double oracle_log_prob_diff(uint32_t x_s, uint32_t x_d, double mutation_rate,
                             double homozygous_rate, double seq_error_rate, uint32_t table_size);
 
+/* 0 (default): u64 binomials with the reference's wrap-around, bit-compatible with the reference.
+ * 1: the same nested sums with a long-double Pascal triangle (the reference formula in exact
+ * arithmetic), for inputs whose x_s + x_d exceeds the reference's own numeric range (~48).
+ * Thread-local. */
+void oracle_set_exact_binomials(int on);
+
 /* In-place normalisation of an n x n matrix (similarity_matrix.cpp:271-293). */
 int oracle_normalize(int normalization, double *mat, uint32_t n);
 

@@ -33,27 +33,33 @@ def test_hip_matches_reference_vectors(name):
 
 
 RANDOM = [
-    # seed, cells, chr, loci, cov, gap_max, mfl, T, frag_max
-    (21, 24, 2, 300, 8, 250, 1000, 1, 600),
-    (22, 24, 2, 300, 8, 250, 200, 2, 600),      # reads longer than mfl: split at flush
-    (23, 100, 1, 800, 20, 3000, 1000, 8, 600),  # two cell blocks of 64
-    (24, 200, 3, 400, 30, 120, 1000, 4, 600),   # four blocks, clustered loci
-    (25, 16, 1, 300, 6, 9, 1000, 1, 500),       # > 32 loci per read: window overflow path
-    (26, 70, 2, 200, 10, 5, 1000, 2, 900),      # > 64 shared loci: beyond the LLR table
+    # seed, cells, chr, loci, cov, gap_max, mfl, T, frag_max, exact binomials in the oracle
+    (21, 24, 2, 300, 8, 250, 1000, 1, 600, False),
+    (22, 24, 2, 300, 8, 250, 200, 2, 600, False),      # reads longer than mfl: split at flush
+    (23, 100, 1, 800, 20, 3000, 1000, 8, 600, False),  # two cell blocks of 64
+    (24, 200, 3, 400, 30, 120, 1000, 4, 600, False),   # four blocks, clustered loci
+    # beyond the reference's own numeric range (its u64 binomial products wrap at x_s+x_d ~ 48):
+    # the oracle evaluates the reference formula with exact binomials there (simmat_oracle.h)
+    (25, 16, 1, 300, 6, 9, 1000, 1, 500, True),        # > 32 loci per read: window overflow path
+    (26, 70, 2, 700, 4, 5, 1000, 2, 700, True),        # > 64 shared loci: beyond the LLR table
 ]
 
 
-@pytest.mark.parametrize("seed,n,nchr,L,cov,gap,mfl,T,fmax", RANDOM)
-def test_hip_matches_oracle_random(seed, n, nchr, L, cov, gap, mfl, T, fmax):
+@pytest.mark.parametrize("seed,n,nchr,L,cov,gap,mfl,T,fmax,exact", RANDOM)
+def test_hip_matches_oracle_random(seed, n, nchr, L, cov, gap, mfl, T, fmax, exact):
     p = random_pileup(seed, n, nchr, L, cov, gap, frag_max=fmax, dup_frac=0.05, triple_frac=0.3,
                       skip_frac=0.15, n_groups=n + 7)
     rng = np.random.default_rng(seed)
     g2p = rng.integers(0, n, size=n + 7).astype(np.uint32)
-    for norm in secedo_amd.NORMALIZATIONS:
-        got = secedo_amd.compute_similarity_matrix(p, n, mfl, g2p, 0.01, 0.5, 0.02, T, "", norm)
-        ref = ob.oracle_compute(p, n, mfl, g2p, 0.01, 0.5, 0.02, T, norm)
-        assert gu.normwise_err(got, ref) <= TOL, (norm, gu.normwise_err(got, ref))
-        assert np.array_equal(got, got.T, equal_nan=True)
+    ob.set_exact_binomials(exact)
+    try:
+        for norm in secedo_amd.NORMALIZATIONS:
+            got = secedo_amd.compute_similarity_matrix(p, n, mfl, g2p, 0.01, 0.5, 0.02, T, "", norm)
+            ref = ob.oracle_compute(p, n, mfl, g2p, 0.01, 0.5, 0.02, T, norm)
+            assert gu.normwise_err(got, ref) <= TOL, (norm, gu.normwise_err(got, ref))
+            assert np.array_equal(got, got.T, equal_nan=True)
+    finally:
+        ob.set_exact_binomials(False)
 
 
 def test_counters_and_raw_matrix():
