@@ -89,6 +89,14 @@ def lib():
             raise ImportError(
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C secedo_amd/csrc` (there is no fallback implementation)" % LIB_PATH)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64 and the library links
+        # /opt/rocm's. Whichever is loaded first serves both, so load torch's first when torch is
+        # there (bench.py and the tests use torch for device memory, streams and RCCL); a process
+        # that initialised /opt/rocm's runtime and imports torch afterwards sees no device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(l, name)  # AttributeError if the .so lacks a declared symbol

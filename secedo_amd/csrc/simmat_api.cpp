@@ -272,8 +272,10 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     a.tile_col = h->tile_col.as<uint16_t>();
     a.tile_begin = tile_begin;
     // enough workgroups to fill 256 CUs several times over; a chunk is never shorter than 64 loci
+    uint32_t target_wgs = 2048;
+    if (const char *env = std::getenv("SECEDO_TARGET_WGS")) target_wgs = std::max(1, std::atoi(env));
     uint32_t chunks = 1;
-    if (n_tiles && n_tiles < 2048) chunks = (2048 + n_tiles - 1) / n_tiles;
+    if (n_tiles && n_tiles < target_wgs) chunks = (target_wgs + n_tiles - 1) / n_tiles;
     const uint32_t max_chunks = h->num_loci / 64 ? h->num_loci / 64 : 1;
     if (chunks > max_chunks) chunks = max_chunks;
     a.n_chunks = chunks;
