@@ -46,7 +46,8 @@ struct IdMap {
 }  // namespace
 
 std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t mfl,
-                        uint32_t num_threads, uint32_t block_cells, PackedPileup *out) {
+                        uint32_t num_threads, uint32_t block_cells, const StageGeometry &geo,
+                        PackedPileup *out) {
     if (!in.chr_locus_off || !in.locus_entry_off) return "null pileup arrays";
     if ((in.id_base16 != nullptr) == (in.id_base32 != nullptr))
         return "exactly one of id_base16 / id_base32 must be given";
@@ -180,8 +181,56 @@ std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t m
             run += c;
         }
     }
-    pk.entry_a.resize(n_kept);
-    pk.entry_b.resize(n_kept);
+    // ---- pass 3b: locus ranges for LDS staging (greedy; one partition shared by all blocks) ----
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t n = pk.read_off[r + 1] - pk.read_off[r];
+        if (n > 1) pk.multi_entries += n;
+    }
+    pk.stage_masks = n_kept && static_cast<double>(pk.multi_entries) > geo.masks_threshold * static_cast<double>(n_kept);
+    pk.cap_entries = pk.stage_masks ? geo.cap_entries_masks : geo.cap_entries_plain;
+    pk.cap_loci = pk.stage_masks ? geo.cap_loci_masks : geo.cap_loci_plain;
+    if (pk.cap_entries == 0 || pk.cap_loci == 0 || pk.cap_loci > 65535 || pk.cap_entries > 65535)
+        return "invalid staging geometry";
+    pk.range_off.clear();
+    pk.range_off.push_back(0);
+    {
+        std::vector<uint32_t> begin_off(nb);  // blk_off[b][range begin]
+        auto restart = [&](uint32_t l) {
+            for (uint32_t b = 0; b < nb; ++b) begin_off[b] = pk.blk_off[static_cast<size_t>(b) * stride + l];
+        };
+        auto fits_through = [&](uint32_t begin, uint32_t l) {  // range [begin, l + 1)
+            if (l + 1 - begin > pk.cap_loci) return false;
+            for (uint32_t b = 0; b < nb; ++b) {
+                if (pk.blk_off[static_cast<size_t>(b) * stride + l + 1] - begin_off[b] > pk.cap_entries) return false;
+            }
+            return true;
+        };
+        uint32_t begin = 0;
+        restart(0);
+        for (uint32_t l = 0; l < L; ++l) {
+            if (fits_through(begin, l)) continue;
+            if (l > begin) {  // close [begin, l) and start over at l
+                pk.range_off.push_back(l);
+                begin = l;
+                restart(l);
+                if (fits_through(begin, l)) continue;
+            }
+            // locus l alone exceeds the cap: a single-locus range the kernel reads from HBM
+            pk.range_off.push_back(l + 1);
+            begin = l + 1;
+            restart(l + 1);
+        }
+        if (pk.range_off.back() != L) pk.range_off.push_back(L);
+    }
+    std::vector<uint32_t> range_begin_of(L);  // first locus of the range a locus belongs to
+    for (size_t r = 0; r + 1 < pk.range_off.size(); ++r) {
+        for (uint32_t l = pk.range_off[r]; l < pk.range_off[r + 1]; ++l) range_begin_of[l] = pk.range_off[r];
+    }
+
+    pk.entry.resize(n_kept);
+    pk.entry32.resize(n_kept);
+    pk.mask32.resize(n_kept);
+    pk.entry_read.resize(n_kept);
     std::vector<uint32_t> cursor(pk.blk_off);  // next free index per (block, locus)
     std::vector<uint64_t> per_cell_sq(num_cells, 0);
     std::vector<uint32_t> cell_cnt(num_cells, 0);
@@ -194,39 +243,43 @@ std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t m
             const uint32_t r = seg_of[e];
             const uint32_t k = slot_of[e];
             const uint32_t lo = pk.read_off[r], hi = pk.read_off[r + 1];
-            EntryA a;
-            EntryB b;
-            a.meta = sg.cell | (static_cast<uint32_t>(pk.read_base[k]) << kMetaBaseShift)
-                    | (sg.tail ? kMetaTail : 0u);
-            a.prev_mask = 0;
-            a.next_mask = 0;
+            const uint32_t base = pk.read_base[k];
+            Entry a;
+            a.meta = sg.cell | (base << kMetaBaseShift) | (sg.tail ? kMetaTail : 0u);
+            a.masks = 0;
+            a.bases = 0;
             a.locus = l;
-            b.next_b0 = 0;
-            b.next_b1 = 0;
-            b.read = r;
-            b.pad = 0;
+            bool wide = false;
             for (uint32_t j = k; j-- > lo;) {
                 const uint32_t dist = l - pk.read_locus[j];  // >= 1
+                if (dist > kNarrowWindow) wide = true;
                 if (dist > kWindow) {
                     a.meta |= kMetaPrevOvf;
                     break;
                 }
-                a.prev_mask |= 1u << (dist - 1);
+                a.masks |= 1u << (dist - 1);
             }
             for (uint32_t j = k + 1; j < hi; ++j) {
                 const uint32_t dist = pk.read_locus[j] - l;
+                if (dist > kNarrowWindow) wide = true;
                 if (dist > kWindow) {
                     a.meta |= kMetaNextOvf;
                     break;
                 }
-                a.next_mask |= 1u << (dist - 1);
-                b.next_b0 |= static_cast<uint32_t>(pk.read_base[j] & 1u) << (dist - 1);
-                b.next_b1 |= static_cast<uint32_t>((pk.read_base[j] >> 1) & 1u) << (dist - 1);
+                a.masks |= 1u << (16 + dist - 1);
+                a.bases |= static_cast<uint32_t>(pk.read_base[j] & 1u) << (dist - 1);
+                a.bases |= static_cast<uint32_t>((pk.read_base[j] >> 1) & 1u) << (16 + dist - 1);
             }
             if (a.meta & (kMetaPrevOvf | kMetaNextOvf)) pk.any_window_overflow = true;
-            const uint32_t dst = cursor[static_cast<size_t>(sg.cell / B) * stride + l]++;
-            pk.entry_a[dst] = a;
-            pk.entry_b[dst] = b;
+            const uint32_t blk = sg.cell / B;
+            const uint32_t dst = cursor[static_cast<size_t>(blk) * stride + l]++;
+            pk.entry[dst] = a;
+            pk.entry_read[dst] = r;
+            pk.entry32[dst] = (sg.cell - blk * B) | (base << kC_BaseShift) | (sg.tail ? kC_Tail : 0u)
+                    | (hi - lo > 1 ? kC_Multi : 0u) | (wide ? kC_Wide : 0u)
+                    | ((l - range_begin_of[l]) << 16);
+            pk.mask32[dst] = (a.masks & 0xFFu) | (((a.masks >> 16) & 0xFFu) << 8)
+                    | ((a.bases & 0xFFu) << 16) | (((a.bases >> 16) & 0xFFu) << 24);
             if (cell_cnt[sg.cell]++ == 0) touched.push_back(sg.cell);
         }
         for (uint32_t cell : touched) {

@@ -33,26 +33,41 @@ struct FlatPileupView {
     uint32_t id_base(uint64_t e) const { return id_base16 ? id_base16[e] : id_base32[e]; }
 };
 
-// One kept pileup entry, 2 x 16 bytes. "Window" = the 32 loci before / after the entry's locus
-// (locus INDEX distance within the pileup, not base pairs).
-struct EntryA {          // read by every pair
-    uint32_t meta;       // bits 0-15 cell (matrix row), 16-17 base, 18 tail, 19 prev_ovf, 20 next_ovf
-    uint32_t prev_mask;  // bit t: the read also has a kept entry at locus - 1 - t
-    uint32_t next_mask;  // bit t: the read also has a kept entry at locus + 1 + t
-    uint32_t locus;      // global locus index
-};
-struct EntryB {          // read only by pairs that share a further locus
-    uint32_t next_b0;    // low bit of the base at locus + 1 + t
-    uint32_t next_b1;    // high bit of the base at locus + 1 + t
-    uint32_t read;       // index of the live read (segment) in read_off
-    uint32_t pad;
+// One kept pileup entry in full: 16 bytes, everything a pair needs unless a 16-locus window
+// overflows. "Window" = the loci before / after the entry's locus (locus INDEX distance within
+// the pileup, not base pairs).
+struct Entry {
+    uint32_t meta;    // bits 0-15 cell (matrix row), 16-17 base, 18 tail, 19 prev_ovf, 20 next_ovf
+    uint32_t masks;   // bit t (t < 16): the read also has a kept entry at locus - 1 - t;
+                      // bit 16 + t: ... at locus + 1 + t
+    uint32_t bases;   // bit t: low bit of the base at locus + 1 + t; bit 16 + t: its high bit
+    uint32_t locus;   // global locus index
 };
 
 constexpr uint32_t kMetaBaseShift = 16;
 constexpr uint32_t kMetaTail = 1u << 18;
 constexpr uint32_t kMetaPrevOvf = 1u << 19;
 constexpr uint32_t kMetaNextOvf = 1u << 20;
-constexpr uint32_t kWindow = 32;
+constexpr uint32_t kWindow = 16;
+
+// The compact form the accumulate kernel streams (4 bytes per entry; its low 16 bits are what is
+// staged in LDS for the column side of a tile):
+//   bits 0-6  cell - block * B      bits 7-8 base      bit 9 tail
+//   bit 10    multi: the read has more than one kept entry (else every pair shares this locus only)
+//   bit 11    wide: the read reaches beyond the 8-locus windows of mask32 -> use the full Entry
+//   bits 16-31 locus - first locus of the entry's locus range
+constexpr uint32_t kC_BaseShift = 7;
+constexpr uint32_t kC_Tail = 1u << 9;
+constexpr uint32_t kC_Multi = 1u << 10;
+constexpr uint32_t kC_Wide = 1u << 11;
+constexpr uint32_t kNarrowWindow = 8;
+
+// LDS staging limits of the accumulate kernel (simmat_kernels.hpp supplies them per tile size)
+struct StageGeometry {
+    uint32_t cap_entries_plain, cap_loci_plain;  // compact records only
+    uint32_t cap_entries_masks, cap_loci_masks;  // compact records + mask32 staged as well
+    double masks_threshold;                      // stage mask32 when this fraction of entries is multi
+};
 
 struct PackedPileup {
     uint32_t num_cells = 0;
@@ -63,13 +78,23 @@ struct PackedPileup {
     uint64_t num_reads = 0;     // live reads (segments)
     uint64_t raw_entries = 0;   // entries of the input pileup
     uint64_t pair_bound = 0;    // max over cells of sum_l n_cell(l)^2 (Cauchy-Schwarz bound)
+    uint64_t multi_entries = 0; // entries of reads with more than one kept entry
     bool any_window_overflow = false;
+    bool stage_masks = false;
 
     // entries sorted by (cell block, locus, input order); blk_off[b * (L+1) + l] is the first
     // entry of block b at locus l, blk_off[b * (L+1) + L] the end of block b
     std::vector<uint32_t> blk_off;
-    std::vector<EntryA> entry_a;
-    std::vector<EntryB> entry_b;
+    std::vector<uint32_t> entry32;     // compact form
+    std::vector<uint32_t> mask32;      // prev8 | next8 << 8 | next_b0 << 16 | next_b1 << 24
+    std::vector<Entry> entry;          // full form (pairs of two multi reads beyond mask32)
+    std::vector<uint32_t> entry_read;  // per entry: index of its live read (slow path only)
+    // locus ranges the accumulate kernel stages through LDS: range r covers loci
+    // [range_off[r], range_off[r+1]); no block has more than cap_entries entries in a range and no
+    // range more than cap_loci loci -- except single-locus ranges whose locus alone exceeds the cap
+    // (the kernel pairs those straight from HBM)
+    std::vector<uint32_t> range_off;
+    uint32_t cap_entries = 0, cap_loci = 0;
     // per live read: its kept entries in locus order (slow path: windows overflowed)
     std::vector<uint32_t> read_off;   // num_reads + 1
     std::vector<uint32_t> read_locus; // num_entries
@@ -78,6 +103,7 @@ struct PackedPileup {
 
 // Returns an empty string on success, else an error message (invalid input).
 std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t max_fragment_length,
-                        uint32_t num_threads, uint32_t block_cells, PackedPileup *out);
+                        uint32_t num_threads, uint32_t block_cells, const StageGeometry &geo,
+                        PackedPileup *out);
 
 }  // namespace secedo

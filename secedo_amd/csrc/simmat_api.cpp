@@ -72,12 +72,13 @@ struct secedo_simmat {
     bool prepared = false;
 
     // geometry
-    uint32_t num_cells = 0, block_cells = 0, num_blocks = 0, num_tiles = 0, num_loci = 0;
+    uint32_t num_cells = 0, block_cells = 0, num_blocks = 0, num_tiles = 0, num_loci = 0, num_ranges = 0;
+    bool stage_masks = false;
     uint64_t num_entries = 0, num_reads = 0, pair_bound = 0;
 
     // HBM
-    DevBuf blk_off, entry_a, entry_b, read_off, read_locus, read_base, tile_row, tile_col, lut,
-            counters, max_bits;
+    DevBuf blk_off, entry32, mask32, entry, entry_read, range_off, read_off, read_locus, read_base, tile_row, tile_col, lut,
+            counters, max_bits, slow_args;
     DevBuf own_acc, own_out;  // used by the one-shot entry point only
 
     // LLR table of the last accumulate()
@@ -176,8 +177,8 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
     HIP_TRY(hipSetDevice(h->device));
 
     secedo::PackedPileup pk;
-    const std::string err = secedo::pack_pileup(h->view, num_cells, max_fragment_length,
-                                                num_threads, block_cells, &pk);
+    const std::string err = secedo::pack_pileup(h->view, num_cells, max_fragment_length, num_threads,
+                                                block_cells, secedo::stage_geometry(block_cells), &pk);
     h->have_pileup = false;  // the borrow ends here
     if (!err.empty()) return fail(SECEDO_E_INVALID_ARG, err);
 
@@ -200,8 +201,13 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
         }
     }
     HIP_TRY(h->blk_off.upload(pk.blk_off));
-    HIP_TRY(h->entry_a.upload(pk.entry_a));
-    HIP_TRY(h->entry_b.upload(pk.entry_b));
+    HIP_TRY(h->entry32.upload(pk.entry32));
+    HIP_TRY(h->mask32.upload(pk.mask32));
+    HIP_TRY(h->entry.upload(pk.entry));
+    HIP_TRY(h->entry_read.upload(pk.entry_read));
+    HIP_TRY(h->range_off.upload(pk.range_off));
+    h->num_ranges = static_cast<uint32_t>(pk.range_off.size()) - 1;
+    h->stage_masks = pk.stage_masks;
     HIP_TRY(h->read_off.upload(pk.read_off));
     HIP_TRY(h->read_locus.upload(pk.read_locus));
     HIP_TRY(h->read_base.upload(pk.read_base));
@@ -252,6 +258,19 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
         HIP_TRY(hipStreamSynchronize(s));
         h->model = t.model;
         h->scale_log2 = t.scale_log2;
+        secedo::SlowPathArgs sp;
+        sp.entry = h->entry.as<uint4>();
+        sp.entry_read = h->entry_read.as<uint32_t>();
+        sp.read_off = h->read_off.as<uint32_t>();
+        sp.read_locus = h->read_locus.as<uint32_t>();
+        sp.read_base = h->read_base.as<uint8_t>();
+        sp.lut = h->lut.as<long long>();
+        sp.model = secedo::LlrModelDev{t.model.ln_u1, t.model.ln_v1, t.model.ln_u2, t.model.ln_v2,
+                                       t.model.ln_w1, t.model.ln_z1, t.model.ln_w2, t.model.ln_z2};
+        sp.scale_log2 = t.scale_log2;
+        HIP_TRY(h->slow_args.ensure(sizeof(sp)));
+        HIP_TRY(hipMemcpyAsync(h->slow_args.p, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
         h->lut_eps = eps;
         h->lut_h = hr;
         h->lut_theta = theta;
@@ -262,35 +281,38 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     secedo::AccumulateArgs a;
     a.blk_off = h->blk_off.as<uint32_t>();
     a.stride = h->num_loci + 1;
-    a.num_loci = h->num_loci;
-    a.entry_a = h->entry_a.as<uint4>();
-    a.entry_b = h->entry_b.as<uint4>();
-    a.read_off = h->read_off.as<uint32_t>();
-    a.read_locus = h->read_locus.as<uint32_t>();
-    a.read_base = h->read_base.as<uint8_t>();
+    a.entry32 = h->entry32.as<uint32_t>();
+    a.mask32 = h->mask32.as<uint32_t>();
+    a.entry = h->entry.as<uint4>();
+    a.range_off = h->range_off.as<uint32_t>();
+    a.num_ranges = h->num_ranges;
     a.tile_row = h->tile_row.as<uint16_t>();
     a.tile_col = h->tile_col.as<uint16_t>();
     a.tile_begin = tile_begin;
-    // enough workgroups to fill 256 CUs several times over; a chunk is never shorter than 64 loci
+    // enough workgroups to fill 256 CUs several times over; a workgroup walks whole locus ranges
     uint32_t target_wgs = 2048;
     if (const char *env = std::getenv("SECEDO_TARGET_WGS")) target_wgs = std::max(1, std::atoi(env));
     uint32_t chunks = 1;
     if (n_tiles && n_tiles < target_wgs) chunks = (target_wgs + n_tiles - 1) / n_tiles;
-    const uint32_t max_chunks = h->num_loci / 64 ? h->num_loci / 64 : 1;
-    if (chunks > max_chunks) chunks = max_chunks;
-    a.n_chunks = chunks;
-    a.chunk_loci = (h->num_loci + chunks - 1) / chunks;
-    if (a.chunk_loci == 0) a.chunk_loci = 1;
+    if (chunks > h->num_ranges) chunks = h->num_ranges ? h->num_ranges : 1;
+    a.chunk_ranges = (h->num_ranges + chunks - 1) / chunks;
+    if (a.chunk_ranges == 0) a.chunk_ranges = 1;
+    a.n_chunks = (h->num_ranges + a.chunk_ranges - 1) / a.chunk_ranges;
+    if (a.n_chunks == 0) a.n_chunks = 1;
     a.lut = h->lut.as<long long>();
-    a.model = secedo::LlrModelDev{h->model.ln_u1, h->model.ln_v1, h->model.ln_u2, h->model.ln_v2,
-                                  h->model.ln_w1, h->model.ln_z1, h->model.ln_w2, h->model.ln_z2};
-    a.scale_log2 = h->scale_log2;
+    a.slow = h->slow_args.as<secedo::SlowPathArgs>();
     a.acc = d_acc;
     a.counters = h->counters.as<unsigned long long>();
 
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(unsigned long long), s));
     HIP_TRY(hipEventRecord(h->ev_begin, s));
-    HIP_TRY(secedo::launch_accumulate(a, h->block_cells, n_tiles, s));
+    int lanes_per_entry = 1;
+    if (const char *env = std::getenv("SECEDO_LANES_PER_ENTRY")) lanes_per_entry = std::atoi(env);
+    // 16-bit pair counters per cell pair are safe when no cell pair can collect 65536 pairs
+    bool count_tile = !h->stage_masks && h->pair_bound < 65536;
+    if (const char *env = std::getenv("SECEDO_COUNT_TILE")) count_tile = count_tile && std::atoi(env) != 0;
+    HIP_TRY(secedo::launch_accumulate(a, h->block_cells, h->stage_masks, count_tile, lanes_per_entry,
+                                      n_tiles, s));
     HIP_TRY(hipEventRecord(h->ev_end, s));
     h->timed = true;
     return SECEDO_OK;

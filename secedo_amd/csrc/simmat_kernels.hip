@@ -20,7 +20,14 @@ namespace {
 constexpr uint32_t META_TAIL = 1u << 18;
 constexpr uint32_t META_PREV_OVF = 1u << 19;
 constexpr uint32_t META_NEXT_OVF = 1u << 20;
+constexpr uint32_t C_CELL = 127u;
+constexpr uint32_t C_BASE_SHIFT = 7;
+constexpr uint32_t C_TAIL = 1u << 9;
+constexpr uint32_t C_MULTI = 1u << 10;
+constexpr uint32_t C_WIDE = 1u << 11;
 constexpr int LUT_DIM = 65;
+constexpr int SLUT_DIM = 10;  // LDS copy of the table for the 8-locus windows: x_s + x_d <= 9
+constexpr long long NO_PAIR = (long long)0x8000000000000000ull;  // "another locus owns this pair"
 
 __device__ __forceinline__ double log_add(double a, double b) {
     const double hi = fmax(a, b), lo = fmin(a, b);
@@ -28,19 +35,23 @@ __device__ __forceinline__ double log_add(double a, double b) {
 }
 
 // D(x_s, x_d) outside the table: closed form in log space (llr_table.hpp)
-__device__ __noinline__ long long llr_fixed_device(const LlrModelDev &m, uint32_t xs, uint32_t xd,
-                                                   int scale_log2) {
+__device__ __noinline__ long long llr_fixed_device(const SlowPathArgs *sp, uint32_t xs, uint32_t xd) {
+    const LlrModelDev m = sp->model;
+    const int scale_log2 = sp->scale_log2;
     const double s = xs, d = xd;
     const double diff = log_add(s * m.ln_u1 + d * m.ln_v1, s * m.ln_u2 + d * m.ln_v2);
     const double same = log_add(s * m.ln_w1 + d * m.ln_z1, s * m.ln_w2 + d * m.ln_z2);
     return llrint(ldexp(diff - same, scale_log2));
 }
 
-// Slow path (a window overflowed on the same side for both reads): merge-walk the two reads'
-// kept entries (reference: similarity_matrix.cpp:223-229). Returns the first shared locus, or
-// 0xFFFFFFFF if none.
-__device__ __noinline__ uint32_t merge_walk(const AccumulateArgs &a, uint32_t r1, uint32_t r2,
-                                            uint32_t *xs_out, uint32_t *xd_out) {
+// Slow path (a 16-locus window overflowed on the same side for both reads): merge-walk the two
+// reads' kept entries (reference: similarity_matrix.cpp:223-229). Returns the fixed-point D if
+// `locus` is the first locus the two reads share (only then does this incidence own the pair),
+// else NO_PAIR. (Values are returned, not written through pointers: an address-taken local in
+// the caller would live in scratch memory.)
+__device__ __noinline__ long long slow_pair(const SlowPathArgs *sp, uint32_t r1, uint32_t r2,
+                                            uint32_t locus) {
+    const SlowPathArgs a = *sp;
     uint32_t i1 = a.read_off[r1], e1 = a.read_off[r1 + 1];
     uint32_t i2 = a.read_off[r2], e2 = a.read_off[r2 + 1];
     uint32_t xs = 0, xd = 0, first = 0xFFFFFFFFu;
@@ -56,87 +67,259 @@ __device__ __noinline__ uint32_t merge_walk(const AccumulateArgs &a, uint32_t r1
             ++i2;
         }
     }
-    *xs_out = xs;
-    *xd_out = xd;
-    return first;
+    if (first != locus) return NO_PAIR;
+    return (xs < LUT_DIM && xd < LUT_DIM) ? a.lut[xs * LUT_DIM + xd] : llr_fixed_device(sp, xs, xd);
 }
 
-template <int B, int THREADS>
+// One (read pair, shared locus) incidence from the full 16-byte entries (pack_host.hpp: Entry);
+// g1/g2 are their global entry indices. The fixed-point log-likelihood ratio if this incidence
+// owns its read pair (no earlier locus shared), else NO_PAIR.
+__device__ __noinline__ long long pair_value_full(const SlowPathArgs *sp, uint32_t g1, uint32_t g2) {
+    const uint4 *entry = sp->entry;
+    const uint4 A1 = entry[g1], A2 = entry[g2];
+    if (A1.y & A2.y & 0xFFFFu) return NO_PAIR;
+    const bool same = (((A1.x ^ A2.x) >> 16) & 3u) == 0u;
+    if ((A1.x & A2.x & (META_PREV_OVF | META_NEXT_OVF)) == 0u) {
+        const uint32_t shared = (A1.y & A2.y) >> 16;
+        const uint32_t x = A1.z ^ A2.z;
+        const uint32_t diff = ((x & 0xFFFFu) | (x >> 16)) & shared;
+        const uint32_t nd = __popc(diff);
+        const uint32_t xd = nd + (same ? 0u : 1u);
+        const uint32_t xs = __popc(shared) - nd + (same ? 1u : 0u);
+        return sp->lut[xs * LUT_DIM + xd];
+    }
+    const uint32_t *entry_read = sp->entry_read;
+    return slow_pair(sp, entry_read[g1], entry_read[g2], A1.w);
+}
+
+// MASKS:  the 8-locus window masks are staged too, so joint (x_s, x_d) terms of multi-locus read
+//         pairs are evaluated from LDS (clustered loci); otherwise such pairs go through the full
+//         entries in HBM (they are rare when loci are sparse).
+// COUNTS: the tile holds two 16-bit pair counters per cell pair (matching | mismatching single-
+//         locus pairs, one ds_add_u32 each) instead of an int64 sum; the workgroup converts them
+//         to fixed point when it flushes (exact integer arithmetic, so the result is bit-identical
+//         to the int64 tile). Needs < 65536 pairs per cell pair, which the host guarantees from
+//         the pileup's pair bound; joint terms bypass the tile (global atomics).
+// G:      lanes that share one row-side entry: lane (sub, k) = (lane / G, lane % G) walks the
+//         column entries j0 + k, j0 + k + G, ... of entry `sub` of its wave's batch.
+template <int B, int THREADS, int CAPJ, int CAPL, bool MASKS, bool COUNTS, int G>
 __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long tile[];  // B*B
+    static_assert(!(MASKS && COUNTS), "the count tile is for the sparse-loci variant");
+    // LDS: [ tile | sJ CAPJ u16 | sOff CAPL+2 u16 | sJm CAPJ u32 (MASKS) | sLut (MASKS) | s_next ]
+    constexpr size_t TILE_BYTES = (size_t)B * B * (COUNTS ? 4 : 8);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long *tile64 = reinterpret_cast<unsigned long long *>(lds_raw);
+    uint32_t *tile32 = reinterpret_cast<uint32_t *>(lds_raw);
+    uint16_t *sJ = reinterpret_cast<uint16_t *>(lds_raw + TILE_BYTES);
+    uint16_t *sOff = sJ + CAPJ;
+    uint32_t *sJm = reinterpret_cast<uint32_t *>(sOff + CAPL + 2);
+    long long *sLut = reinterpret_cast<long long *>(sJm + (MASKS ? CAPJ : 0));
+    uint32_t *s_next = reinterpret_cast<uint32_t *>(sLut + (MASKS ? SLUT_DIM * SLUT_DIM : 0));
+
+    constexpr int JPT = (CAPJ + THREADS - 1) / THREADS;      // staged column entries per thread
+    constexpr int OPT = (CAPL + 1 + THREADS - 1) / THREADS;  // staged offsets per thread
+    constexpr int WAVES = THREADS / 64;
+    constexpr uint32_t EPB = 64 / G;                         // row-side entries per wave batch
 
     const uint32_t t = a.tile_begin + blockIdx.x / a.n_chunks;
     const uint32_t chunk = blockIdx.x % a.n_chunks;
     const uint32_t I = a.tile_row[t], J = a.tile_col[t];
-    const uint32_t tid = threadIdx.x;
+    const bool diag = (I == J);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t sub = lane / G, kk = lane % G;
 
-    for (uint32_t i = tid; i < B * B; i += THREADS) tile[i] = 0ull;
-    __syncthreads();
+    if (COUNTS) {
+        for (uint32_t i = tid; i < B * B; i += THREADS) tile32[i] = 0u;
+    } else {
+        for (uint32_t i = tid; i < B * B; i += THREADS) tile64[i] = 0ull;
+    }
+    if (MASKS) {
+        for (uint32_t i = tid; i < SLUT_DIM * SLUT_DIM; i += THREADS)
+            sLut[i] = a.lut[(i / SLUT_DIM) * LUT_DIM + (i % SLUT_DIM)];
+    }
 
-    const uint32_t l0 = chunk * a.chunk_loci;
-    const uint32_t l1 = min(a.num_loci, l0 + a.chunk_loci);
-    const size_t rowI = (size_t)I * a.stride, rowJ = (size_t)J * a.stride;
+    const uint32_t r_begin = min(a.num_ranges, chunk * a.chunk_ranges);
+    const uint32_t r_end = min(a.num_ranges, r_begin + a.chunk_ranges);
+    const uint32_t *offI = a.blk_off + (size_t)I * a.stride;
+    const uint32_t *offJ = a.blk_off + (size_t)J * a.stride;
+    const long long d10 = a.lut[1 * LUT_DIM + 0], d01 = a.lut[0 * LUT_DIM + 1];
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B;
     unsigned long long n_updates = 0, n_pairs = 0;
 
-    if (l0 < l1) {
-        const uint32_t i_begin = a.blk_off[rowI + l0], i_end = a.blk_off[rowI + l1];
-        const long long d10 = a.lut[1 * LUT_DIM + 0], d01 = a.lut[0 * LUT_DIM + 1];
-        for (uint32_t e1 = i_begin + tid; e1 < i_end; e1 += THREADS) {
-            const uint4 A1 = a.entry_a[e1];
-            const uint32_t l = A1.w;
-            uint32_t j0, j1;
-            if (I == J) {  // pairs inside one block: every unordered pair once
-                j0 = e1 + 1;
-                j1 = a.blk_off[rowI + l + 1];
-            } else {
-                j0 = a.blk_off[rowJ + l];
-                j1 = a.blk_off[rowJ + l + 1];
-            }
-            const uint32_t c1 = A1.x & 0xFFFFu;
-            const uint32_t row = (c1 - I * B) * B;
-            for (uint32_t e2 = j0; e2 < j1; ++e2) {
-                const uint4 A2 = a.entry_a[e2];
-                const uint32_t c2 = A2.x & 0xFFFFu;
-                if (c1 == c2) continue;                    // same cell (:215)
-                if (A1.x & A2.x & META_TAIL) continue;     // neither read was ever flushed (:407-408)
-                ++n_updates;
-                if (A1.y & A2.y) continue;                 // an earlier shared locus owns this pair
-                const bool same = (((A1.x ^ A2.x) >> 16) & 3u) == 0u;
-                long long v;
-                if ((A1.x & A2.x & (META_PREV_OVF | META_NEXT_OVF)) == 0u) {
-                    const uint32_t shared = A1.z & A2.z;
-                    if (shared == 0u) {
-                        v = same ? d10 : d01;              // the pair shares this locus only
-                    } else {                               // joint (x_s, x_d) term from the windows
-                        const uint4 B1 = a.entry_b[e1];
-                        const uint4 B2 = a.entry_b[e2];
-                        const uint32_t diff = ((B1.x ^ B2.x) | (B1.y ^ B2.y)) & shared;
-                        const uint32_t xd = __popc(diff) + (same ? 0u : 1u);
-                        const uint32_t xs = __popc(shared) - __popc(diff) + (same ? 1u : 0u);
-                        v = a.lut[xs * LUT_DIM + xd];
-                    }
-                } else {
-                    uint32_t xs, xd;
-                    const uint32_t first = merge_walk(a, a.entry_b[e1].z, a.entry_b[e2].z, &xs, &xd);
-                    if (first != l) continue;
-                    v = (xs < LUT_DIM && xd < LUT_DIM) ? a.lut[xs * LUT_DIM + xd]
-                                                       : llr_fixed_device(a.model, xs, xd, a.scale_log2);
+    // the next range's column side, in flight in registers while the current range is paired
+    uint32_t pJ[JPT], pM[MASKS ? JPT : 1], pO[OPT];
+    uint32_t n_la = 0, n_lb = 0, n_ib = 0, n_ie = 0, n_jb = 0, n_je = 0;
+    bool n_staged = false;
+
+    auto prefetch = [&](uint32_t r) {
+        n_la = a.range_off[r];
+        n_lb = a.range_off[r + 1];
+        n_ib = offI[n_la];
+        n_ie = offI[n_lb];
+        n_jb = offJ[n_la];
+        n_je = offJ[n_lb];
+        n_staged = (n_je - n_jb) <= (uint32_t)CAPJ && (n_lb - n_la) <= (uint32_t)CAPL;
+        if (n_staged) {
+#pragma unroll
+            for (int k = 0; k < JPT; ++k) {
+                const uint32_t i = tid + k * THREADS;
+                if (i < n_je - n_jb) {
+                    pJ[k] = a.entry32[n_jb + i];
+                    if (MASKS) pM[k] = a.mask32[n_jb + i];
                 }
-                ++n_pairs;
-                atomicAdd(&tile[row + (c2 - J * B)], (unsigned long long)v);
+            }
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) {
+                const uint32_t i = tid + k * THREADS;
+                if (i <= n_lb - n_la) pO[k] = offJ[n_la + i];
             }
         }
+    };
+
+    if (r_begin < r_end) prefetch(r_begin);
+    for (uint32_t r = r_begin; r < r_end; ++r) {
+        const uint32_t la = n_la, lb = n_lb, ib = n_ib, ie = n_ie, jb = n_jb, je = n_je;
+        const bool staged = n_staged;
+        __syncthreads();  // every wave is done with the previous range (first time: with zeroing)
+        if (staged) {
+#pragma unroll
+            for (int k = 0; k < JPT; ++k) {
+                const uint32_t i = tid + k * THREADS;
+                if (i < je - jb) {
+                    sJ[i] = (uint16_t)pJ[k];
+                    if (MASKS) sJm[i] = pM[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) {
+                const uint32_t i = tid + k * THREADS;
+                if (i <= lb - la) sOff[i] = (uint16_t)(pO[k] - jb);
+            }
+        }
+        if (tid == 0) *s_next = WAVES;  // batches 0..WAVES-1 are pre-assigned, one per wave
+        __syncthreads();
+        if (r + 1 < r_end) prefetch(r + 1);
+
+        const uint32_t nI = ie - ib;
+        uint32_t upd = 0, skipped = 0;  // per range, 32-bit
+        if (staged) {
+            // each wave pulls batches of EPB consecutive row-side entries (the next batch's
+            // records already in flight) and pairs them against the staged column
+            const uint32_t n_batch = (nI + EPB - 1u) / EPB;
+            uint32_t cur = tid >> 6;
+            uint32_t rec = 0, m1 = 0;
+            if (cur < n_batch && cur * EPB + sub < nI) {
+                rec = a.entry32[ib + cur * EPB + sub];
+                if (MASKS) m1 = a.mask32[ib + cur * EPB + sub];
+            }
+            while (cur < n_batch) {
+                uint32_t nxt = 0;
+                if (lane == 0) nxt = atomicAdd(s_next, 1u);
+                nxt = __builtin_amdgcn_readfirstlane(nxt);
+                uint32_t rec_n = 0, m1_n = 0;
+                if (nxt < n_batch && nxt * EPB + sub < nI) {
+                    rec_n = a.entry32[ib + nxt * EPB + sub];
+                    if (MASKS) m1_n = a.mask32[ib + nxt * EPB + sub];
+                }
+                const uint32_t i = cur * EPB + sub;
+                if (i < nI) {
+                    const uint32_t lrel = rec >> 16;
+                    uint32_t j = (diag ? i + 1u : (uint32_t)sOff[lrel]) + kk;
+                    const uint32_t j1 = sOff[lrel + 1];
+                    const uint32_t row = (rec & C_CELL) * B;
+                    // in a diagonal tile equal cells must be skipped (:215): make the test
+                    // "(x & cell_mask) != 0 or not diagonal" a single AND against a constant
+                    const uint32_t cell_test = diag ? C_CELL : 0u;
+                    uint32_t w2 = (j < j1) ? (uint32_t)sJ[j] : 0u;
+                    while (j < j1) {
+                        const uint32_t w = w2, jc = j;
+                        j += G;
+                        if (j < j1) w2 = sJ[j];  // next column entry in flight across the atomic
+                        const uint32_t x = rec ^ w, both = rec & w;
+                        // skip pairs of reads that were both never flushed (:407-408) and, inside a
+                        // diagonal tile, pairs of the same cell (:215)
+                        const bool ok = (both & C_TAIL) == 0u && ((x & cell_test) != 0u || !diag);
+                        if (ok) {
+                            ++upd;
+                            const bool differ = (x & (3u << C_BASE_SHIFT)) != 0u;
+                            if (__builtin_expect((both & C_MULTI) != 0u, MASKS ? 1 : 0)) {
+                                // both reads cover further loci: joint (x_s, x_d) term
+                                long long v = differ ? d01 : d10;
+                                bool owner = true;
+                                if (MASKS && ((rec | w) & C_WIDE) == 0u) {
+                                    const uint32_t m2 = sJm[jc];
+                                    owner = (m1 & m2 & 0xFFu) == 0u;  // else an earlier shared locus owns it
+                                    const uint32_t shared = ((m1 & m2) >> 8) & 0xFFu;
+                                    if (shared) {
+                                        const uint32_t y = m1 ^ m2;
+                                        const uint32_t diff = ((y >> 16) | (y >> 24)) & shared;
+                                        const uint32_t nd = __popc(diff);
+                                        const uint32_t xd = nd + (differ ? 1u : 0u);
+                                        const uint32_t xs = __popc(shared) - nd + (differ ? 0u : 1u);
+                                        v = sLut[xs * SLUT_DIM + xd];
+                                    }
+                                } else {
+                                    v = pair_value_full(a.slow, ib + i, jb + jc);
+                                    owner = (v != NO_PAIR);
+                                }
+                                if (owner) {
+                                    if (COUNTS) atomicAdd(&dst[row + (w & C_CELL)], (unsigned long long)v);
+                                    else atomicAdd(&tile64[row + (w & C_CELL)], (unsigned long long)v);
+                                } else {
+                                    ++skipped;
+                                }
+                            } else if (COUNTS) {
+                                atomicAdd(&tile32[row + (w & C_CELL)], differ ? 0x10000u : 1u);
+                            } else {
+                                atomicAdd(&tile64[row + (w & C_CELL)], (unsigned long long)(differ ? d01 : d10));
+                            }
+                        }
+                    }
+                }
+                cur = nxt;
+                rec = rec_n;
+                m1 = m1_n;
+            }
+        } else {
+            // a locus range that does not fit the staging buffers (a single very deep locus):
+            // pair it straight from HBM/L2 with the full entries, straight into HBM
+            for (uint32_t e1 = ib + tid; e1 < ie; e1 += THREADS) {
+                const uint4 A1 = a.entry[e1];
+                const uint32_t l = A1.w;
+                const uint32_t j0 = diag ? e1 + 1 : offJ[l];
+                const uint32_t j1 = offJ[l + 1];
+                const uint32_t c1 = A1.x & 0xFFFFu;
+                const uint32_t row = (c1 - I * B) * B;
+                for (uint32_t e2 = j0; e2 < j1; ++e2) {
+                    const uint32_t m2 = a.entry[e2].x;
+                    const uint32_t c2 = m2 & 0xFFFFu;
+                    if (c1 == c2) continue;
+                    if (A1.x & m2 & META_TAIL) continue;
+                    ++upd;
+                    const long long v = pair_value_full(a.slow, e1, e2);
+                    if (v == NO_PAIR) {
+                        ++skipped;
+                        continue;
+                    }
+                    atomicAdd(&dst[row + (c2 - J * B)], (unsigned long long)v);
+                }
+            }
+        }
+        n_updates += upd;
+        n_pairs += upd - skipped;
     }
     __syncthreads();
 
-    unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B;
-    if (a.n_chunks == 1) {
-        for (uint32_t i = tid; i < B * B; i += THREADS) dst[i] = tile[i];
-    } else {
-        for (uint32_t i = tid; i < B * B; i += THREADS) {
-            const unsigned long long v = tile[i];
-            if (v) atomicAdd(&dst[i], v);
+    // flush: always additive (joint terms and deep ranges may already have landed in HBM)
+    for (uint32_t i = tid; i < B * B; i += THREADS) {
+        unsigned long long v;
+        if (COUNTS) {
+            const uint32_t c = tile32[i];
+            v = (unsigned long long)((long long)(c & 0xFFFFu) * d10 + (long long)(c >> 16) * d01);
+        } else {
+            v = tile64[i];
         }
+        if (v) atomicAdd(&dst[i], v);
     }
 
     // work counters: wave reduction, one atomic per wave
@@ -144,7 +327,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
         n_updates += __shfl_down(n_updates, off);
         n_pairs += __shfl_down(n_pairs, off);
     }
-    if ((tid & 63u) == 0u && (n_updates | n_pairs)) {
+    if (lane == 0u && (n_updates | n_pairs)) {
         atomicAdd(&a.counters[0], n_updates);
         atomicAdd(&a.counters[1], n_pairs);
     }
@@ -220,23 +403,46 @@ __global__ __launch_bounds__(256) void write_matrix(const long long *acc, uint32
     }
 }
 
+template <int B, int THREADS, int CAPJ, int CAPL, bool MASKS, bool COUNTS, int G>
+hipError_t launch_acc_g(const AccumulateArgs &args, uint32_t grid, hipStream_t stream) {
+    constexpr size_t lds = (size_t)B * B * (COUNTS ? 4 : 8) + (size_t)CAPJ * 2 + ((size_t)CAPL + 2) * 2
+            + (MASKS ? (size_t)CAPJ * 4 + SLUT_DIM * SLUT_DIM * 8 : 0) + 16;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert((CAPL + 2) % 4 == 0 && CAPJ % 8 == 0, "alignment of the LDS carve-up");
+    auto kern = &accumulate_tiles<B, THREADS, CAPJ, CAPL, MASKS, COUNTS, G>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
+    return hipGetLastError();
+}
+
+template <int B, int THREADS, int CAPJ, int CAPL, bool MASKS, bool COUNTS>
+hipError_t launch_acc(const AccumulateArgs &args, uint32_t grid, int lanes_per_entry, hipStream_t stream) {
+    if (lanes_per_entry == 2) return launch_acc_g<B, THREADS, CAPJ, CAPL, MASKS, COUNTS, 2>(args, grid, stream);
+    return launch_acc_g<B, THREADS, CAPJ, CAPL, MASKS, COUNTS, 1>(args, grid, stream);
+}
+
 }  // namespace
 
-hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, uint32_t n_tiles,
-                             hipStream_t stream) {
+StageGeometry stage_geometry(uint32_t block_cells) {
+    if (block_cells == 128) return StageGeometry{kCapJ128, kCapL128, kCapJ128M, kCapL128M, kMasksThreshold};
+    return StageGeometry{kCapJ64, kCapL64, kCapJ64M, kCapL64M, kMasksThreshold};
+}
+
+hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, bool stage_masks,
+                             bool count_tile, int lanes_per_entry, uint32_t n_tiles, hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
     const uint32_t grid = n_tiles * args.n_chunks;
+    const int g = lanes_per_entry;
     if (block_cells == 128) {
-        constexpr int B = 128, T = 1024;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_tiles<B, T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, B * B * 8);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((accumulate_tiles<B, T>), dim3(grid), dim3(T), B * B * 8, stream, args);
-    } else {
-        constexpr int B = 64, T = 256;
-        hipLaunchKernelGGL((accumulate_tiles<B, T>), dim3(grid), dim3(T), B * B * 8, stream, args);
+        if (stage_masks) return launch_acc<128, 1024, kCapJ128M, kCapL128M, true, false>(args, grid, g, stream);
+        if (count_tile) return launch_acc<128, 1024, kCapJ128, kCapL128, false, true>(args, grid, g, stream);
+        return launch_acc<128, 1024, kCapJ128, kCapL128, false, false>(args, grid, g, stream);
     }
-    return hipGetLastError();
+    if (stage_masks) return launch_acc<64, 256, kCapJ64M, kCapL64M, true, false>(args, grid, g, stream);
+    if (count_tile) return launch_acc<64, 256, kCapJ64, kCapL64, false, true>(args, grid, g, stream);
+    return launch_acc<64, 256, kCapJ64, kCapL64, false, false>(args, grid, g, stream);
 }
 
 hipError_t launch_finalize(const int64_t *acc, uint32_t n, uint32_t nb, uint32_t block_cells,

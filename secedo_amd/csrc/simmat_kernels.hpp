@@ -4,6 +4,8 @@
 #include <hip/hip_runtime_api.h>
 #include <hip/hip_vector_types.h>
 
+#include "pack_host.hpp"
+
 #include <algorithm>
 #include <cstddef>
 #include <cstdint>
@@ -14,33 +16,57 @@ struct LlrModelDev {  // LlrModel of llr_table.hpp, by value into the kernel
     double ln_u1, ln_v1, ln_u2, ln_v2, ln_w1, ln_z1, ln_w2, ln_z2;
 };
 
+// LDS staging geometry of accumulate_tiles per tile size: column-side entries and loci per locus
+// range, without / with the 8-locus window masks staged too. pack_host.cpp cuts the locus ranges
+// to these limits. LDS per workgroup: B=64: 32 KiB tile + 12/28 KiB; B=128: 128 KiB tile + 24/28 KiB.
+constexpr uint32_t kCapJ64 = 4096, kCapL64 = 2046, kCapJ64M = 4096, kCapL64M = 2046;
+constexpr uint32_t kCapJ128 = 4096, kCapL128 = 2046, kCapJ128M = 4096, kCapL128M = 2046;
+constexpr double kMasksThreshold = 0.05;  // stage the masks when > 5 % of the entries are multi-locus
+
+// Everything only the rare paths touch lives in HBM behind one pointer, so that the kernel's
+// by-value argument block stays in SGPRs (passing it by reference to a non-inlined device
+// function would put it in scratch memory and every hot-loop access with it).
+struct SlowPathArgs {
+    const uint4 *entry;        // full entries (Entry)
+    const uint32_t *entry_read;
+    const uint32_t *read_off;
+    const uint32_t *read_locus;
+    const uint8_t *read_base;
+    const long long *lut;      // 65 x 65, row = x_s
+    LlrModelDev model;
+    int scale_log2;
+};
+
 struct AccumulateArgs {
     // packed pileup (pack_host.hpp), all in HBM
     const uint32_t *blk_off;   // num_blocks * stride
     uint32_t stride;           // num_loci + 1
-    uint32_t num_loci;
-    const uint4 *entry_a;      // EntryA
-    const uint4 *entry_b;      // EntryB
-    const uint32_t *read_off;
-    const uint32_t *read_locus;
-    const uint8_t *read_base;
+    const uint32_t *entry32;   // compact entries
+    const uint32_t *mask32;    // 8-locus windows
+    const uint4 *entry;        // full entries (Entry), for locus ranges too deep to stage
+    const uint32_t *range_off; // num_ranges + 1 locus boundaries
+    uint32_t num_ranges;
+    const SlowPathArgs *slow;  // in HBM
     // tiles: upper-triangular block pairs, row-major
     const uint16_t *tile_row;
     const uint16_t *tile_col;
     uint32_t tile_begin;       // first tile of this launch
-    uint32_t n_chunks;         // locus chunks per tile (workgroups per tile)
-    uint32_t chunk_loci;       // loci per chunk
+    uint32_t n_chunks;         // workgroups per tile
+    uint32_t chunk_ranges;     // locus ranges per workgroup
     // log-likelihood ratios, fixed point
     const long long *lut;      // 65 x 65, row = x_s
-    LlrModelDev model;
-    int scale_log2;
     // outputs
     int64_t *acc;              // tile-major: [tile][B*B]
     unsigned long long *counters;  // [0] incidences examined, [1] read pairs accumulated
 };
 
-hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, uint32_t n_tiles,
-                             hipStream_t stream);
+StageGeometry stage_geometry(uint32_t block_cells);
+
+// stage_masks / count_tile / lanes_per_entry (1 or 2): the kernel variants, see accumulate_tiles.
+// count_tile requires fewer than 65536 pairs per cell pair (PackedPileup::pair_bound) and
+// !stage_masks. The accumulator must be zeroed by the caller: the flush is additive.
+hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, bool stage_masks,
+                             bool count_tile, int lanes_per_entry, uint32_t n_tiles, hipStream_t stream);
 
 // mode 0..2 = SECEDO_NORM_*, 3 = raw D
 hipError_t launch_finalize(const int64_t *acc, uint32_t n, uint32_t nb, uint32_t block_cells,
