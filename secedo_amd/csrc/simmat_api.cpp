@@ -173,7 +173,13 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
                           uint32_t num_threads, uint32_t block_cells) {
     if (!h) return fail(SECEDO_E_INVALID_ARG, "handle is null");
     if (!h->have_pileup) return fail(SECEDO_E_STATE, "set_pileup was not called");
-    if (block_cells == 0) block_cells = num_cells >= 4096 ? 128 : 64;
+    if (block_cells == 0) {
+        block_cells = num_cells >= 4096 ? 128 : 64;
+        if (const char *env = std::getenv("SECEDO_BLOCK_CELLS")) {
+            const int v = std::atoi(env);
+            if (v == 64 || v == 128) block_cells = static_cast<uint32_t>(v);
+        }
+    }
     HIP_TRY(hipSetDevice(h->device));
 
     secedo::PackedPileup pk;
@@ -299,6 +305,8 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     if (a.chunk_ranges == 0) a.chunk_ranges = 1;
     a.n_chunks = (h->num_ranges + a.chunk_ranges - 1) / a.chunk_ranges;
     if (a.n_chunks == 0) a.n_chunks = 1;
+    a.debug = 0;
+    if (const char *env = std::getenv("SECEDO_DEBUG_ABLATE")) a.debug = static_cast<uint32_t>(std::atoi(env));
     a.lut = h->lut.as<long long>();
     a.slow = h->slow_args.as<secedo::SlowPathArgs>();
     a.acc = d_acc;
@@ -306,13 +314,10 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
 
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(unsigned long long), s));
     HIP_TRY(hipEventRecord(h->ev_begin, s));
-    int lanes_per_entry = 1;
-    if (const char *env = std::getenv("SECEDO_LANES_PER_ENTRY")) lanes_per_entry = std::atoi(env);
     // 16-bit pair counters per cell pair are safe when no cell pair can collect 65536 pairs
     bool count_tile = !h->stage_masks && h->pair_bound < 65536;
     if (const char *env = std::getenv("SECEDO_COUNT_TILE")) count_tile = count_tile && std::atoi(env) != 0;
-    HIP_TRY(secedo::launch_accumulate(a, h->block_cells, h->stage_masks, count_tile, lanes_per_entry,
-                                      n_tiles, s));
+    HIP_TRY(secedo::launch_accumulate(a, h->block_cells, h->stage_masks, count_tile, n_tiles, s));
     HIP_TRY(hipEventRecord(h->ev_end, s));
     h->timed = true;
     return SECEDO_OK;

@@ -34,6 +34,17 @@ __device__ __forceinline__ double log_add(double a, double b) {
     return hi + log1p(exp(lo - hi));
 }
 
+// wave64 inclusive prefix sum in registers (DPP row shifts + row broadcasts; no LDS traffic)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xA, 0xF, true);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xC, 0xF, true);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // D(x_s, x_d) outside the table: closed form in log space (llr_table.hpp)
 __device__ __noinline__ long long llr_fixed_device(const SlowPathArgs *sp, uint32_t xs, uint32_t xd) {
     const LlrModelDev m = sp->model;
@@ -100,13 +111,26 @@ __device__ __noinline__ long long pair_value_full(const SlowPathArgs *sp, uint32
 //         to fixed point when it flushes (exact integer arithmetic, so the result is bit-identical
 //         to the int64 tile). Needs < 65536 pairs per cell pair, which the host guarantees from
 //         the pileup's pair bound; joint terms bypass the tile (global atomics).
-// G:      lanes that share one row-side entry: lane (sub, k) = (lane / G, lane % G) walks the
-//         column entries j0 + k, j0 + k + G, ... of entry `sub` of its wave's batch.
-template <int B, int THREADS, int CAPJ, int CAPL, bool MASKS, bool COUNTS, int G>
+// HCAP:   pairs of one wave batch that are flattened over the lanes (below); deeper batches fall
+//         back to one lane per row-side entry.
+//
+// Work distribution. A workgroup walks its locus ranges; per range the column side (block J) is
+// staged in LDS. Each wave then pulls batches of 64 consecutive row-side entries (block I). A lane's
+// entry pairs with the c = j1 - j0 column entries of its locus, and c varies from lane to lane, so
+// the batch's pairs are FLATTENED: a wave prefix sum over c gives every entry a slice [P, P + c) of
+// the batch's T pairs, the slice is filled with the owning lane's number in a per-wave LDS strip,
+// and pair p is then handled by lane p % 64 -- every lane busy until the batch's last 64 pairs.
+template <int B, int THREADS, int CAPJ, int CAPL, int HCAP, bool MASKS, bool COUNTS>
 __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs a) {
     static_assert(!(MASKS && COUNTS), "the count tile is for the sparse-loci variant");
-    // LDS: [ tile | sJ CAPJ u16 | sOff CAPL+2 u16 | sJm CAPJ u32 (MASKS) | sLut (MASKS) | s_next ]
     constexpr size_t TILE_BYTES = (size_t)B * B * (COUNTS ? 4 : 8);
+    constexpr int WAVES = THREADS / 64;
+    constexpr int JPT = (CAPJ + THREADS - 1) / THREADS;      // staged column entries per thread
+    constexpr int OPT = (CAPL + 1 + THREADS - 1) / THREADS;  // staged offsets per thread
+    constexpr size_t WAVE_BYTES = (size_t)HCAP + 64 * 8 + (MASKS ? 64 * 4 : 0);
+
+    // LDS: [ tile | sJ CAPJ u16 | sOff CAPL+2 u16 | sJm CAPJ u32, sLut (MASKS) | s_next | per wave:
+    //        owner HCAP u8, wrec 64 x {entry, j0 - P}, wm 64 u32 (MASKS) ]
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long *tile64 = reinterpret_cast<unsigned long long *>(lds_raw);
     uint32_t *tile32 = reinterpret_cast<uint32_t *>(lds_raw);
@@ -115,18 +139,16 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     uint32_t *sJm = reinterpret_cast<uint32_t *>(sOff + CAPL + 2);
     long long *sLut = reinterpret_cast<long long *>(sJm + (MASKS ? CAPJ : 0));
     uint32_t *s_next = reinterpret_cast<uint32_t *>(sLut + (MASKS ? SLUT_DIM * SLUT_DIM : 0));
-
-    constexpr int JPT = (CAPJ + THREADS - 1) / THREADS;      // staged column entries per thread
-    constexpr int OPT = (CAPL + 1 + THREADS - 1) / THREADS;  // staged offsets per thread
-    constexpr int WAVES = THREADS / 64;
-    constexpr uint32_t EPB = 64 / G;                         // row-side entries per wave batch
+    unsigned char *wave_base = reinterpret_cast<unsigned char *>(s_next + 4) + (threadIdx.x >> 6) * WAVE_BYTES;
+    unsigned char *owner = wave_base;
+    uint2 *wrec = reinterpret_cast<uint2 *>(wave_base + HCAP);
+    uint32_t *wm = reinterpret_cast<uint32_t *>(wave_base + HCAP + 64 * 8);
 
     const uint32_t t = a.tile_begin + blockIdx.x / a.n_chunks;
     const uint32_t chunk = blockIdx.x % a.n_chunks;
     const uint32_t I = a.tile_row[t], J = a.tile_col[t];
     const bool diag = (I == J);
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t sub = lane / G, kk = lane % G;
 
     if (COUNTS) {
         for (uint32_t i = tid; i < B * B; i += THREADS) tile32[i] = 0u;
@@ -145,6 +167,52 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     const long long d10 = a.lut[1 * LUT_DIM + 0], d01 = a.lut[0 * LUT_DIM + 1];
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B;
     unsigned long long n_updates = 0, n_pairs = 0;
+    uint32_t upd = 0, skipped = 0;  // per range, 32-bit, per lane
+    uint32_t upd_w = 0;             // per range, wave-uniform (lane 0 reports it)
+    // inside a diagonal tile pairs of the same cell are skipped (:215); elsewhere cells differ
+    const uint32_t cell_test = diag ? C_CELL : 0u;
+
+    // one (read pair, shared locus) incidence: row-side entry `rec` (mask m1, global index g1)
+    // against column-side entry `w` (staged index jc, global index g2)
+    auto pair = [&](uint32_t rec, uint32_t m1, uint32_t w, uint32_t jc, uint32_t g1, uint32_t g2) {
+        const uint32_t x = rec ^ w, both = rec & w;
+        // reads that were both never flushed do not pair (:407-408)
+        if ((both & C_TAIL) != 0u || ((x & cell_test) == 0u && diag)) return;
+        ++upd;
+        const bool differ = (x & (3u << C_BASE_SHIFT)) != 0u;
+        const uint32_t cell = (rec & C_CELL) * B + (w & C_CELL);
+        if (__builtin_expect((both & C_MULTI) != 0u, MASKS ? 1 : 0)) {
+            // both reads cover further loci: joint (x_s, x_d) term, owned by their first shared locus
+            long long v = differ ? d01 : d10;
+            bool owner_here = true;
+            if (MASKS && ((rec | w) & C_WIDE) == 0u) {
+                const uint32_t m2 = sJm[jc];
+                owner_here = (m1 & m2 & 0xFFu) == 0u;
+                const uint32_t shared = ((m1 & m2) >> 8) & 0xFFu;
+                if (shared) {
+                    const uint32_t y = m1 ^ m2;
+                    const uint32_t diff = ((y >> 16) | (y >> 24)) & shared;
+                    const uint32_t nd = __popc(diff);
+                    const uint32_t xd = nd + (differ ? 1u : 0u);
+                    const uint32_t xs = __popc(shared) - nd + (differ ? 0u : 1u);
+                    v = sLut[xs * SLUT_DIM + xd];
+                }
+            } else {
+                v = pair_value_full(a.slow, g1, g2);
+                owner_here = (v != NO_PAIR);
+            }
+            if (owner_here) {
+                if (COUNTS) atomicAdd(&dst[cell], (unsigned long long)v);
+                else atomicAdd(&tile64[cell], (unsigned long long)v);
+            } else {
+                ++skipped;
+            }
+        } else if (COUNTS) {
+            atomicAdd(&tile32[cell], differ ? 0x10000u : 1u);
+        } else {
+            atomicAdd(&tile64[cell], (unsigned long long)(differ ? d01 : d10));
+        }
+    };
 
     // the next range's column side, in flight in registers while the current range is paired
     uint32_t pJ[JPT], pM[MASKS ? JPT : 1], pO[OPT];
@@ -201,80 +269,114 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
         if (r + 1 < r_end) prefetch(r + 1);
 
         const uint32_t nI = ie - ib;
-        uint32_t upd = 0, skipped = 0;  // per range, 32-bit
+        upd = 0;
+        upd_w = 0;
+        skipped = 0;
         if (staged) {
-            // each wave pulls batches of EPB consecutive row-side entries (the next batch's
-            // records already in flight) and pairs them against the staged column
-            const uint32_t n_batch = (nI + EPB - 1u) / EPB;
+            const uint32_t n_batch = (nI + 63u) / 64u;
             uint32_t cur = tid >> 6;
             uint32_t rec = 0, m1 = 0;
-            if (cur < n_batch && cur * EPB + sub < nI) {
-                rec = a.entry32[ib + cur * EPB + sub];
-                if (MASKS) m1 = a.mask32[ib + cur * EPB + sub];
+            if (cur < n_batch && cur * 64u + lane < nI) {
+                rec = a.entry32[ib + cur * 64u + lane];
+                if (MASKS) m1 = a.mask32[ib + cur * 64u + lane];
             }
             while (cur < n_batch) {
                 uint32_t nxt = 0;
                 if (lane == 0) nxt = atomicAdd(s_next, 1u);
                 nxt = __builtin_amdgcn_readfirstlane(nxt);
                 uint32_t rec_n = 0, m1_n = 0;
-                if (nxt < n_batch && nxt * EPB + sub < nI) {
-                    rec_n = a.entry32[ib + nxt * EPB + sub];
-                    if (MASKS) m1_n = a.mask32[ib + nxt * EPB + sub];
+                if (nxt < n_batch && nxt * 64u + lane < nI) {  // next batch's records in flight
+                    rec_n = a.entry32[ib + nxt * 64u + lane];
+                    if (MASKS) m1_n = a.mask32[ib + nxt * 64u + lane];
                 }
-                const uint32_t i = cur * EPB + sub;
+                const uint32_t i = cur * 64u + lane;
+                uint32_t j0 = 0, c = 0;
                 if (i < nI) {
                     const uint32_t lrel = rec >> 16;
-                    uint32_t j = (diag ? i + 1u : (uint32_t)sOff[lrel]) + kk;
+                    j0 = diag ? i + 1u : (uint32_t)sOff[lrel];
                     const uint32_t j1 = sOff[lrel + 1];
-                    const uint32_t row = (rec & C_CELL) * B;
-                    // in a diagonal tile equal cells must be skipped (:215): make the test
-                    // "(x & cell_mask) != 0 or not diagonal" a single AND against a constant
-                    const uint32_t cell_test = diag ? C_CELL : 0u;
-                    uint32_t w2 = (j < j1) ? (uint32_t)sJ[j] : 0u;
-                    while (j < j1) {
-                        const uint32_t w = w2, jc = j;
-                        j += G;
-                        if (j < j1) w2 = sJ[j];  // next column entry in flight across the atomic
-                        const uint32_t x = rec ^ w, both = rec & w;
-                        // skip pairs of reads that were both never flushed (:407-408) and, inside a
-                        // diagonal tile, pairs of the same cell (:215)
-                        const bool ok = (both & C_TAIL) == 0u && ((x & cell_test) != 0u || !diag);
-                        if (ok) {
-                            ++upd;
-                            const bool differ = (x & (3u << C_BASE_SHIFT)) != 0u;
-                            if (__builtin_expect((both & C_MULTI) != 0u, MASKS ? 1 : 0)) {
-                                // both reads cover further loci: joint (x_s, x_d) term
-                                long long v = differ ? d01 : d10;
-                                bool owner = true;
-                                if (MASKS && ((rec | w) & C_WIDE) == 0u) {
-                                    const uint32_t m2 = sJm[jc];
-                                    owner = (m1 & m2 & 0xFFu) == 0u;  // else an earlier shared locus owns it
-                                    const uint32_t shared = ((m1 & m2) >> 8) & 0xFFu;
-                                    if (shared) {
-                                        const uint32_t y = m1 ^ m2;
-                                        const uint32_t diff = ((y >> 16) | (y >> 24)) & shared;
-                                        const uint32_t nd = __popc(diff);
-                                        const uint32_t xd = nd + (differ ? 1u : 0u);
-                                        const uint32_t xs = __popc(shared) - nd + (differ ? 0u : 1u);
-                                        v = sLut[xs * SLUT_DIM + xd];
-                                    }
-                                } else {
-                                    v = pair_value_full(a.slow, ib + i, jb + jc);
-                                    owner = (v != NO_PAIR);
-                                }
-                                if (owner) {
-                                    if (COUNTS) atomicAdd(&dst[row + (w & C_CELL)], (unsigned long long)v);
-                                    else atomicAdd(&tile64[row + (w & C_CELL)], (unsigned long long)v);
-                                } else {
-                                    ++skipped;
-                                }
-                            } else if (COUNTS) {
-                                atomicAdd(&tile32[row + (w & C_CELL)], differ ? 0x10000u : 1u);
-                            } else {
-                                atomicAdd(&tile64[row + (w & C_CELL)], (unsigned long long)(differ ? d01 : d10));
+                    c = j1 > j0 ? j1 - j0 : 0u;
+                }
+                // wave inclusive prefix sum of c
+                const uint32_t pin = wave_inclusive_scan(c);
+                const uint32_t total = __builtin_amdgcn_readlane(pin, 63);
+                const uint32_t pex = pin - c;
+                if (a.debug & 8u) { cur = nxt; rec = rec_n; m1 = m1_n; continue; }
+                if (total <= (uint32_t)HCAP) {
+                    // flatten: pair p of the batch belongs to lane owner[p]
+                    if (!(a.debug & 4u))
+                    for (uint32_t p = pex; p < pin; ++p) owner[p] = (unsigned char)lane;
+                    // what a pair needs of its row-side entry: the entry's low 16 bits, its tile row
+                    // (element index) in the high 16, and j0 - P so that column index = that + p
+                    wrec[lane] = make_uint2((rec & 0xFFFFu) | (((rec & C_CELL) * B) << 16), j0 - pex);
+                    if (MASKS) wm[lane] = m1;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (!MASKS) {
+                        // sparse-loci variants: single-locus pairs only in the hot loop; the (rare)
+                        // pairs of two multi-locus reads are picked up by the second loop
+                        // Uniform trip count, two pairs per lane and trip (independent LDS read
+                        // chains), lanes past the end clamped and masked: keeps the loop free of
+                        // exec-mask bookkeeping.
+                        uint32_t multi_seen = 0;
+                        const uint32_t last = total - 1u;
+                        for (uint32_t base = 0; base < ((a.debug & 2u) ? 0u : total); base += 128u) {
+                            const uint32_t pa = base + lane, pb = pa + 64u;
+                            const uint32_t oa = owner[min(pa, last)], ob = owner[min(pb, last)];
+                            const uint2 ra = wrec[oa], rb = wrec[ob];
+                            const uint32_t wa = sJ[ra.y + min(pa, last)], wb = sJ[rb.y + min(pb, last)];
+                            const uint32_t xa = ra.x ^ wa, ba = ra.x & wa;
+                            const uint32_t xb = rb.x ^ wb, bb = rb.x & wb;
+                            // reads both never flushed do not pair (:407-408); inside a diagonal
+                            // tile equal cells do not pair (:215)
+                            const bool oka = pa < total && (ba & C_TAIL) == 0u && ((xa & cell_test) != 0u || !diag);
+                            const bool okb = pb < total && (bb & C_TAIL) == 0u && ((xb & cell_test) != 0u || !diag);
+                            upd += (oka ? 1u : 0u) + (okb ? 1u : 0u);
+                            multi_seen |= (oka ? ba : 0u) | (okb ? bb : 0u);
+                            if (a.debug & 1u) continue;
+                            if (oka && (ba & C_MULTI) == 0u) {
+                                const uint32_t cell = (ra.x >> 16) + (wa & C_CELL);
+                                const bool differ = (xa & (3u << C_BASE_SHIFT)) != 0u;
+                                if (COUNTS) atomicAdd(&tile32[cell], differ ? 0x10000u : 1u);
+                                else atomicAdd(&tile64[cell], (unsigned long long)(differ ? d01 : d10));
+                            }
+                            if (okb && (bb & C_MULTI) == 0u) {
+                                const uint32_t cell = (rb.x >> 16) + (wb & C_CELL);
+                                const bool differ = (xb & (3u << C_BASE_SHIFT)) != 0u;
+                                if (COUNTS) atomicAdd(&tile32[cell], differ ? 0x10000u : 1u);
+                                else atomicAdd(&tile64[cell], (unsigned long long)(differ ? d01 : d10));
                             }
                         }
+                        const bool any_multi = (multi_seen & C_MULTI) != 0u;
+                        if (__ballot(any_multi)) {
+                            for (uint32_t p = lane; p < total; p += 64u) {
+                                const uint32_t o = owner[p];
+                                const uint2 ro = wrec[o];
+                                const uint32_t jc = ro.y + p;
+                                const uint32_t w = sJ[jc];
+                                const uint32_t x = ro.x ^ w, both = ro.x & w;
+                                const bool ok = (both & C_TAIL) == 0u && ((x & cell_test) != 0u || !diag);
+                                if (ok && (both & C_MULTI) != 0u) {
+                                    const long long v = pair_value_full(a.slow, ib + cur * 64u + o, jb + jc);
+                                    const uint32_t cell = (ro.x >> 16) + (w & C_CELL);
+                                    if (v == NO_PAIR) ++skipped;
+                                    else if (COUNTS) atomicAdd(&dst[cell], (unsigned long long)v);
+                                    else atomicAdd(&tile64[cell], (unsigned long long)v);
+                                }
+                            }
+                        }
+                    } else {
+                        for (uint32_t p = lane; p < total; p += 64u) {
+                            const uint32_t o = owner[p];
+                            const uint2 ro = wrec[o];
+                            const uint32_t jc = ro.y + p;
+                            pair(ro.x, wm[o], sJ[jc], jc, ib + cur * 64u + o, jb + jc);
+                        }
                     }
+                    __builtin_amdgcn_wave_barrier();  // the strip is reused by the next batch
+                } else {
+                    // a very deep batch: one lane per row-side entry
+                    for (uint32_t jc = j0; jc < j0 + c; ++jc) pair(rec, m1, sJ[jc], jc, ib + i, jb + jc);
                 }
                 cur = nxt;
                 rec = rec_n;
@@ -305,8 +407,9 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                 }
             }
         }
-        n_updates += upd;
-        n_pairs += upd - skipped;
+        const uint32_t upd_all = upd + (lane == 0u ? upd_w : 0u);
+        n_updates += upd_all;
+        n_pairs += (unsigned long long)upd_all - skipped;
     }
     __syncthreads();
 
@@ -403,13 +506,14 @@ __global__ __launch_bounds__(256) void write_matrix(const long long *acc, uint32
     }
 }
 
-template <int B, int THREADS, int CAPJ, int CAPL, bool MASKS, bool COUNTS, int G>
-hipError_t launch_acc_g(const AccumulateArgs &args, uint32_t grid, hipStream_t stream) {
+template <int B, int THREADS, int CAPJ, int CAPL, int HCAP, bool MASKS, bool COUNTS>
+hipError_t launch_acc(const AccumulateArgs &args, uint32_t grid, hipStream_t stream) {
     constexpr size_t lds = (size_t)B * B * (COUNTS ? 4 : 8) + (size_t)CAPJ * 2 + ((size_t)CAPL + 2) * 2
-            + (MASKS ? (size_t)CAPJ * 4 + SLUT_DIM * SLUT_DIM * 8 : 0) + 16;
+            + (MASKS ? (size_t)CAPJ * 4 + SLUT_DIM * SLUT_DIM * 8 : 0) + 16
+            + (size_t)(THREADS / 64) * ((size_t)HCAP + 64 * 8 + (MASKS ? 64 * 4 : 0));
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static_assert((CAPL + 2) % 4 == 0 && CAPJ % 8 == 0, "alignment of the LDS carve-up");
-    auto kern = &accumulate_tiles<B, THREADS, CAPJ, CAPL, MASKS, COUNTS, G>;
+    static_assert((CAPL + 2) % 4 == 0 && CAPJ % 8 == 0 && HCAP % 16 == 0, "alignment of the LDS carve-up");
+    auto kern = &accumulate_tiles<B, THREADS, CAPJ, CAPL, HCAP, MASKS, COUNTS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -417,32 +521,25 @@ hipError_t launch_acc_g(const AccumulateArgs &args, uint32_t grid, hipStream_t s
     return hipGetLastError();
 }
 
-template <int B, int THREADS, int CAPJ, int CAPL, bool MASKS, bool COUNTS>
-hipError_t launch_acc(const AccumulateArgs &args, uint32_t grid, int lanes_per_entry, hipStream_t stream) {
-    if (lanes_per_entry == 2) return launch_acc_g<B, THREADS, CAPJ, CAPL, MASKS, COUNTS, 2>(args, grid, stream);
-    return launch_acc_g<B, THREADS, CAPJ, CAPL, MASKS, COUNTS, 1>(args, grid, stream);
-}
-
 }  // namespace
 
 StageGeometry stage_geometry(uint32_t block_cells) {
-    if (block_cells == 128) return StageGeometry{kCapJ128, kCapL128, kCapJ128M, kCapL128M, kMasksThreshold};
+    if (block_cells == 128) return StageGeometry{kCapJ128, kCapL128, kCapJ128, kCapL128, 2.0 /* never */};
     return StageGeometry{kCapJ64, kCapL64, kCapJ64M, kCapL64M, kMasksThreshold};
 }
 
 hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, bool stage_masks,
-                             bool count_tile, int lanes_per_entry, uint32_t n_tiles, hipStream_t stream) {
+                             bool count_tile, uint32_t n_tiles, hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
     const uint32_t grid = n_tiles * args.n_chunks;
-    const int g = lanes_per_entry;
     if (block_cells == 128) {
-        if (stage_masks) return launch_acc<128, 1024, kCapJ128M, kCapL128M, true, false>(args, grid, g, stream);
-        if (count_tile) return launch_acc<128, 1024, kCapJ128, kCapL128, false, true>(args, grid, g, stream);
-        return launch_acc<128, 1024, kCapJ128, kCapL128, false, false>(args, grid, g, stream);
+        // the 128 KiB int64 tile leaves no room for the window masks: joint terms go through HBM
+        if (count_tile) return launch_acc<128, 1024, kCapJ128, kCapL128, 1024, false, true>(args, grid, stream);
+        return launch_acc<128, 1024, kCapJ128, kCapL128, 512, false, false>(args, grid, stream);
     }
-    if (stage_masks) return launch_acc<64, 256, kCapJ64M, kCapL64M, true, false>(args, grid, g, stream);
-    if (count_tile) return launch_acc<64, 256, kCapJ64, kCapL64, false, true>(args, grid, g, stream);
-    return launch_acc<64, 256, kCapJ64, kCapL64, false, false>(args, grid, g, stream);
+    if (stage_masks) return launch_acc<64, 256, kCapJ64M, kCapL64M, 1024, true, false>(args, grid, stream);
+    if (count_tile) return launch_acc<64, 256, kCapJ64, kCapL64, 1024, false, true>(args, grid, stream);
+    return launch_acc<64, 256, kCapJ64, kCapL64, 1024, false, false>(args, grid, stream);
 }
 
 hipError_t launch_finalize(const int64_t *acc, uint32_t n, uint32_t nb, uint32_t block_cells,

@@ -53,6 +53,7 @@ struct AccumulateArgs {
     uint32_t tile_begin;       // first tile of this launch
     uint32_t n_chunks;         // workgroups per tile
     uint32_t chunk_ranges;     // locus ranges per workgroup
+    uint32_t debug;            // ablation switches for profiling (0 in production)
     // log-likelihood ratios, fixed point
     const long long *lut;      // 65 x 65, row = x_s
     // outputs
@@ -62,11 +63,11 @@ struct AccumulateArgs {
 
 StageGeometry stage_geometry(uint32_t block_cells);
 
-// stage_masks / count_tile / lanes_per_entry (1 or 2): the kernel variants, see accumulate_tiles.
-// count_tile requires fewer than 65536 pairs per cell pair (PackedPileup::pair_bound) and
-// !stage_masks. The accumulator must be zeroed by the caller: the flush is additive.
+// stage_masks / count_tile: the kernel variants, see accumulate_tiles. count_tile requires fewer
+// than 65536 pairs per cell pair (PackedPileup::pair_bound) and !stage_masks; stage_masks exists
+// for 64-cell tiles only. The accumulator must be zeroed by the caller: the flush is additive.
 hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, bool stage_masks,
-                             bool count_tile, int lanes_per_entry, uint32_t n_tiles, hipStream_t stream);
+                             bool count_tile, uint32_t n_tiles, hipStream_t stream);
 
 // mode 0..2 = SECEDO_NORM_*, 3 = raw D
 hipError_t launch_finalize(const int64_t *acc, uint32_t n, uint32_t nb, uint32_t block_cells,
