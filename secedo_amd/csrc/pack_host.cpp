@@ -46,14 +46,14 @@ struct IdMap {
 }  // namespace
 
 std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t mfl,
-                        uint32_t num_threads, uint32_t block_cells, const StageGeometry &geo,
-                        PackedPileup *out) {
+                        uint32_t num_threads, uint32_t block_cells,
+                        StageGeometry (*geometry)(uint32_t block_cells), PackedPileup *out) {
     if (!in.chr_locus_off || !in.locus_entry_off) return "null pileup arrays";
     if ((in.id_base16 != nullptr) == (in.id_base32 != nullptr))
         return "exactly one of id_base16 / id_base32 must be given";
     if (num_threads == 0) return "num_threads must be positive";
     if (num_cells == 0 || num_cells > 65535) return "num_cells must be in [1, 65535]";
-    if (block_cells != 64 && block_cells != 128) return "block_cells must be 64 or 128";
+    if (block_cells != 0 && block_cells != 64 && block_cells != 128) return "block_cells must be 0, 64 or 128";
     const uint32_t L = in.n_loci();
     const uint64_t E = in.n_entries();
     if (E >= 0xFFFFFFF0ull) return "more than 2^32 pileup entries are not supported";
@@ -62,8 +62,6 @@ std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t m
     PackedPileup &pk = *out;
     pk = PackedPileup();
     pk.num_cells = num_cells;
-    pk.block_cells = block_cells;
-    pk.num_blocks = (num_cells + block_cells - 1) / block_cells;
     pk.num_loci = L;
     pk.raw_entries = E;
 
@@ -165,6 +163,19 @@ std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t m
         }
     }
 
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t n = pk.read_off[r + 1] - pk.read_off[r];
+        if (n > 1) pk.multi_entries += n;
+    }
+    if (block_cells == 0) {
+        const StageGeometry g64 = geometry(64);
+        const bool clustered = n_kept && static_cast<double>(pk.multi_entries) > g64.masks_threshold * static_cast<double>(n_kept);
+        block_cells = (clustered || num_cells <= 64) ? 64 : 128;
+    }
+    const StageGeometry geo = geometry(block_cells);
+    pk.block_cells = block_cells;
+    pk.num_blocks = (num_cells + block_cells - 1) / block_cells;
+
     // ---- pass 3: bin by (cell block, locus), emit the entry records --------------------------
     const uint32_t B = block_cells, nb = pk.num_blocks;
     const size_t stride = static_cast<size_t>(L) + 1;
@@ -182,10 +193,6 @@ std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t m
         }
     }
     // ---- pass 3b: locus ranges for LDS staging (greedy; one partition shared by all blocks) ----
-    for (uint32_t r = 0; r < R; ++r) {
-        const uint32_t n = pk.read_off[r + 1] - pk.read_off[r];
-        if (n > 1) pk.multi_entries += n;
-    }
     pk.stage_masks = n_kept && static_cast<double>(pk.multi_entries) > geo.masks_threshold * static_cast<double>(n_kept);
     pk.cap_entries = pk.stage_masks ? geo.cap_entries_masks : geo.cap_entries_plain;
     pk.cap_loci = pk.stage_masks ? geo.cap_loci_masks : geo.cap_loci_plain;

@@ -102,8 +102,10 @@ struct PackedPileup {
 };
 
 // Returns an empty string on success, else an error message (invalid input).
+// block_cells: 64 or 128, or 0 = choose: 128-cell tiles amortise the per-batch work best, but
+// only 64-cell tiles leave LDS room for the window masks that clustered loci need.
 std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t max_fragment_length,
-                        uint32_t num_threads, uint32_t block_cells, const StageGeometry &geo,
-                        PackedPileup *out);
+                        uint32_t num_threads, uint32_t block_cells,
+                        StageGeometry (*geometry)(uint32_t block_cells), PackedPileup *out);
 
 }  // namespace secedo

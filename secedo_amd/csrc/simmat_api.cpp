@@ -174,7 +174,6 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
     if (!h) return fail(SECEDO_E_INVALID_ARG, "handle is null");
     if (!h->have_pileup) return fail(SECEDO_E_STATE, "set_pileup was not called");
     if (block_cells == 0) {
-        block_cells = num_cells >= 4096 ? 128 : 64;
         if (const char *env = std::getenv("SECEDO_BLOCK_CELLS")) {
             const int v = std::atoi(env);
             if (v == 64 || v == 128) block_cells = static_cast<uint32_t>(v);
@@ -184,12 +183,12 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
 
     secedo::PackedPileup pk;
     const std::string err = secedo::pack_pileup(h->view, num_cells, max_fragment_length, num_threads,
-                                                block_cells, secedo::stage_geometry(block_cells), &pk);
+                                                block_cells, &secedo::stage_geometry, &pk);
     h->have_pileup = false;  // the borrow ends here
     if (!err.empty()) return fail(SECEDO_E_INVALID_ARG, err);
 
     h->num_cells = num_cells;
-    h->block_cells = block_cells;
+    h->block_cells = pk.block_cells;
     h->num_blocks = pk.num_blocks;
     h->num_loci = pk.num_loci;
     h->num_entries = pk.num_entries;
@@ -296,7 +295,7 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     a.tile_col = h->tile_col.as<uint16_t>();
     a.tile_begin = tile_begin;
     // enough workgroups to fill 256 CUs several times over; a workgroup walks whole locus ranges
-    uint32_t target_wgs = 2048;
+    uint32_t target_wgs = h->block_cells == 128 ? 576 : 2048;  // 1024- vs 256-thread workgroups
     if (const char *env = std::getenv("SECEDO_TARGET_WGS")) target_wgs = std::max(1, std::atoi(env));
     uint32_t chunks = 1;
     if (n_tiles && n_tiles < target_wgs) chunks = (target_wgs + n_tiles - 1) / n_tiles;
