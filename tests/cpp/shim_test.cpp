@@ -1,0 +1,75 @@
+// shim_test.cpp -- pure C++ host (no Python, no torch) through include/secedo_simmat.hpp.
+//
+// Stand-ins for the two reference types the shim is templated on, written for this test:
+// `PosData` carries the three members of the reference's per-locus record
+// (reference: sequenced_data.hpp:26-37) and `Mat` the owning row-major matrix subset the boundary
+// returns (reference: util/mat.hpp:86 constructor, :117 element access, rows()/cols()).
+//
+// usage: shim_test <pileup.bin> <num_cells> <mfl> <num_threads> <normalization> <out.f64>
+//   pileup.bin = the reference's binary pileup records (u32 position, u16 coverage,
+//   u32 read_ids[coverage], u16 id_base[coverage]; util/pileup_reader.cpp:166-179), one chromosome.
+#include "secedo_simmat.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+struct PosData {
+    uint32_t position;
+    std::vector<uint32_t> read_ids;
+    std::vector<uint16_t> group_ids_bases;
+};
+
+class Mat {
+  public:
+    Mat(uint32_t r, uint32_t c) : r_(r), c_(c), el_(new double[static_cast<size_t>(r) * c]()) {}
+    Mat(Mat &&) = default;
+    Mat(const Mat &) = delete;
+    double &operator()(uint32_t i, uint32_t j) { return el_[static_cast<size_t>(i) * c_ + j]; }
+    uint32_t rows() const { return r_; }
+    uint32_t cols() const { return c_; }
+    const double *data() const { return el_.get(); }
+
+  private:
+    uint32_t r_, c_;
+    std::unique_ptr<double[]> el_;
+};
+
+int main(int argc, char **argv) {
+    if (argc != 7) {
+        std::fprintf(stderr, "usage: %s pileup.bin num_cells mfl num_threads normalization out.f64\n", argv[0]);
+        return 2;
+    }
+    std::ifstream f(argv[1], std::ios::binary);
+    std::vector<PosData> chromosome;
+    while (true) {
+        uint32_t position;
+        uint16_t coverage;
+        if (!f.read(reinterpret_cast<char *>(&position), 4)) break;
+        f.read(reinterpret_cast<char *>(&coverage), 2);
+        PosData pd{position, std::vector<uint32_t>(coverage), std::vector<uint16_t>(coverage)};
+        f.read(reinterpret_cast<char *>(pd.read_ids.data()), coverage * 4);
+        f.read(reinterpret_cast<char *>(pd.group_ids_bases.data()), coverage * 2);
+        chromosome.push_back(std::move(pd));
+    }
+    const uint32_t n = static_cast<uint32_t>(std::atoi(argv[2]));
+    std::vector<uint32_t> identity(n);
+    for (uint32_t i = 0; i < n; ++i) identity[i] = i;
+    try {
+        Mat m = secedo_amd::computeSimilarityMatrix<Mat, PosData>(
+                {chromosome}, n, static_cast<uint32_t>(std::atoi(argv[3])), identity, 0.01, 0.5, 0.01,
+                static_cast<uint32_t>(std::atoi(argv[4])), "", argv[5]);
+        std::ofstream out(argv[6], std::ios::binary);
+        out.write(reinterpret_cast<const char *>(m.data()), sizeof(double) * n * n);
+    } catch (const std::logic_error &e) {
+        std::fprintf(stderr, "logic_error: %s\n", e.what());
+        return 3;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 4;
+    }
+    return 0;
+}

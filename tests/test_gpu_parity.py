@@ -120,3 +120,33 @@ def test_edge_inputs():
     p = from_rows([[(10, [(1, 0, 0), (2, 9, 1)])]])
     with pytest.raises(secedo_amd.SecedoError):
         secedo_amd.compute_similarity_matrix(p, 2, 1000, np.arange(10, dtype=np.uint32), 0.01, 0.5, 0.01, 1)
+
+
+def test_cpp_host_without_torch(tmp_path):
+    """Pure C++ host through include/secedo_simmat.hpp (system HIP runtime, no Python in the process),
+    fed with the reference's binary pileup record format; must equal the Python-driven result."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "shim_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cpp", "shim_test.cpp"), "-o", exe,
+                    "-L" + os.path.join(root, "secedo_amd"), "-lsecedo_simmat",
+                    "-Wl,-rpath," + os.path.join(root, "secedo_amd")], check=True)
+    n = 90
+    p = random_pileup(41, n, 1, 600, 12, 400, dup_frac=0.03)
+    path = str(tmp_path / "p.bin")
+    with open(path, "wb") as f:  # record layout of reference util/pileup_reader.cpp:166-179
+        for l in range(p.n_loci):
+            b, e = int(p.locus_entry_off[l]), int(p.locus_entry_off[l + 1])
+            f.write(np.uint32(p.locus_pos[l]).tobytes())
+            f.write(np.uint16(e - b).tobytes())
+            f.write(p.read_ids[b:e].astype(np.uint32).tobytes())
+            f.write(p.id_base[b:e].astype(np.uint16).tobytes())
+    for norm in secedo_amd.NORMALIZATIONS:
+        out = str(tmp_path / ("m_%s.f64" % norm))
+        subprocess.run([exe, path, str(n), "1000", "4", norm, out], check=True)
+        got = np.fromfile(out, dtype=np.float64).reshape(n, n)
+        ref = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 4, norm)
+        assert gu.normwise_err(got, ref) <= TOL
+        assert np.array_equal(got, secedo_amd.compute_similarity_matrix(p, n, 1000, None, 0.01, 0.5, 0.01, 4, "", norm))
