@@ -149,6 +149,14 @@ def main():
     kern_ms = ev_ms[len(ev_ms) // 2]
 
     if rank == 0:
+        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_traffic.json)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                t = json.load(fh).get(args.workload if not args.clustered and world == 1 else "")
+            if t:
+                traffic = (t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024
+        except (OSError, ValueError, KeyError):
+            traffic = None
         E, L, N = plan.num_entries, plan.num_loci, n_cells
         b_alg = 16 * local_updates + 6 * E / world + 4 * L + 16 * N * N / world  # this rank's launch
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
@@ -175,7 +183,7 @@ def main():
             "wall_s_full_matrix": elapsed / args.steps,
             "prepare_host_s": prepare_s,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "accumulate_tiles", "kernel_ms": kern_ms,
                          "kernel_ms_last_timed_step": last_ms,
                          "algorithmic_bytes": b_alg},
