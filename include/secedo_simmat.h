@@ -99,9 +99,30 @@ int secedo_simmat_set_pileup(secedo_simmat_t *handle, const uint32_t *chr_locus_
                              const uint32_t *id_base32, const uint32_t *group_id_to_pos,
                              uint32_t n_groups);
 
-/* Synchronous (host work + H2D). block_cells: cells per tile edge, 0 = choose (64 or 128). */
+/* Same, for a raw flat pileup that already lives in HBM (device pointers, borrowed until
+ * secedo_simmat_prepare() returns). n_loci = chr_locus_off[n_chr], n_entries = locus_entry_off[n_loci]. */
+int secedo_simmat_set_pileup_device(secedo_simmat_t *handle, const uint32_t *d_chr_locus_off,
+                                    uint32_t n_chr, const uint32_t *d_locus_pos,
+                                    const uint64_t *d_locus_entry_off, const uint32_t *d_read_ids,
+                                    const uint16_t *d_id_base16, const uint32_t *d_id_base32,
+                                    const uint32_t *d_group_id_to_pos, uint32_t n_groups,
+                                    uint32_t n_loci, uint64_t n_entries);
+
+/* Where prepare() packs: 0 = on the GPU, on the host only when the pileup requires it (a read
+ * spanning >= max_fragment_length is split at flushes, reference similarity_matrix.cpp:368-382; the
+ * empty pileup; >= 2^31 entries); 1 = always on the host; 2 = on the GPU or fail (SECEDO_E_LIMIT).
+ * Both paths produce the same packed pileup up to the order of entries inside one (cell block,
+ * locus) group, which the integer accumulation does not depend on. Env SECEDO_PACKING=host|device
+ * overrides. */
+int secedo_simmat_set_packing(secedo_simmat_t *handle, int mode);
+/* 1 if the last prepare() packed on the GPU, else 0. */
+int secedo_simmat_used_device_packing(const secedo_simmat_t *handle);
+
+/* Read assembly, flush schedule, tile packing (see above). Work is enqueued on `stream` with a few
+ * stream synchronisations for scalar read-backs; host packing is synchronous.
+ * block_cells: cells per tile edge, 0 = choose (64 or 128). */
 int secedo_simmat_prepare(secedo_simmat_t *handle, uint32_t num_cells, uint32_t max_fragment_length,
-                          uint32_t num_threads, uint32_t block_cells);
+                          uint32_t num_threads, uint32_t block_cells, void *stream);
 
 /* Geometry after prepare(). Tiles are the upper-triangular (I <= J) cell-block pairs. */
 uint32_t secedo_simmat_num_tiles(const secedo_simmat_t *handle);

@@ -51,7 +51,11 @@ SIGNATURES = {
     "secedo_simmat_destroy": (None, [_vp]),
     "secedo_simmat_set_pileup": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp,
                                            C.c_uint32]),
-    "secedo_simmat_prepare": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "secedo_simmat_set_pileup_device": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                  C.c_uint32, C.c_uint32, C.c_uint64]),
+    "secedo_simmat_set_packing": (C.c_int, [_vp, C.c_int]),
+    "secedo_simmat_used_device_packing": (C.c_int, [_vp]),
+    "secedo_simmat_prepare": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "secedo_simmat_num_tiles": (C.c_uint32, [_vp]),
     "secedo_simmat_block_cells": (C.c_uint32, [_vp]),
     "secedo_simmat_acc_elems": (C.c_uint64, [_vp]),

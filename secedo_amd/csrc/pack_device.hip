@@ -1,0 +1,602 @@
+// pack_device.hip -- device-side packing of the raw flat pileup (see pack_device.hpp).
+//
+// Pipeline (every step a grid-stride kernel or a hipCUB primitive on `stream`):
+//   1  entry -> locus, chromosome; sort entries by (chromosome, read id), stable     [radix sort]
+//   2  runs of equal key = reads; span check (a read longer than max_fragment_length would be split
+//      at a flush: host path); duplicate-position rule per (read, locus) group
+//      (reference: similarity_matrix.cpp:387-395)
+//   3  kept entries -> per-read lists (CSR), multi-locus statistics
+//   4  first-appearance rank of every read, completed-prefix count per locus, flush chain per
+//      chromosome (reference :348-373) -> number of flushed reads F_c -> tail flags (:407-408)
+//   5  entry records (window masks), binning sort by (cell block, locus, cell), block offsets,
+//      pair bound, locus ranges, final gather
+#include "pack_device.hpp"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+
+namespace secedo {
+
+DeviceArena::~DeviceArena() {
+    if (p) (void)hipFree(p);
+}
+
+hipError_t DeviceArena::ensure(size_t n) {
+    if (n <= bytes && p) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    const size_t want = n ? n + n / 8 + 256 : 256;  // head room: sizes vary a little from call to call
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) bytes = want;
+    return e;
+}
+
+namespace {
+
+constexpr int TPB = 256;
+
+inline uint32_t blocks_for(uint64_t n) {
+    return static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((n + TPB - 1) / TPB, 1u << 16)));
+}
+
+struct Scalars {
+    uint32_t error;       // 1 group id outside group_id_to_pos, 2 row outside the matrix, 3 positions not increasing
+    uint32_t need_host;
+    uint32_t num_ranges;
+    uint32_t pad;
+    unsigned long long multi_entries;
+    unsigned long long pair_bound;
+};
+
+struct Raw {  // by-value kernel argument: the raw pileup
+    const uint32_t *chr_locus_off;
+    uint32_t n_chr;
+    const uint32_t *locus_pos;
+    const uint64_t *locus_entry_off;
+    const uint32_t *read_ids;
+    const uint16_t *id_base16;
+    const uint32_t *id_base32;
+    const uint32_t *g2p;
+    uint32_t n_groups;
+    uint32_t n_loci;
+    uint32_t n_entries;
+    __device__ __forceinline__ uint32_t id_base(uint32_t e) const {
+        return id_base16 ? (uint32_t)id_base16[e] : id_base32[e];
+    }
+};
+
+// index of the last element <= x in a non-decreasing array a[0..n) with a[0] <= x  (u64 / u32)
+template <class T>
+__device__ __forceinline__ uint32_t last_le(const T *a, uint32_t n, T x) {
+    uint32_t lo = 0, hi = n;  // invariant: a[lo] <= x, (hi == n or a[hi] > x)
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (a[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// number of elements <= x in a non-decreasing array
+__device__ __forceinline__ uint32_t count_le(const uint32_t *a, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n;  // answer in [lo, hi]
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (a[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_entry_keys(Raw in, uint32_t *entry_locus, unsigned long long *key, uint32_t *val) {
+    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < in.n_entries; e += gridDim.x * TPB) {
+        // locus l with off[l] <= e < off[l+1]: the last offset <= e (empty loci share offsets; the
+        // last of them is the non-empty one)
+        const uint32_t l = last_le<uint64_t>(in.locus_entry_off, in.n_loci + 1, (uint64_t)e);
+        const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
+        entry_locus[e] = l;
+        key[e] = ((unsigned long long)c << 32) | in.read_ids[e];
+        val[e] = e;
+    }
+}
+
+__global__ void k_check_positions(Raw in, Scalars *sc) {
+    for (uint32_t l = blockIdx.x * TPB + threadIdx.x; l + 1 < in.n_loci; l += gridDim.x * TPB) {
+        if (in.locus_pos[l + 1] <= in.locus_pos[l]) {
+            // allowed only across a chromosome boundary
+            const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
+            if (l + 1 < in.chr_locus_off[c + 1]) sc->error = 3;
+        }
+    }
+}
+
+__global__ void k_heads(const unsigned long long *skey, uint32_t n, uint32_t *head) {
+    for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB)
+        head[s] = (s == 0 || skey[s] != skey[s - 1]) ? 1u : 0u;
+}
+
+__global__ void k_run_starts(const uint32_t *head, const uint32_t *run_incl, uint32_t n, uint32_t *run_start) {
+    for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
+        if (head[s]) run_start[run_incl[s] - 1] = s;
+        if (s == n - 1) run_start[run_incl[s]] = n;
+    }
+}
+
+// per read: first entry, start position, span check; marks first entries for the appearance rank
+__global__ void k_run_info(Raw in, const uint32_t *run_start, uint32_t n_runs, const uint32_t *sval,
+                           const uint32_t *entry_locus, uint32_t mfl, uint32_t *first_entry,
+                           uint32_t *start_pos, uint32_t *mark, Scalars *sc) {
+    for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r < n_runs; r += gridDim.x * TPB) {
+        const uint32_t e0 = sval[run_start[r]], e1 = sval[run_start[r + 1] - 1];
+        const uint32_t p0 = in.locus_pos[entry_locus[e0]], p1 = in.locus_pos[entry_locus[e1]];
+        // a read whose entries reach start + mfl can be flushed before its last entry arrives and is
+        // then re-opened as a new read (:368-371, :379-382): that schedule is emulated on the host
+        if (p1 - p0 >= mfl || (unsigned long long)p1 + mfl > 0xFFFFFFFFull) sc->need_host = 1;
+        first_entry[r] = e0;
+        start_pos[r] = p0;
+        mark[e0] = 1u;
+    }
+}
+
+// duplicate-position rule (:387-395) per (read, locus) group of the sorted order
+__global__ void k_dup_rule(Raw in, const unsigned long long *skey, const uint32_t *sval,
+                           const uint32_t *entry_locus, uint32_t n, uint32_t *keep) {
+    for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
+        const uint32_t l = entry_locus[sval[s]];
+        if (s > 0 && skey[s] == skey[s - 1] && entry_locus[sval[s - 1]] == l) continue;  // not a group head
+        uint32_t stored = s;  // position of the stored entry of this (read, locus)
+        bool have = true;
+        keep[s] = 0u;
+        for (uint32_t t = s + 1; t < n && skey[t] == skey[s] && entry_locus[sval[t]] == l; ++t) {
+            keep[t] = 0u;
+            if (have) {
+                // second mate at the stored position: equal base -> ignored; different -> both go
+                if ((in.id_base(sval[t]) & 3u) != (in.id_base(sval[stored]) & 3u)) have = false;
+            } else {
+                stored = t;  // the position is free again: this entry is appended
+                have = true;
+            }
+        }
+        if (have) keep[stored] = 1u;
+    }
+}
+
+__global__ void k_csr(Raw in, const uint32_t *sval, const uint32_t *entry_locus, const uint32_t *keep,
+                      const uint32_t *slot, uint32_t n, uint32_t *read_locus, uint8_t *read_base) {
+    for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
+        if (!keep[s]) continue;
+        const uint32_t e = sval[s];
+        read_locus[slot[s]] = entry_locus[e];
+        read_base[slot[s]] = (uint8_t)(in.id_base(e) & 3u);
+    }
+}
+
+__global__ void k_read_off(const uint32_t *run_start, const uint32_t *slot, const uint32_t *keep,
+                           uint32_t n_runs, uint32_t n, uint32_t *read_off) {
+    for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r <= n_runs; r += gridDim.x * TPB) {
+        read_off[r] = (r < n_runs) ? slot[run_start[r]] : slot[n - 1] + keep[n - 1];
+    }
+}
+
+__global__ void k_multi(const uint32_t *read_off, uint32_t n_runs, Scalars *sc) {
+    unsigned long long local = 0;
+    for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r < n_runs; r += gridDim.x * TPB) {
+        const uint32_t c = read_off[r + 1] - read_off[r];
+        if (c > 1) local += c;
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&sc->multi_entries, local);
+}
+
+// appearance rank of each read; read starts in rank order; per chromosome the first rank
+__global__ void k_ranks(Raw in, const uint32_t *first_entry, const uint32_t *start_pos,
+                        const uint32_t *arank, uint32_t n_runs, uint32_t *run_rank,
+                        uint32_t *starts_by_rank, uint32_t *rbeg) {
+    for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r < n_runs; r += gridDim.x * TPB) {
+        const uint32_t rk = arank[first_entry[r]];
+        run_rank[r] = rk;
+        starts_by_rank[rk] = start_pos[r];
+    }
+    for (uint32_t c = blockIdx.x * TPB + threadIdx.x; c <= in.n_chr; c += gridDim.x * TPB) {
+        rbeg[c] = arank[(uint32_t)in.locus_entry_off[in.chr_locus_off[c]]];
+    }
+}
+
+// completed-prefix count per locus (:348-352): reads of the chromosome with start + mfl <= position
+__global__ void k_completed(Raw in, const uint32_t *starts_by_rank, const uint32_t *rbeg, uint32_t mfl,
+                            uint32_t *cnt) {
+    for (uint32_t l = blockIdx.x * TPB + threadIdx.x; l < in.n_loci; l += gridDim.x * TPB) {
+        const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
+        const uint32_t pos = in.locus_pos[l];
+        cnt[l] = pos < mfl ? 0u : count_le(starts_by_rank + rbeg[c], rbeg[c + 1] - rbeg[c], pos - mfl);
+    }
+}
+
+// flush chain (:356-373): flushed = c(l) whenever c(l) - flushed >= 4 * num_threads. One workgroup
+// per chromosome; the chain is sequential, so lane 0 walks LDS tiles of the counts.
+__global__ __launch_bounds__(TPB) void k_flush_chain(Raw in, const uint32_t *cnt, uint32_t threshold,
+                                                    uint32_t *flushed_out) {
+    __shared__ uint32_t buf[2048];
+    __shared__ uint32_t s_flushed;
+    const uint32_t c = blockIdx.x;
+    const uint32_t l0 = in.chr_locus_off[c], l1 = in.chr_locus_off[c + 1];
+    if (threadIdx.x == 0) s_flushed = 0;
+    for (uint32_t base = l0; base < l1; base += 2048) {
+        const uint32_t n = min(2048u, l1 - base);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += TPB) buf[i] = cnt[base + i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t f = s_flushed;
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t v = buf[i];
+                if (v - f >= threshold) f = v;  // v >= f: the counts never decrease
+            }
+            s_flushed = f;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) flushed_out[c] = s_flushed;
+}
+
+struct RecOut {
+    uint4 *t_entry;
+    uint32_t *t_c32, *t_m32, *t_read;
+    unsigned long long *key2;
+    uint32_t *val2;
+    uint32_t *blk_cnt;
+};
+
+// entry records in per-read (CSR) order + the binning key (cell block, locus, cell)
+__global__ void k_records(Raw in, const unsigned long long *skey, const uint32_t *sval,
+                          const uint32_t *keep, const uint32_t *slot, const uint32_t *run_incl,
+                          const uint32_t *read_off, const uint32_t *read_locus, const uint8_t *read_base,
+                          const uint32_t *run_rank, const uint32_t *rbeg, const uint32_t *flushed,
+                          uint32_t num_cells, uint32_t B, RecOut out, Scalars *sc) {
+    const uint32_t n = in.n_entries, L = in.n_loci;
+    for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
+        if (!keep[s]) continue;
+        const uint32_t r = run_incl[s] - 1;
+        const uint32_t k = slot[s];
+        const uint32_t lo = read_off[r], hi = read_off[r + 1];
+        const uint32_t l = read_locus[k];
+        const uint32_t base = read_base[k];
+        const uint32_t e = sval[s];
+        const uint32_t group = in.id_base(e) >> 2;
+        uint32_t cell = 0;
+        if (group >= in.n_groups) {
+            sc->error = 1;
+        } else {
+            cell = in.g2p[group];
+            if (cell >= num_cells) {
+                sc->error = 2;
+                cell = 0;
+            }
+        }
+        const uint32_t chr = (uint32_t)(skey[s] >> 32);
+        const bool tail = run_rank[r] - rbeg[chr] >= flushed[chr];
+        uint32_t meta = cell | (base << kMetaBaseShift) | (tail ? kMetaTail : 0u);
+        uint32_t masks = 0, bases = 0;
+        bool wide = false;
+        for (uint32_t j = k; j-- > lo;) {
+            const uint32_t dist = l - read_locus[j];
+            if (dist > kNarrowWindow) wide = true;
+            if (dist > kWindow) {
+                meta |= kMetaPrevOvf;
+                break;
+            }
+            masks |= 1u << (dist - 1);
+        }
+        for (uint32_t j = k + 1; j < hi; ++j) {
+            const uint32_t dist = read_locus[j] - l;
+            if (dist > kNarrowWindow) wide = true;
+            if (dist > kWindow) {
+                meta |= kMetaNextOvf;
+                break;
+            }
+            masks |= 1u << (16 + dist - 1);
+            bases |= (uint32_t)(read_base[j] & 1u) << (dist - 1);
+            bases |= (uint32_t)((read_base[j] >> 1) & 1u) << (16 + dist - 1);
+        }
+        const uint32_t blk = cell / B, cib = cell - blk * B;
+        out.t_entry[k] = make_uint4(meta, masks, bases, l);
+        out.t_c32[k] = cib | (base << kC_BaseShift) | (tail ? kC_Tail : 0u) | (hi - lo > 1 ? kC_Multi : 0u)
+                | (wide ? kC_Wide : 0u);
+        out.t_m32[k] = (masks & 0xFFu) | (((masks >> 16) & 0xFFu) << 8) | ((bases & 0xFFu) << 16)
+                | (((bases >> 16) & 0xFFu) << 24);
+        out.t_read[k] = r;
+        out.key2[k] = ((unsigned long long)blk * L + l) * B + cib;
+        out.val2[k] = k;
+        atomicAdd(&out.blk_cnt[(size_t)blk * (L + 1) + l], 1u);
+    }
+}
+
+// sum over loci of (entries of one cell at the locus)^2, per cell: the Cauchy-Schwarz pair bound
+__global__ void k_cell_squares(const unsigned long long *skey2, uint32_t n, uint32_t B, uint32_t L,
+                               unsigned long long *per_cell_sq) {
+    for (uint32_t d = blockIdx.x * TPB + threadIdx.x; d < n; d += gridDim.x * TPB) {
+        if (d > 0 && skey2[d] == skey2[d - 1]) continue;
+        unsigned long long cnt = 1;
+        for (uint32_t t = d + 1; t < n && skey2[t] == skey2[d]; ++t) ++cnt;
+        const unsigned long long key = skey2[d];
+        const uint32_t cib = (uint32_t)(key % B);
+        const uint32_t blk = (uint32_t)((key / B) / L);
+        atomicAdd(&per_cell_sq[(size_t)blk * B + cib], cnt * cnt);
+    }
+}
+
+__global__ void k_max_u64(const unsigned long long *a, uint32_t n, Scalars *sc) {
+    unsigned long long best = 0;
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) best = max(best, a[i]);
+    for (int off = 32; off > 0; off >>= 1) best = max(best, (unsigned long long)__shfl_down(best, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(&sc->pair_bound, best);
+}
+
+// greedy locus ranges (one partition for all cell blocks): the longest range from `s` in which no
+// block has more than cap_entries entries and that has at most cap_loci loci; a locus that exceeds
+// the cap alone becomes a single-locus range. One workgroup; feasibility is monotone in the end.
+__global__ __launch_bounds__(TPB) void k_ranges(const uint32_t *blk_off, uint32_t nb, uint32_t L,
+                                               uint32_t cap_entries, uint32_t cap_loci,
+                                               uint32_t *range_off, Scalars *sc) {
+    const size_t stride = (size_t)L + 1;
+    uint32_t s = 0, nr = 0;
+    if (threadIdx.x == 0) range_off[0] = 0;
+    auto feasible = [&](uint32_t e) {
+        int ok = 1;
+        for (uint32_t b = threadIdx.x; b < nb; b += TPB)
+            if (blk_off[b * stride + e] - blk_off[b * stride + s] > cap_entries) ok = 0;
+        return __syncthreads_and(ok) != 0;
+    };
+    while (s < L) {
+        uint32_t e = s + 1;
+        if (feasible(e)) {
+            uint32_t lo = e, hi = min(L, s + cap_loci);  // lo feasible
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo + 1) / 2;
+                if (feasible(mid)) lo = mid; else hi = mid - 1;
+            }
+            e = lo;
+        }
+        ++nr;
+        if (threadIdx.x == 0) range_off[nr] = e;
+        s = e;
+    }
+    if (threadIdx.x == 0) sc->num_ranges = nr;
+}
+
+__global__ void k_gather(const uint32_t *sval2, uint32_t n, const RecOut tmp, const uint32_t *range_off,
+                         uint32_t n_ranges, uint4 *entry, uint32_t *entry32, uint32_t *mask32,
+                         uint32_t *entry_read) {
+    for (uint32_t d = blockIdx.x * TPB + threadIdx.x; d < n; d += gridDim.x * TPB) {
+        const uint32_t k = sval2[d];
+        const uint4 a = tmp.t_entry[k];
+        const uint32_t r = last_le<uint32_t>(range_off, n_ranges + 1, a.w);
+        entry[d] = a;
+        entry32[d] = tmp.t_c32[k] | ((a.w - range_off[r]) << 16);
+        mask32[d] = tmp.t_m32[k];
+        entry_read[d] = tmp.t_read[k];
+    }
+}
+
+int bits_for(unsigned long long max_value) {
+    int b = 1;
+    while (b < 64 && (max_value >> b) != 0) ++b;
+    return b;
+}
+
+#define HIP_OK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(e__); \
+    } while (0)
+
+}  // namespace
+
+std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, uint32_t mfl,
+                               uint32_t num_threads, uint32_t block_cells,
+                               StageGeometry (*geometry)(uint32_t), hipStream_t stream,
+                               DevicePacked *out, bool *need_host) {
+    *need_host = false;
+    if ((in.id_base16 != nullptr) == (in.id_base32 != nullptr))
+        return "exactly one of id_base16 / id_base32 must be given";
+    if (num_threads == 0) return "num_threads must be positive";
+    if (num_cells == 0 || num_cells > 65535) return "num_cells must be in [1, 65535]";
+    if (block_cells != 0 && block_cells != 64 && block_cells != 128) return "block_cells must be 0, 64 or 128";
+    const uint64_t E64 = in.n_entries;
+    const uint32_t L = in.n_loci, C = in.n_chr;
+    if (E64 >= (1ull << 31) || L == 0 || E64 == 0 || (uint64_t)4 * num_threads > 0xFFFFFFFFull) {
+        *need_host = true;  // sizes this path does not cover (incl. the empty pileup)
+        return std::string();
+    }
+    const uint32_t E = static_cast<uint32_t>(E64);
+    DevicePacked &pk = *out;
+    // worst-case block count (64-cell blocks) for buffers sized before the tile size is chosen
+    const size_t n_off_max = (size_t)((num_cells + 63) / 64) * ((size_t)L + 1);
+    if (n_off_max >= (1ull << 31)) {
+        *need_host = true;
+        return std::string();
+    }
+    enum { KEY_A, KEY_B, VAL_A, VAL_B, ELOC, WORK_A, WORK_B, RUNS, CUB, TMP, MISC, BIN };
+    auto &S = pk.scratch;
+
+    Raw raw{in.chr_locus_off, C, in.locus_pos, in.locus_entry_off, in.read_ids, in.id_base16,
+            in.id_base32, in.group_id_to_pos, in.n_groups, L, E};
+
+    // ---- buffers (sized up front: a re-allocation in mid-pipeline would synchronise) -----------
+    // MISC: Scalars | rbeg[C+1] | flushed[C] | cnt[L]
+    HIP_OK(S[MISC].ensure(sizeof(Scalars) + sizeof(uint32_t) * ((size_t)2 * C + 2 + L) + 64));
+    Scalars *sc = S[MISC].as<Scalars>();
+    uint32_t *rbeg = reinterpret_cast<uint32_t *>(sc + 1);
+    uint32_t *flushed = rbeg + C + 1;
+    uint32_t *cnt = flushed + C;
+    // KEY_A: sort keys in, later mark[E+1] | arank[E+1], later the per-(block, locus) counts
+    HIP_OK(S[KEY_A].ensure(std::max<size_t>({(size_t)E * 8, ((size_t)2 * E + 4) * 4, (n_off_max + 1) * 4})));
+    HIP_OK(S[KEY_B].ensure((size_t)E * 8));
+    HIP_OK(S[VAL_A].ensure((size_t)E * 4));
+    HIP_OK(S[VAL_B].ensure((size_t)E * 4));
+    HIP_OK(S[ELOC].ensure((size_t)E * 4));
+    HIP_OK(S[WORK_A].ensure(((size_t)E + 1) * 4));
+    HIP_OK(S[WORK_B].ensure(((size_t)E + 1) * 4));
+    // RUNS: run_start[R+1] | first_entry[R] | start_pos[R] | run_rank[R] | starts_by_rank[R], R <= E
+    HIP_OK(S[RUNS].ensure(((size_t)5 * E + 8) * 4));
+    // TMP: per kept entry 16 + 4 + 4 + 4 bytes; BIN: key2 x2, val2 x2, per-cell squares
+    HIP_OK(S[TMP].ensure((size_t)E * 28 + 64));
+    HIP_OK(S[BIN].ensure((size_t)E * 24 + ((size_t)num_cells + 130) * 8 + 64));
+    unsigned long long *key_a = S[KEY_A].as<unsigned long long>(), *key_b = S[KEY_B].as<unsigned long long>();
+    uint32_t *val_a = S[VAL_A].as<uint32_t>(), *val_b = S[VAL_B].as<uint32_t>();
+    uint32_t *eloc = S[ELOC].as<uint32_t>();
+    uint32_t *work_a = S[WORK_A].as<uint32_t>(), *work_b = S[WORK_B].as<uint32_t>();
+    {
+        size_t need = 0, most = 0;
+        HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, key_a, key_b, val_a, val_b, (int)E, 0, 64, stream));
+        most = std::max(most, need);
+        HIP_OK(hipcub::DeviceScan::InclusiveSum(nullptr, need, work_a, work_b, (int)E + 1, stream));
+        most = std::max(most, need);
+        HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, work_a, work_b, (int)n_off_max, stream));
+        most = std::max(most, need);
+        HIP_OK(S[CUB].ensure(most + 1024));
+    }
+    void *cub_tmp = S[CUB].p;
+    size_t cub_cap = 0;
+    HIP_OK(hipMemsetAsync(sc, 0, sizeof(Scalars), stream));
+
+    // ---- 1: keys + stable sort by (chromosome, read id) -------------------------------------
+    hipLaunchKernelGGL(k_check_positions, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, sc);
+    hipLaunchKernelGGL(k_entry_keys, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, key_a, val_a);
+    cub_cap = S[CUB].bytes;
+    HIP_OK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_cap, key_a, key_b, val_a, val_b, (int)E, 0,
+                                               32 + bits_for(C), stream));
+    const unsigned long long *skey = key_b;
+    const uint32_t *sval = val_b;
+
+    // ---- 2: reads = runs of equal key ------------------------------------------------------
+    uint32_t *head = work_a, *run_incl = work_b;  // run_incl stays alive until k_records
+    hipLaunchKernelGGL(k_heads, dim3(blocks_for(E)), dim3(TPB), 0, stream, skey, E, head);
+    cub_cap = S[CUB].bytes;
+    HIP_OK(hipcub::DeviceScan::InclusiveSum(cub_tmp, cub_cap, head, run_incl, (int)E, stream));
+    uint32_t R = 0;
+    HIP_OK(hipMemcpyAsync(&R, run_incl + (E - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    uint32_t *run_start = S[RUNS].as<uint32_t>();
+    uint32_t *first_entry = run_start + R + 1, *start_pos = first_entry + R, *run_rank = start_pos + R,
+             *starts_by_rank = run_rank + R;
+    hipLaunchKernelGGL(k_run_starts, dim3(blocks_for(E)), dim3(TPB), 0, stream, head, run_incl, E, run_start);
+    uint32_t *mark = S[KEY_A].as<uint32_t>();  // the unsorted keys are dead
+    uint32_t *arank = mark + (E + 1);
+    HIP_OK(hipMemsetAsync(mark, 0, ((size_t)E + 1) * 4, stream));
+    hipLaunchKernelGGL(k_run_info, dim3(blocks_for(R)), dim3(TPB), 0, stream, raw, run_start, R, sval, eloc, mfl,
+                       first_entry, start_pos, mark, sc);
+    uint32_t *keep = work_a;  // overwrites head (k_run_starts is done with it: same stream)
+    hipLaunchKernelGGL(k_dup_rule, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sval, eloc, E, keep);
+    uint32_t *slot = val_a;  // the unsorted values are dead
+    cub_cap = S[CUB].bytes;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, keep, slot, (int)E, stream));
+    cub_cap = S[CUB].bytes;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, mark, arank, (int)E + 1, stream));
+    uint32_t last_slot = 0, last_keep = 0;
+    Scalars hsc;
+    HIP_OK(hipMemcpyAsync(&last_slot, slot + (E - 1), 4, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(&last_keep, keep + (E - 1), 4, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    if (hsc.error == 3) return "positions must be strictly increasing within a chromosome";
+    if (hsc.need_host) {
+        *need_host = true;
+        return std::string();
+    }
+    const uint32_t n_kept = last_slot + last_keep;
+    const size_t nk = std::max<uint32_t>(n_kept, 1);
+
+    // ---- 3: per-read lists ------------------------------------------------------------------
+    HIP_OK(pk.read_off.ensure(((size_t)R + 1) * 4));
+    HIP_OK(pk.read_locus.ensure(nk * 4));
+    HIP_OK(pk.read_base.ensure(nk));
+    HIP_OK(pk.range_off.ensure(((size_t)L + 2) * 4));
+    HIP_OK(pk.entry.ensure(nk * 16));
+    HIP_OK(pk.entry32.ensure(nk * 4));
+    HIP_OK(pk.mask32.ensure(nk * 4));
+    HIP_OK(pk.entry_read.ensure(nk * 4));
+    HIP_OK(pk.blk_off.ensure((n_off_max + 1) * 4));
+    uint32_t *read_off = pk.read_off.as<uint32_t>(), *read_locus = pk.read_locus.as<uint32_t>();
+    uint8_t *read_base = pk.read_base.as<uint8_t>();
+    hipLaunchKernelGGL(k_csr, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, eloc, keep, slot, E, read_locus, read_base);
+    hipLaunchKernelGGL(k_read_off, dim3(blocks_for(R + 1)), dim3(TPB), 0, stream, run_start, slot, keep, R, E, read_off);
+    hipLaunchKernelGGL(k_multi, dim3(blocks_for(R)), dim3(TPB), 0, stream, read_off, R, sc);
+
+    // ---- 4: appearance ranks, completed counts, flush chain ----------------------------------
+    hipLaunchKernelGGL(k_ranks, dim3(blocks_for(std::max(R, C + 1))), dim3(TPB), 0, stream, raw, first_entry,
+                       start_pos, arank, R, run_rank, starts_by_rank, rbeg);
+    hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, starts_by_rank, rbeg, mfl, cnt);
+    hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, stream, raw, cnt, 4u * num_threads, flushed);
+
+    HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    pk.multi_entries = hsc.multi_entries;
+    if (block_cells == 0) {
+        const StageGeometry g64 = geometry(64);
+        const bool clustered = n_kept && (double)pk.multi_entries > g64.masks_threshold * (double)n_kept;
+        block_cells = (clustered || num_cells <= 64) ? 64 : 128;
+    }
+    const StageGeometry geo = geometry(block_cells);
+    const uint32_t B = block_cells, nb = (num_cells + B - 1) / B;
+    pk.num_cells = num_cells;
+    pk.block_cells = B;
+    pk.num_blocks = nb;
+    pk.num_loci = L;
+    pk.num_entries = n_kept;
+    pk.num_reads = R;
+    pk.stage_masks = n_kept && (double)pk.multi_entries > geo.masks_threshold * (double)n_kept;
+    pk.cap_entries = pk.stage_masks ? geo.cap_entries_masks : geo.cap_entries_plain;
+    pk.cap_loci = pk.stage_masks ? geo.cap_loci_masks : geo.cap_loci_plain;
+
+    // ---- 5: records, binning, offsets, bound, ranges, gather ---------------------------------
+    RecOut tmp;
+    tmp.t_entry = S[TMP].as<uint4>();
+    tmp.t_c32 = reinterpret_cast<uint32_t *>(tmp.t_entry + nk);
+    tmp.t_m32 = tmp.t_c32 + nk;
+    tmp.t_read = tmp.t_m32 + nk;
+    unsigned long long *key2_a = S[BIN].as<unsigned long long>();
+    unsigned long long *key2_b = key2_a + nk;
+    unsigned long long *per_cell_sq = key2_b + nk;  // nb * B entries
+    uint32_t *val2_a = reinterpret_cast<uint32_t *>(per_cell_sq + (size_t)nb * B + 1);
+    uint32_t *val2_b = val2_a + nk;
+    tmp.key2 = key2_a;
+    tmp.val2 = val2_a;
+    const size_t n_off = (size_t)nb * ((size_t)L + 1);
+    uint32_t *blk_off = pk.blk_off.as<uint32_t>();
+    uint32_t *blk_cnt = S[KEY_A].as<uint32_t>();  // mark / arank are dead after k_ranks
+    tmp.blk_cnt = blk_cnt;
+    HIP_OK(hipMemsetAsync(blk_cnt, 0, (n_off + 1) * 4, stream));
+    HIP_OK(hipMemsetAsync(per_cell_sq, 0, ((size_t)nb * B + 1) * 8, stream));
+    hipLaunchKernelGGL(k_records, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sval, keep, slot, run_incl,
+                       read_off, read_locus, read_base, run_rank, rbeg, flushed, num_cells, B, tmp, sc);
+    if (n_kept) {
+        cub_cap = S[CUB].bytes;
+        HIP_OK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_cap, key2_a, key2_b, val2_a, val2_b, (int)n_kept, 0,
+                                                   bits_for(((unsigned long long)nb * L + L) * B + B), stream));
+    }
+    cub_cap = S[CUB].bytes;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
+    if (n_kept) {
+        hipLaunchKernelGGL(k_cell_squares, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, key2_b, n_kept, B, L, per_cell_sq);
+        hipLaunchKernelGGL(k_max_u64, dim3(blocks_for((size_t)nb * B)), dim3(TPB), 0, stream, per_cell_sq, nb * B, sc);
+    }
+    hipLaunchKernelGGL(k_ranges, dim3(1), dim3(TPB), 0, stream, blk_off, nb, L, pk.cap_entries, pk.cap_loci,
+                       pk.range_off.as<uint32_t>(), sc);
+    HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    if (hsc.error == 1) return "group id outside group_id_to_pos";
+    if (hsc.error == 2) return "group_id_to_pos maps outside the matrix";
+    pk.pair_bound = hsc.pair_bound;
+    pk.num_ranges = hsc.num_ranges;
+    if (n_kept) {
+        hipLaunchKernelGGL(k_gather, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, val2_b, n_kept, tmp,
+                           pk.range_off.as<uint32_t>(), pk.num_ranges, pk.entry.as<uint4>(),
+                           pk.entry32.as<uint32_t>(), pk.mask32.as<uint32_t>(), pk.entry_read.as<uint32_t>());
+    }
+    HIP_OK(hipGetLastError());
+    return std::string();
+}
+
+}  // namespace secedo

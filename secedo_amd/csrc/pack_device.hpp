@@ -1,0 +1,61 @@
+// pack_device.hpp -- device-side read assembly, flush schedule and tile packing (gfx950).
+//
+// Same result as pack_host.cpp (see its header for the reference semantics) but computed on the
+// GPU from the raw flat pileup resident in HBM, for the common case in which no read outlives
+// max_fragment_length (no read is split at a flush). When that precondition does not hold, or a
+// size limit of this path is exceeded, `need_host` is set and the caller packs on the host.
+#pragma once
+
+#include "pack_host.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <string>
+
+namespace secedo {
+
+// Raw flat pileup, device pointers (layout of include/secedo_simmat.h)
+struct DeviceFlatPileup {
+    const uint32_t *chr_locus_off = nullptr;
+    uint32_t n_chr = 0;
+    const uint32_t *locus_pos = nullptr;
+    const uint64_t *locus_entry_off = nullptr;
+    const uint32_t *read_ids = nullptr;
+    const uint16_t *id_base16 = nullptr;
+    const uint32_t *id_base32 = nullptr;
+    const uint32_t *group_id_to_pos = nullptr;
+    uint32_t n_groups = 0;
+    uint32_t n_loci = 0;
+    uint64_t n_entries = 0;
+};
+
+// Growable device allocation owned by the caller (simmat_api.cpp's handle)
+struct DeviceArena {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DeviceArena();
+    hipError_t ensure(size_t n);
+    template <class T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
+// The packed pileup in HBM: the arrays of PackedPileup, device resident
+struct DevicePacked {
+    DeviceArena blk_off, entry32, mask32, entry, entry_read, range_off, read_off, read_locus, read_base;
+    DeviceArena scratch[12];  // temporaries, kept between calls to avoid re-allocation
+    uint32_t num_cells = 0, block_cells = 0, num_blocks = 0, num_loci = 0, num_ranges = 0;
+    uint64_t num_entries = 0, num_reads = 0, pair_bound = 0, multi_entries = 0;
+    bool stage_masks = false;
+    uint32_t cap_entries = 0, cap_loci = 0;
+};
+
+// Returns "" on success. On success with *need_host == true nothing usable was produced and the
+// caller must fall back to pack_pileup() on the host (reads longer than max_fragment_length, or
+// more than 2^31 entries). Synchronises `stream` a few times (scalar read-backs).
+std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells,
+                               uint32_t max_fragment_length, uint32_t num_threads,
+                               uint32_t block_cells, StageGeometry (*geometry)(uint32_t),
+                               hipStream_t stream, DevicePacked *out, bool *need_host);
+
+}  // namespace secedo

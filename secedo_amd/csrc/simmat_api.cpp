@@ -6,6 +6,7 @@
 #include "secedo_simmat.h"
 
 #include "llr_table.hpp"
+#include "pack_device.hpp"
 #include "pack_host.hpp"
 #include "simmat_kernels.hpp"
 
@@ -67,18 +68,21 @@ struct DevBuf {
 
 struct secedo_simmat {
     int device = 0;
-    secedo::FlatPileupView view;
-    bool have_pileup = false;
+    // the pileup handed to set_pileup / set_pileup_device (borrowed until prepare returns)
+    secedo::FlatPileupView view;         // host pointers
+    secedo::DeviceFlatPileup dview;      // device pointers
+    bool have_host = false, have_device = false;
     bool prepared = false;
+    int packing_mode = 0;                // 0 auto (device, host when required), 1 host, 2 device only
+    int used_device_packing = 0;
 
-    // geometry
-    uint32_t num_cells = 0, block_cells = 0, num_blocks = 0, num_tiles = 0, num_loci = 0, num_ranges = 0;
-    bool stage_masks = false;
-    uint64_t num_entries = 0, num_reads = 0, pair_bound = 0;
+    // raw pileup uploaded by prepare() when it came as host pointers
+    DevBuf raw_chr, raw_pos, raw_off, raw_rid, raw_idb, raw_g2p;
 
-    // HBM
-    DevBuf blk_off, entry32, mask32, entry, entry_read, range_off, read_off, read_locus, read_base, tile_row, tile_col, lut,
-            counters, max_bits, slow_args;
+    // the packed pileup in HBM + geometry
+    secedo::DevicePacked pk;
+    uint32_t num_tiles = 0;
+    DevBuf tile_row, tile_col, lut, counters, max_bits, slow_args;
     DevBuf own_acc, own_out;  // used by the one-shot entry point only
 
     // LLR table of the last accumulate()
@@ -90,6 +94,24 @@ struct secedo_simmat {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timed = false;
 };
+
+namespace {
+
+template <class T>
+hipError_t arena_upload(secedo::DeviceArena &a, const std::vector<T> &v) {
+    hipError_t e = a.ensure(v.size() * sizeof(T));
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpy(a.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+template <class T>
+hipError_t buf_upload(DevBuf &b, const T *src, size_t n) {
+    hipError_t e = b.ensure(n * sizeof(T));
+    if (e != hipSuccess || n == 0) return e;
+    return hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -164,63 +186,194 @@ int secedo_simmat_set_pileup(secedo_simmat_t *h, const uint32_t *chr_locus_off, 
     h->view.id_base32 = id_base32;
     h->view.group_id_to_pos = group_id_to_pos;
     h->view.n_groups = n_groups;
-    h->have_pileup = true;
+    h->have_host = true;
+    h->have_device = false;
     h->prepared = false;
     return SECEDO_OK;
 }
 
-int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_fragment_length,
-                          uint32_t num_threads, uint32_t block_cells) {
+int secedo_simmat_set_pileup_device(secedo_simmat_t *h, const uint32_t *d_chr_locus_off, uint32_t n_chr,
+                                    const uint32_t *d_locus_pos, const uint64_t *d_locus_entry_off,
+                                    const uint32_t *d_read_ids, const uint16_t *d_id_base16,
+                                    const uint32_t *d_id_base32, const uint32_t *d_group_id_to_pos,
+                                    uint32_t n_groups, uint32_t n_loci, uint64_t n_entries) {
     if (!h) return fail(SECEDO_E_INVALID_ARG, "handle is null");
-    if (!h->have_pileup) return fail(SECEDO_E_STATE, "set_pileup was not called");
+    if (!d_chr_locus_off || !d_locus_entry_off) return fail(SECEDO_E_INVALID_ARG, "null offset arrays");
+    if ((d_id_base16 != nullptr) == (d_id_base32 != nullptr))
+        return fail(SECEDO_E_INVALID_ARG, "exactly one of id_base16 / id_base32 must be given");
+    if (!d_group_id_to_pos && n_groups) return fail(SECEDO_E_INVALID_ARG, "group_id_to_pos is null");
+    h->dview.chr_locus_off = d_chr_locus_off;
+    h->dview.n_chr = n_chr;
+    h->dview.locus_pos = d_locus_pos;
+    h->dview.locus_entry_off = d_locus_entry_off;
+    h->dview.read_ids = d_read_ids;
+    h->dview.id_base16 = d_id_base16;
+    h->dview.id_base32 = d_id_base32;
+    h->dview.group_id_to_pos = d_group_id_to_pos;
+    h->dview.n_groups = n_groups;
+    h->dview.n_loci = n_loci;
+    h->dview.n_entries = n_entries;
+    h->have_device = true;
+    h->have_host = false;
+    h->prepared = false;
+    return SECEDO_OK;
+}
+
+int secedo_simmat_set_packing(secedo_simmat_t *h, int mode) {
+    if (!h) return fail(SECEDO_E_INVALID_ARG, "handle is null");
+    if (mode < 0 || mode > 2) return fail(SECEDO_E_INVALID_ARG, "packing mode must be 0 (auto), 1 (host) or 2 (device)");
+    h->packing_mode = mode;
+    return SECEDO_OK;
+}
+
+int secedo_simmat_used_device_packing(const secedo_simmat_t *h) { return h ? h->used_device_packing : 0; }
+
+int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_fragment_length,
+                          uint32_t num_threads, uint32_t block_cells, void *stream) {
+    if (!h) return fail(SECEDO_E_INVALID_ARG, "handle is null");
+    if (!h->have_host && !h->have_device) return fail(SECEDO_E_STATE, "set_pileup was not called");
     if (block_cells == 0) {
         if (const char *env = std::getenv("SECEDO_BLOCK_CELLS")) {
             const int v = std::atoi(env);
             if (v == 64 || v == 128) block_cells = static_cast<uint32_t>(v);
         }
     }
-    HIP_TRY(hipSetDevice(h->device));
-
-    secedo::PackedPileup pk;
-    const std::string err = secedo::pack_pileup(h->view, num_cells, max_fragment_length, num_threads,
-                                                block_cells, &secedo::stage_geometry, &pk);
-    h->have_pileup = false;  // the borrow ends here
-    if (!err.empty()) return fail(SECEDO_E_INVALID_ARG, err);
-
-    h->num_cells = num_cells;
-    h->block_cells = pk.block_cells;
-    h->num_blocks = pk.num_blocks;
-    h->num_loci = pk.num_loci;
-    h->num_entries = pk.num_entries;
-    h->num_reads = pk.num_reads;
-    h->pair_bound = pk.pair_bound;
-    h->num_tiles = pk.num_blocks * (pk.num_blocks + 1) / 2;
-
-    std::vector<uint16_t> trow, tcol;
-    trow.reserve(h->num_tiles);
-    tcol.reserve(h->num_tiles);
-    for (uint32_t i = 0; i < pk.num_blocks; ++i) {
-        for (uint32_t j = i; j < pk.num_blocks; ++j) {
-            trow.push_back(static_cast<uint16_t>(i));
-            tcol.push_back(static_cast<uint16_t>(j));
-        }
+    int mode = h->packing_mode;
+    if (const char *env = std::getenv("SECEDO_PACKING")) {
+        if (!std::strcmp(env, "host")) mode = 1;
+        if (!std::strcmp(env, "device")) mode = 2;
     }
-    HIP_TRY(h->blk_off.upload(pk.blk_off));
-    HIP_TRY(h->entry32.upload(pk.entry32));
-    HIP_TRY(h->mask32.upload(pk.mask32));
-    HIP_TRY(h->entry.upload(pk.entry));
-    HIP_TRY(h->entry_read.upload(pk.entry_read));
-    HIP_TRY(h->range_off.upload(pk.range_off));
-    h->num_ranges = static_cast<uint32_t>(pk.range_off.size()) - 1;
-    h->stage_masks = pk.stage_masks;
-    HIP_TRY(h->read_off.upload(pk.read_off));
-    HIP_TRY(h->read_locus.upload(pk.read_locus));
-    HIP_TRY(h->read_base.upload(pk.read_base));
-    HIP_TRY(h->tile_row.upload(trow));
-    HIP_TRY(h->tile_col.upload(tcol));
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    h->prepared = false;
+    h->used_device_packing = 0;
+    secedo::DevicePacked &pk = h->pk;
+
+    bool need_host = (mode == 1);
+    if (!need_host) {
+        if (h->have_host) {  // raw pileup to HBM
+            const secedo::FlatPileupView &v = h->view;
+            const uint32_t L = v.n_loci();
+            const uint64_t E = v.n_entries();
+            HIP_TRY(buf_upload(h->raw_chr, v.chr_locus_off, (size_t)v.n_chr + 1));
+            HIP_TRY(buf_upload(h->raw_pos, v.locus_pos, L));
+            HIP_TRY(buf_upload(h->raw_off, v.locus_entry_off, (size_t)L + 1));
+            HIP_TRY(buf_upload(h->raw_rid, v.read_ids, E));
+            if (v.id_base16) HIP_TRY(buf_upload(h->raw_idb, v.id_base16, E));
+            else HIP_TRY(buf_upload(h->raw_idb, v.id_base32, E));
+            HIP_TRY(buf_upload(h->raw_g2p, v.group_id_to_pos, v.n_groups));
+            h->dview.chr_locus_off = h->raw_chr.as<uint32_t>();
+            h->dview.n_chr = v.n_chr;
+            h->dview.locus_pos = h->raw_pos.as<uint32_t>();
+            h->dview.locus_entry_off = h->raw_off.as<uint64_t>();
+            h->dview.read_ids = h->raw_rid.as<uint32_t>();
+            h->dview.id_base16 = v.id_base16 ? h->raw_idb.as<uint16_t>() : nullptr;
+            h->dview.id_base32 = v.id_base16 ? nullptr : h->raw_idb.as<uint32_t>();
+            h->dview.group_id_to_pos = h->raw_g2p.as<uint32_t>();
+            h->dview.n_groups = v.n_groups;
+            h->dview.n_loci = L;
+            h->dview.n_entries = E;
+        }
+        const std::string err = secedo::pack_pileup_device(h->dview, num_cells, max_fragment_length,
+                                                           num_threads, block_cells, &secedo::stage_geometry,
+                                                           s, &pk, &need_host);
+        if (!err.empty()) {
+            h->have_host = h->have_device = false;
+            return fail(err.find("hip") == 0 ? SECEDO_E_HIP : SECEDO_E_INVALID_ARG, err);
+        }
+        if (need_host && mode == 2) {
+            h->have_host = h->have_device = false;
+            return fail(SECEDO_E_LIMIT, "this pileup needs the host packing path (a read is longer than "
+                                        "max_fragment_length, or a size limit of the device path)");
+        }
+        if (!need_host) h->used_device_packing = 1;
+    }
+
+    if (need_host) {
+        // the exact sequential emulation on the host (reads split at flushes, any size)
+        std::vector<uint32_t> hc, hp, hr, hg, hi32;
+        std::vector<uint64_t> ho;
+        std::vector<uint16_t> hi16;
+        secedo::FlatPileupView v = h->view;
+        if (!h->have_host) {  // the pileup lives in HBM only: bring it back
+            const secedo::DeviceFlatPileup &d = h->dview;
+            HIP_TRY(hipStreamSynchronize(s));
+            hc.resize((size_t)d.n_chr + 1);
+            hp.resize(d.n_loci);
+            ho.resize((size_t)d.n_loci + 1);
+            hr.resize(d.n_entries);
+            hg.resize(d.n_groups);
+            HIP_TRY(hipMemcpy(hc.data(), d.chr_locus_off, hc.size() * 4, hipMemcpyDeviceToHost));
+            if (d.n_loci) HIP_TRY(hipMemcpy(hp.data(), d.locus_pos, hp.size() * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(ho.data(), d.locus_entry_off, ho.size() * 8, hipMemcpyDeviceToHost));
+            if (d.n_entries) HIP_TRY(hipMemcpy(hr.data(), d.read_ids, hr.size() * 4, hipMemcpyDeviceToHost));
+            if (d.n_groups) HIP_TRY(hipMemcpy(hg.data(), d.group_id_to_pos, hg.size() * 4, hipMemcpyDeviceToHost));
+            if (d.id_base16) {
+                hi16.resize(d.n_entries);
+                if (d.n_entries) HIP_TRY(hipMemcpy(hi16.data(), d.id_base16, hi16.size() * 2, hipMemcpyDeviceToHost));
+            } else {
+                hi32.resize(d.n_entries);
+                if (d.n_entries) HIP_TRY(hipMemcpy(hi32.data(), d.id_base32, hi32.size() * 4, hipMemcpyDeviceToHost));
+            }
+            v.chr_locus_off = hc.data();
+            v.n_chr = d.n_chr;
+            v.locus_pos = hp.data();
+            v.locus_entry_off = ho.data();
+            v.read_ids = hr.data();
+            v.id_base16 = d.id_base16 ? hi16.data() : nullptr;
+            v.id_base32 = d.id_base16 ? nullptr : hi32.data();
+            v.group_id_to_pos = hg.data();
+            v.n_groups = d.n_groups;
+        }
+        secedo::PackedPileup hp_pk;
+        const std::string err = secedo::pack_pileup(v, num_cells, max_fragment_length, num_threads,
+                                                    block_cells, &secedo::stage_geometry, &hp_pk);
+        if (!err.empty()) {
+            h->have_host = h->have_device = false;
+            return fail(SECEDO_E_INVALID_ARG, err);
+        }
+        HIP_TRY(arena_upload(pk.blk_off, hp_pk.blk_off));
+        HIP_TRY(arena_upload(pk.entry32, hp_pk.entry32));
+        HIP_TRY(arena_upload(pk.mask32, hp_pk.mask32));
+        HIP_TRY(arena_upload(pk.entry, hp_pk.entry));
+        HIP_TRY(arena_upload(pk.entry_read, hp_pk.entry_read));
+        HIP_TRY(arena_upload(pk.range_off, hp_pk.range_off));
+        HIP_TRY(arena_upload(pk.read_off, hp_pk.read_off));
+        HIP_TRY(arena_upload(pk.read_locus, hp_pk.read_locus));
+        HIP_TRY(arena_upload(pk.read_base, hp_pk.read_base));
+        pk.num_cells = hp_pk.num_cells;
+        pk.block_cells = hp_pk.block_cells;
+        pk.num_blocks = hp_pk.num_blocks;
+        pk.num_loci = hp_pk.num_loci;
+        pk.num_entries = hp_pk.num_entries;
+        pk.num_reads = hp_pk.num_reads;
+        pk.pair_bound = hp_pk.pair_bound;
+        pk.multi_entries = hp_pk.multi_entries;
+        pk.stage_masks = hp_pk.stage_masks;
+        pk.cap_entries = hp_pk.cap_entries;
+        pk.cap_loci = hp_pk.cap_loci;
+        pk.num_ranges = static_cast<uint32_t>(hp_pk.range_off.size()) - 1;
+    }
+    h->have_host = h->have_device = false;  // the borrow ends here
+
+    const uint32_t nb = pk.num_blocks;
+    if (h->num_tiles != nb * (nb + 1) / 2 || !h->tile_row.p) {
+        h->num_tiles = nb * (nb + 1) / 2;
+        std::vector<uint16_t> trow, tcol;
+        trow.reserve(h->num_tiles);
+        tcol.reserve(h->num_tiles);
+        for (uint32_t i = 0; i < nb; ++i) {
+            for (uint32_t j = i; j < nb; ++j) {
+                trow.push_back(static_cast<uint16_t>(i));
+                tcol.push_back(static_cast<uint16_t>(j));
+            }
+        }
+        HIP_TRY(h->tile_row.upload(trow));
+        HIP_TRY(h->tile_col.upload(tcol));
+    }
     HIP_TRY(h->counters.ensure(2 * sizeof(unsigned long long)));
     HIP_TRY(h->max_bits.ensure(sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(h->counters.p, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(unsigned long long), s));
     h->have_lut = false;
     h->prepared = true;
     h->timed = false;
@@ -228,13 +381,13 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
 }
 
 uint32_t secedo_simmat_num_tiles(const secedo_simmat_t *h) { return h ? h->num_tiles : 0; }
-uint32_t secedo_simmat_block_cells(const secedo_simmat_t *h) { return h ? h->block_cells : 0; }
+uint32_t secedo_simmat_block_cells(const secedo_simmat_t *h) { return h ? h->pk.block_cells : 0; }
 uint64_t secedo_simmat_acc_elems(const secedo_simmat_t *h) {
-    return h ? static_cast<uint64_t>(h->num_tiles) * h->block_cells * h->block_cells : 0;
+    return h ? static_cast<uint64_t>(h->num_tiles) * h->pk.block_cells * h->pk.block_cells : 0;
 }
-uint64_t secedo_simmat_num_entries(const secedo_simmat_t *h) { return h ? h->num_entries : 0; }
-uint64_t secedo_simmat_num_reads(const secedo_simmat_t *h) { return h ? h->num_reads : 0; }
-uint64_t secedo_simmat_num_loci(const secedo_simmat_t *h) { return h ? h->num_loci : 0; }
+uint64_t secedo_simmat_num_entries(const secedo_simmat_t *h) { return h ? h->pk.num_entries : 0; }
+uint64_t secedo_simmat_num_reads(const secedo_simmat_t *h) { return h ? h->pk.num_reads : 0; }
+uint64_t secedo_simmat_num_loci(const secedo_simmat_t *h) { return h ? h->pk.num_loci : 0; }
 
 int secedo_simmat_zero_acc(secedo_simmat_t *h, int64_t *d_acc, void *stream) {
     if (!h || !d_acc) return fail(SECEDO_E_INVALID_ARG, "null argument");
@@ -255,7 +408,7 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     if (!h->have_lut || h->lut_eps != eps || h->lut_h != hr || h->lut_theta != theta) {
-        const secedo::LlrTable t = secedo::make_llr_table(eps, hr, theta, h->pair_bound);
+        const secedo::LlrTable t = secedo::make_llr_table(eps, hr, theta, h->pk.pair_bound);
         HIP_TRY(h->lut.ensure(t.fixed.size() * sizeof(int64_t)));
         // pageable-memory copy on the same stream: complete before it returns
         HIP_TRY(hipMemcpyAsync(h->lut.p, t.fixed.data(), t.fixed.size() * sizeof(int64_t),
@@ -264,11 +417,11 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
         h->model = t.model;
         h->scale_log2 = t.scale_log2;
         secedo::SlowPathArgs sp;
-        sp.entry = h->entry.as<uint4>();
-        sp.entry_read = h->entry_read.as<uint32_t>();
-        sp.read_off = h->read_off.as<uint32_t>();
-        sp.read_locus = h->read_locus.as<uint32_t>();
-        sp.read_base = h->read_base.as<uint8_t>();
+        sp.entry = h->pk.entry.as<uint4>();
+        sp.entry_read = h->pk.entry_read.as<uint32_t>();
+        sp.read_off = h->pk.read_off.as<uint32_t>();
+        sp.read_locus = h->pk.read_locus.as<uint32_t>();
+        sp.read_base = h->pk.read_base.as<uint8_t>();
         sp.lut = h->lut.as<long long>();
         sp.model = secedo::LlrModelDev{t.model.ln_u1, t.model.ln_v1, t.model.ln_u2, t.model.ln_v2,
                                        t.model.ln_w1, t.model.ln_z1, t.model.ln_w2, t.model.ln_z2};
@@ -284,25 +437,25 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
 
     const uint32_t n_tiles = tile_end - tile_begin;
     secedo::AccumulateArgs a;
-    a.blk_off = h->blk_off.as<uint32_t>();
-    a.stride = h->num_loci + 1;
-    a.entry32 = h->entry32.as<uint32_t>();
-    a.mask32 = h->mask32.as<uint32_t>();
-    a.entry = h->entry.as<uint4>();
-    a.range_off = h->range_off.as<uint32_t>();
-    a.num_ranges = h->num_ranges;
+    a.blk_off = h->pk.blk_off.as<uint32_t>();
+    a.stride = h->pk.num_loci + 1;
+    a.entry32 = h->pk.entry32.as<uint32_t>();
+    a.mask32 = h->pk.mask32.as<uint32_t>();
+    a.entry = h->pk.entry.as<uint4>();
+    a.range_off = h->pk.range_off.as<uint32_t>();
+    a.num_ranges = h->pk.num_ranges;
     a.tile_row = h->tile_row.as<uint16_t>();
     a.tile_col = h->tile_col.as<uint16_t>();
     a.tile_begin = tile_begin;
     // enough workgroups to fill 256 CUs several times over; a workgroup walks whole locus ranges
-    uint32_t target_wgs = h->block_cells == 128 ? 576 : 2048;  // 1024- vs 256-thread workgroups
+    uint32_t target_wgs = h->pk.block_cells == 128 ? 576 : 2048;  // 1024- vs 256-thread workgroups
     if (const char *env = std::getenv("SECEDO_TARGET_WGS")) target_wgs = std::max(1, std::atoi(env));
     uint32_t chunks = 1;
     if (n_tiles && n_tiles < target_wgs) chunks = (target_wgs + n_tiles - 1) / n_tiles;
-    if (chunks > h->num_ranges) chunks = h->num_ranges ? h->num_ranges : 1;
-    a.chunk_ranges = (h->num_ranges + chunks - 1) / chunks;
+    if (chunks > h->pk.num_ranges) chunks = h->pk.num_ranges ? h->pk.num_ranges : 1;
+    a.chunk_ranges = (h->pk.num_ranges + chunks - 1) / chunks;
     if (a.chunk_ranges == 0) a.chunk_ranges = 1;
-    a.n_chunks = (h->num_ranges + a.chunk_ranges - 1) / a.chunk_ranges;
+    a.n_chunks = (h->pk.num_ranges + a.chunk_ranges - 1) / a.chunk_ranges;
     if (a.n_chunks == 0) a.n_chunks = 1;
     a.debug = 0;
     if (const char *env = std::getenv("SECEDO_DEBUG_ABLATE")) a.debug = static_cast<uint32_t>(std::atoi(env));
@@ -314,9 +467,9 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(unsigned long long), s));
     HIP_TRY(hipEventRecord(h->ev_begin, s));
     // 16-bit pair counters per cell pair are safe when no cell pair can collect 65536 pairs
-    bool count_tile = !h->stage_masks && h->pair_bound < 65536;
+    bool count_tile = !h->pk.stage_masks && h->pk.pair_bound < 65536;
     if (const char *env = std::getenv("SECEDO_COUNT_TILE")) count_tile = count_tile && std::atoi(env) != 0;
-    HIP_TRY(secedo::launch_accumulate(a, h->block_cells, h->stage_masks, count_tile, n_tiles, s));
+    HIP_TRY(secedo::launch_accumulate(a, h->pk.block_cells, h->pk.stage_masks, count_tile, n_tiles, s));
     HIP_TRY(hipEventRecord(h->ev_end, s));
     h->timed = true;
     return SECEDO_OK;
@@ -327,7 +480,7 @@ static int finalize_mode(secedo_simmat_t *h, int mode, const int64_t *d_acc, dou
     if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
     if (!h->have_lut) return fail(SECEDO_E_STATE, "accumulate was not called");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(secedo::launch_finalize(d_acc, h->num_cells, h->num_blocks, h->block_cells, h->scale_log2,
+    HIP_TRY(secedo::launch_finalize(d_acc, h->pk.num_cells, h->pk.num_blocks, h->pk.block_cells, h->scale_log2,
                                     mode, h->max_bits.as<unsigned long long>(), d_out,
                                     static_cast<hipStream_t>(stream)));
     return SECEDO_OK;
@@ -386,7 +539,7 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
     rc = secedo_simmat_set_pileup(h, chr_locus_off, n_chr, locus_pos, locus_entry_off, read_ids,
                                   id_base16, id_base32, group_id_to_pos, n_groups);
     if (rc != SECEDO_OK) return rc;
-    rc = secedo_simmat_prepare(h, num_cells, max_fragment_length, num_threads, 0);
+    rc = secedo_simmat_prepare(h, num_cells, max_fragment_length, num_threads, 0, nullptr);
     if (rc != SECEDO_OK) return rc;
     HIP_TRY(h->own_acc.ensure(secedo_simmat_acc_elems(h) * sizeof(int64_t)));
     const size_t out_bytes = static_cast<size_t>(num_cells) * num_cells * sizeof(double);

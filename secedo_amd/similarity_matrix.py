@@ -116,6 +116,52 @@ class SimilarityMatrixPlan:
         self.close()
 
     # -- prepare ---------------------------------------------------------------------------
+    def set_packing(self, mode: str = "auto"):
+        """Where prepare packs: "auto" (GPU, host when the pileup requires it), "host", "device"."""
+        _lib.check(_lib.lib().secedo_simmat_set_packing(self._h, {"auto": 0, "host": 1, "device": 2}[mode]))
+        return self
+
+    @property
+    def used_device_packing(self) -> bool:
+        return bool(_lib.lib().secedo_simmat_used_device_packing(self._h))
+
+    def upload(self, pos_data, group_id_to_pos=None, num_cells=None):
+        """Raw flat pileup -> HBM (torch tensors); returns the resident pileup for prepare_resident."""
+        p = _as_flat(pos_data)
+        t = self._torch
+        dev = "cuda:%d" % self.device
+        if group_id_to_pos is None:
+            n = num_cells if num_cells is not None else (int(p.id_base.max() >> 2) + 1 if p.n_entries else 1)
+            group_id_to_pos = np.arange(n, dtype=np.uint32)
+        g2p = np.ascontiguousarray(group_id_to_pos, dtype=np.uint32)
+        id16, id32 = _id_arrays(p)
+
+        def dev_tensor(a, view):
+            return t.from_numpy(np.ascontiguousarray(a).view(view)).to(dev)
+
+        res = dict(
+            chr=dev_tensor(p.chr_locus_off, np.int32), pos=dev_tensor(p.locus_pos, np.int32),
+            off=dev_tensor(p.locus_entry_off, np.int64), rid=dev_tensor(p.read_ids, np.int32),
+            idb=dev_tensor(id16, np.int16) if id16 is not None else dev_tensor(id32, np.int32),
+            idb_is16=id16 is not None, g2p=dev_tensor(g2p, np.int32), n_chr=p.n_chr, n_loci=p.n_loci,
+            n_entries=p.n_entries, n_groups=len(g2p))
+        return res
+
+    def prepare_resident(self, res, num_cells, max_fragment_length, num_threads=8, block_cells=0):
+        """prepare() from a pileup already resident in HBM (see upload): no host data touched unless
+        the pileup needs the host packing path."""
+        L = _lib.lib()
+        idb = C.c_void_p(res["idb"].data_ptr())
+        _lib.check(L.secedo_simmat_set_pileup_device(
+            self._h, C.c_void_p(res["chr"].data_ptr()), res["n_chr"], C.c_void_p(res["pos"].data_ptr()),
+            C.c_void_p(res["off"].data_ptr()), C.c_void_p(res["rid"].data_ptr()),
+            idb if res["idb_is16"] else None, None if res["idb_is16"] else idb,
+            C.c_void_p(res["g2p"].data_ptr()), res["n_groups"], res["n_loci"], res["n_entries"]))
+        _lib.check(L.secedo_simmat_prepare(self._h, num_cells, max_fragment_length, num_threads, block_cells,
+                                           self._stream()))
+        self.num_cells = num_cells
+        return self
+
     def prepare(self, pos_data, num_cells, max_fragment_length, group_id_to_pos=None,
                 num_threads=8, block_cells=0):
         p = _as_flat(pos_data)
@@ -128,7 +174,7 @@ class SimilarityMatrixPlan:
             _lib.ptr(p.locus_entry_off), _lib.ptr(p.read_ids), _lib.ptr(id16), _lib.ptr(id32),
             _lib.ptr(g2p), len(g2p)))
         _lib.check(L.secedo_simmat_prepare(self._h, num_cells, max_fragment_length, num_threads,
-                                           block_cells))
+                                           block_cells, self._stream()))
         self.num_cells = num_cells
         return self
 

@@ -150,3 +150,63 @@ def test_cpp_host_without_torch(tmp_path):
         ref = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 4, norm)
         assert gu.normwise_err(got, ref) <= TOL
         assert np.array_equal(got, secedo_amd.compute_similarity_matrix(p, n, 1000, None, 0.01, 0.5, 0.01, 4, "", norm))
+
+
+PACK_CASES = [
+    # seed, cells, chr, loci, cov, gap_max, mfl, T, block_cells
+    (51, 90, 3, 500, 15, 300, 1000, 4, 0),
+    (52, 200, 2, 400, 30, 120, 1000, 1, 64),
+    (53, 150, 1, 1500, 25, 2500, 1000, 8, 128),
+    (54, 16, 1, 300, 6, 9, 1000, 2, 0),       # long reads: window overflow, > 16 loci per read
+    (55, 300, 24, 60, 40, 1500, 1000, 3, 0),  # many short chromosomes: tails dominate
+]
+
+
+@pytest.mark.parametrize("seed,n,nchr,L,cov,gap,mfl,T,block", PACK_CASES)
+def test_device_packing_equals_host_packing(seed, n, nchr, L, cov, gap, mfl, T, block):
+    """The GPU packing pipeline (sort by read, duplicate rule, flush chain, masks, binning) must give
+    the same work counters and a bit-identical matrix as the sequential host emulation. (The raw
+    accumulators may differ inside diagonal tiles, where a pair lands at [r][c] or [c][r] depending on
+    the entry order inside a locus; finalize adds the two.)"""
+    import torch
+    fmax = 500 if gap < 20 else 600
+    p = random_pileup(seed, n, nchr, L, cov, gap, frag_max=fmax, dup_frac=0.06, triple_frac=0.4,
+                      skip_frac=0.1, n_groups=n + 3)
+    g2p = np.random.default_rng(seed).integers(0, n, size=n + 3).astype(np.uint32)
+    accs, counts = [], []
+    for mode in ("host", "device"):
+        with secedo_amd.SimilarityMatrixPlan(0) as plan:
+            plan.set_packing(mode)
+            plan.prepare(p, n, mfl, g2p, T, block_cells=block)
+            assert plan.used_device_packing == (mode == "device")
+            acc = plan.new_acc()
+            plan.accumulate(acc, 0.01, 0.5, 0.02)
+            torch.cuda.synchronize()
+            accs.append((plan.block_cells, plan.finalize_raw(acc).clone()))
+            counts.append(plan.last_counts() + (plan.num_entries, plan.num_reads))
+    assert counts[0] == counts[1]
+    assert accs[0][0] == accs[1][0] and torch.equal(accs[0][1], accs[1][1])
+
+
+def test_resident_pileup_and_fallback_to_host():
+    """prepare_resident: raw pileup in HBM -> matrix without touching host data; a read longer than
+    max_fragment_length makes the automatic mode fall back to the exact host emulation."""
+    n = 120
+    p = random_pileup(61, n, 2, 600, 20, 300)
+    ref = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 4, "ADD_MIN")
+    ref_split = ob.oracle_compute(p, n, 150, None, 0.01, 0.5, 0.01, 4, "ADD_MIN")
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        res = plan.upload(p, None, n)
+        plan.prepare_resident(res, n, 1000, 4)
+        assert plan.used_device_packing
+        acc = plan.new_acc()
+        plan.accumulate(acc, 0.01, 0.5, 0.01)
+        assert gu.normwise_err(plan.finalize(acc, "ADD_MIN").cpu().numpy(), ref) <= TOL
+        plan.prepare_resident(res, n, 150, 4)  # fragments are up to 600 long: reads get split
+        assert not plan.used_device_packing
+        acc = plan.new_acc()
+        plan.accumulate(acc, 0.01, 0.5, 0.01)
+        assert gu.normwise_err(plan.finalize(acc, "ADD_MIN").cpu().numpy(), ref_split) <= TOL
+        plan.set_packing("device")
+        with pytest.raises(secedo_amd.SecedoError):
+            plan.prepare_resident(res, n, 150, 4)
