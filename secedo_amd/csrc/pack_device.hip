@@ -240,30 +240,16 @@ __global__ __launch_bounds__(TPB) void k_flush_chain(Raw in, const uint32_t *cnt
     if (threadIdx.x == 0) flushed_out[c] = s_flushed;
 }
 
-struct RecOut {
-    uint4 *t_entry;
-    uint32_t *t_c32, *t_m32, *t_read;
-    unsigned long long *key2;
-    uint32_t *val2;
-    uint32_t *blk_cnt;
-};
-
-// entry records in per-read (CSR) order + the binning key (cell block, locus, cell)
-__global__ void k_records(Raw in, const unsigned long long *skey, const uint32_t *sval,
-                          const uint32_t *keep, const uint32_t *slot, const uint32_t *run_incl,
-                          const uint32_t *read_off, const uint32_t *read_locus, const uint8_t *read_base,
-                          const uint32_t *run_rank, const uint32_t *rbeg, const uint32_t *flushed,
-                          uint32_t num_cells, uint32_t B, RecOut out, Scalars *sc) {
+// binning key (cell block, locus, cell) of every kept entry, in per-read (CSR) order; validates the
+// group -> row mapping
+__global__ void k_keys2(Raw in, const uint32_t *sval, const uint32_t *keep, const uint32_t *slot,
+                        const uint32_t *run_incl, const uint32_t *read_locus, uint32_t num_cells, uint32_t B,
+                        unsigned long long *key2, uint32_t *val2, uint32_t *t_read, Scalars *sc) {
     const uint32_t n = in.n_entries, L = in.n_loci;
     for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
         if (!keep[s]) continue;
-        const uint32_t r = run_incl[s] - 1;
         const uint32_t k = slot[s];
-        const uint32_t lo = read_off[r], hi = read_off[r + 1];
-        const uint32_t l = read_locus[k];
-        const uint32_t base = read_base[k];
-        const uint32_t e = sval[s];
-        const uint32_t group = in.id_base(e) >> 2;
+        const uint32_t group = in.id_base(sval[s]) >> 2;
         uint32_t cell = 0;
         if (group >= in.n_groups) {
             sc->error = 1;
@@ -274,7 +260,139 @@ __global__ void k_records(Raw in, const unsigned long long *skey, const uint32_t
                 cell = 0;
             }
         }
-        const uint32_t chr = (uint32_t)(skey[s] >> 32);
+        const uint32_t blk = cell / B, cib = cell - blk * B;
+        key2[k] = ((unsigned long long)blk * L + read_locus[k]) * B + cib;
+        val2[k] = k;
+        t_read[k] = run_incl[s] - 1;
+    }
+}
+
+// After the binning sort: entries per (block, locus) group -> blk_cnt (no atomics: the head of a
+// group counts its run), and sum over loci of (entries of one cell at the locus)^2 per cell (the
+// Cauchy-Schwarz pair bound), accumulated in LDS per workgroup: a workgroup's slice of the sorted
+// order spans only a few cell blocks.
+__global__ __launch_bounds__(TPB) void k_group_counts(const unsigned long long *skey2, uint32_t n, uint32_t B,
+                                                     uint32_t L, uint32_t *blk_cnt,
+                                                     unsigned long long *per_cell_sq) {
+    constexpr uint32_t SLOTS = 512;
+    __shared__ unsigned long long sq[SLOTS];
+    __shared__ uint32_t first_cell;
+    const uint32_t per_block = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t d0 = blockIdx.x * per_block, d1 = min(n, d0 + per_block);
+    for (uint32_t i = threadIdx.x; i < SLOTS; i += TPB) sq[i] = 0;
+    if (threadIdx.x == 0 && d0 < n) {
+        const unsigned long long key = skey2[d0];
+        first_cell = (uint32_t)((key / B) / L) * B;  // first cell of the slice's first block
+    }
+    __syncthreads();
+    for (uint32_t d = d0 + threadIdx.x; d < d1; d += TPB) {
+        const unsigned long long key = skey2[d];
+        const unsigned long long grp = key / B;  // (block, locus)
+        if (d == 0 || skey2[d - 1] / B != grp) {
+            uint32_t len = 1;
+            for (uint32_t t = d + 1; t < n && skey2[t] / B == grp; ++t) ++len;
+            const uint32_t blk = (uint32_t)(grp / L), l = (uint32_t)(grp % L);
+            blk_cnt[(size_t)blk * (L + 1) + l] = len;
+        }
+        if (d == 0 || skey2[d - 1] != key) {
+            unsigned long long cnt = 1;
+            for (uint32_t t = d + 1; t < n && skey2[t] == key; ++t) ++cnt;
+            const uint32_t cell = (uint32_t)(grp / L) * B + (uint32_t)(key % B);
+            const uint32_t rel = cell - first_cell;
+            if (rel < SLOTS) atomicAdd(&sq[rel], cnt * cnt);
+            else atomicAdd(&per_cell_sq[cell], cnt * cnt);
+        }
+    }
+    __syncthreads();
+    if (d0 < n) {
+        for (uint32_t i = threadIdx.x; i < SLOTS; i += TPB) {
+            if (sq[i]) atomicAdd(&per_cell_sq[first_cell + i], sq[i]);
+        }
+    }
+}
+
+__global__ void k_max_u64(const unsigned long long *a, uint32_t n, Scalars *sc) {
+    unsigned long long best = 0;
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) best = max(best, a[i]);
+    for (int off = 32; off > 0; off >>= 1) best = max(best, (unsigned long long)__shfl_down(best, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(&sc->pair_bound, best);
+}
+
+// greedy locus ranges (one partition for all cell blocks): the longest range from `s` in which no
+// block has more than cap_entries entries and that has at most cap_loci loci; a locus that exceeds
+// the cap alone becomes a single-locus range. One workgroup; feasibility is monotone in the end,
+// and the search starts from the previous range's length (ranges of a pileup are of similar size).
+__global__ __launch_bounds__(TPB) void k_ranges(const uint32_t *blk_off, uint32_t nb, uint32_t L,
+                                               uint32_t cap_entries, uint32_t cap_loci,
+                                               uint32_t *range_off, Scalars *sc) {
+    const size_t stride = (size_t)L + 1;
+    uint32_t s = 0, nr = 0, guess = 0;
+    if (threadIdx.x == 0) range_off[0] = 0;
+    auto feasible = [&](uint32_t e) {
+        int ok = 1;
+        for (uint32_t b = threadIdx.x; b < nb; b += TPB)
+            if (blk_off[b * stride + e] - blk_off[b * stride + s] > cap_entries) ok = 0;
+        return __syncthreads_and(ok) != 0;
+    };
+    while (s < L) {
+        uint32_t e = s + 1;
+        if (feasible(e)) {
+            const uint32_t top = min(L, s + cap_loci);
+            uint32_t lo = e, hi = top;  // lo feasible, answer in [lo, hi]
+            if (guess > 1 && s + guess <= top) {  // bracket around the previous length
+                const uint32_t g = s + guess;
+                if (feasible(g)) {
+                    lo = g;
+                    uint32_t step = max(guess / 8, 1u);
+                    while (lo < top) {  // gallop up
+                        const uint32_t nx = min(top, lo + step);
+                        if (feasible(nx)) lo = nx; else { hi = nx - 1; break; }
+                        step *= 2;
+                    }
+                    if (lo == top) hi = top;
+                } else {
+                    hi = g - 1;
+                    uint32_t step = max(guess / 8, 1u);
+                    while (hi > lo) {  // gallop down
+                        const uint32_t nx = (hi - lo > step) ? hi - step : lo;
+                        if (feasible(nx)) { lo = nx; break; }
+                        hi = nx - 1;
+                        step *= 2;
+                    }
+                }
+            }
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo + 1) / 2;
+                if (feasible(mid)) lo = mid; else hi = mid - 1;
+            }
+            e = lo;
+        }
+        guess = e - s;
+        ++nr;
+        if (threadIdx.x == 0) range_off[nr] = e;
+        s = e;
+    }
+    if (threadIdx.x == 0) sc->num_ranges = nr;
+}
+
+// entry records at their final (binned) position d: window masks from the per-read lists
+__global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_t *sval2, uint32_t n,
+                          const uint32_t *t_read, const uint32_t *read_off, const uint32_t *read_locus,
+                          const uint8_t *read_base, const uint32_t *run_rank, const uint32_t *rbeg,
+                          const uint32_t *flushed, const uint32_t *range_off, uint32_t n_ranges, uint32_t B,
+                          uint4 *entry, uint32_t *entry32, uint32_t *mask32, uint32_t *entry_read) {
+    const uint32_t L = in.n_loci;
+    for (uint32_t d = blockIdx.x * TPB + threadIdx.x; d < n; d += gridDim.x * TPB) {
+        const unsigned long long key = skey2[d];
+        const uint32_t k = sval2[d];
+        const uint32_t cib = (uint32_t)(key % B);
+        const unsigned long long grp = key / B;
+        const uint32_t blk = (uint32_t)(grp / L), l = (uint32_t)(grp % L);
+        const uint32_t cell = blk * B + cib;
+        const uint32_t r = t_read[k];
+        const uint32_t lo = read_off[r], hi = read_off[r + 1];
+        const uint32_t base = read_base[k];
+        const uint32_t chr = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
         const bool tail = run_rank[r] - rbeg[chr] >= flushed[chr];
         uint32_t meta = cell | (base << kMetaBaseShift) | (tail ? kMetaTail : 0u);
         uint32_t masks = 0, bases = 0;
@@ -299,83 +417,13 @@ __global__ void k_records(Raw in, const unsigned long long *skey, const uint32_t
             bases |= (uint32_t)(read_base[j] & 1u) << (dist - 1);
             bases |= (uint32_t)((read_base[j] >> 1) & 1u) << (16 + dist - 1);
         }
-        const uint32_t blk = cell / B, cib = cell - blk * B;
-        out.t_entry[k] = make_uint4(meta, masks, bases, l);
-        out.t_c32[k] = cib | (base << kC_BaseShift) | (tail ? kC_Tail : 0u) | (hi - lo > 1 ? kC_Multi : 0u)
-                | (wide ? kC_Wide : 0u);
-        out.t_m32[k] = (masks & 0xFFu) | (((masks >> 16) & 0xFFu) << 8) | ((bases & 0xFFu) << 16)
+        const uint32_t rg = last_le<uint32_t>(range_off, n_ranges + 1, l);
+        entry[d] = make_uint4(meta, masks, bases, l);
+        entry32[d] = cib | (base << kC_BaseShift) | (tail ? kC_Tail : 0u) | (hi - lo > 1 ? kC_Multi : 0u)
+                | (wide ? kC_Wide : 0u) | ((l - range_off[rg]) << 16);
+        mask32[d] = (masks & 0xFFu) | (((masks >> 16) & 0xFFu) << 8) | ((bases & 0xFFu) << 16)
                 | (((bases >> 16) & 0xFFu) << 24);
-        out.t_read[k] = r;
-        out.key2[k] = ((unsigned long long)blk * L + l) * B + cib;
-        out.val2[k] = k;
-        atomicAdd(&out.blk_cnt[(size_t)blk * (L + 1) + l], 1u);
-    }
-}
-
-// sum over loci of (entries of one cell at the locus)^2, per cell: the Cauchy-Schwarz pair bound
-__global__ void k_cell_squares(const unsigned long long *skey2, uint32_t n, uint32_t B, uint32_t L,
-                               unsigned long long *per_cell_sq) {
-    for (uint32_t d = blockIdx.x * TPB + threadIdx.x; d < n; d += gridDim.x * TPB) {
-        if (d > 0 && skey2[d] == skey2[d - 1]) continue;
-        unsigned long long cnt = 1;
-        for (uint32_t t = d + 1; t < n && skey2[t] == skey2[d]; ++t) ++cnt;
-        const unsigned long long key = skey2[d];
-        const uint32_t cib = (uint32_t)(key % B);
-        const uint32_t blk = (uint32_t)((key / B) / L);
-        atomicAdd(&per_cell_sq[(size_t)blk * B + cib], cnt * cnt);
-    }
-}
-
-__global__ void k_max_u64(const unsigned long long *a, uint32_t n, Scalars *sc) {
-    unsigned long long best = 0;
-    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) best = max(best, a[i]);
-    for (int off = 32; off > 0; off >>= 1) best = max(best, (unsigned long long)__shfl_down(best, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(&sc->pair_bound, best);
-}
-
-// greedy locus ranges (one partition for all cell blocks): the longest range from `s` in which no
-// block has more than cap_entries entries and that has at most cap_loci loci; a locus that exceeds
-// the cap alone becomes a single-locus range. One workgroup; feasibility is monotone in the end.
-__global__ __launch_bounds__(TPB) void k_ranges(const uint32_t *blk_off, uint32_t nb, uint32_t L,
-                                               uint32_t cap_entries, uint32_t cap_loci,
-                                               uint32_t *range_off, Scalars *sc) {
-    const size_t stride = (size_t)L + 1;
-    uint32_t s = 0, nr = 0;
-    if (threadIdx.x == 0) range_off[0] = 0;
-    auto feasible = [&](uint32_t e) {
-        int ok = 1;
-        for (uint32_t b = threadIdx.x; b < nb; b += TPB)
-            if (blk_off[b * stride + e] - blk_off[b * stride + s] > cap_entries) ok = 0;
-        return __syncthreads_and(ok) != 0;
-    };
-    while (s < L) {
-        uint32_t e = s + 1;
-        if (feasible(e)) {
-            uint32_t lo = e, hi = min(L, s + cap_loci);  // lo feasible
-            while (lo < hi) {
-                const uint32_t mid = lo + (hi - lo + 1) / 2;
-                if (feasible(mid)) lo = mid; else hi = mid - 1;
-            }
-            e = lo;
-        }
-        ++nr;
-        if (threadIdx.x == 0) range_off[nr] = e;
-        s = e;
-    }
-    if (threadIdx.x == 0) sc->num_ranges = nr;
-}
-
-__global__ void k_gather(const uint32_t *sval2, uint32_t n, const RecOut tmp, const uint32_t *range_off,
-                         uint32_t n_ranges, uint4 *entry, uint32_t *entry32, uint32_t *mask32,
-                         uint32_t *entry_read) {
-    for (uint32_t d = blockIdx.x * TPB + threadIdx.x; d < n; d += gridDim.x * TPB) {
-        const uint32_t k = sval2[d];
-        const uint4 a = tmp.t_entry[k];
-        const uint32_t r = last_le<uint32_t>(range_off, n_ranges + 1, a.w);
-        entry[d] = a;
-        entry32[d] = tmp.t_c32[k] | ((a.w - range_off[r]) << 16);
-        mask32[d] = tmp.t_m32[k];
-        entry_read[d] = tmp.t_read[k];
+        entry_read[d] = r;
     }
 }
 
@@ -440,8 +488,8 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     HIP_OK(S[WORK_B].ensure(((size_t)E + 1) * 4));
     // RUNS: run_start[R+1] | first_entry[R] | start_pos[R] | run_rank[R] | starts_by_rank[R], R <= E
     HIP_OK(S[RUNS].ensure(((size_t)5 * E + 8) * 4));
-    // TMP: per kept entry 16 + 4 + 4 + 4 bytes; BIN: key2 x2, val2 x2, per-cell squares
-    HIP_OK(S[TMP].ensure((size_t)E * 28 + 64));
+    // TMP: read index per kept entry; BIN: key2 x2, val2 x2, per-cell squares
+    HIP_OK(S[TMP].ensure((size_t)E * 4 + 64));
     HIP_OK(S[BIN].ensure((size_t)E * 24 + ((size_t)num_cells + 130) * 8 + 64));
     unsigned long long *key_a = S[KEY_A].as<unsigned long long>(), *key_b = S[KEY_B].as<unsigned long long>();
     uint32_t *val_a = S[VAL_A].as<uint32_t>(), *val_b = S[VAL_B].as<uint32_t>();
@@ -550,38 +598,30 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     pk.cap_entries = pk.stage_masks ? geo.cap_entries_masks : geo.cap_entries_plain;
     pk.cap_loci = pk.stage_masks ? geo.cap_loci_masks : geo.cap_loci_plain;
 
-    // ---- 5: records, binning, offsets, bound, ranges, gather ---------------------------------
-    RecOut tmp;
-    tmp.t_entry = S[TMP].as<uint4>();
-    tmp.t_c32 = reinterpret_cast<uint32_t *>(tmp.t_entry + nk);
-    tmp.t_m32 = tmp.t_c32 + nk;
-    tmp.t_read = tmp.t_m32 + nk;
+    // ---- 5: binning sort, offsets, bound, ranges, records ---------------------------------------
+    uint32_t *t_read = S[TMP].as<uint32_t>();
     unsigned long long *key2_a = S[BIN].as<unsigned long long>();
     unsigned long long *key2_b = key2_a + nk;
     unsigned long long *per_cell_sq = key2_b + nk;  // nb * B entries
     uint32_t *val2_a = reinterpret_cast<uint32_t *>(per_cell_sq + (size_t)nb * B + 1);
     uint32_t *val2_b = val2_a + nk;
-    tmp.key2 = key2_a;
-    tmp.val2 = val2_a;
     const size_t n_off = (size_t)nb * ((size_t)L + 1);
     uint32_t *blk_off = pk.blk_off.as<uint32_t>();
     uint32_t *blk_cnt = S[KEY_A].as<uint32_t>();  // mark / arank are dead after k_ranks
-    tmp.blk_cnt = blk_cnt;
     HIP_OK(hipMemsetAsync(blk_cnt, 0, (n_off + 1) * 4, stream));
     HIP_OK(hipMemsetAsync(per_cell_sq, 0, ((size_t)nb * B + 1) * 8, stream));
-    hipLaunchKernelGGL(k_records, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sval, keep, slot, run_incl,
-                       read_off, read_locus, read_base, run_rank, rbeg, flushed, num_cells, B, tmp, sc);
+    hipLaunchKernelGGL(k_keys2, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, keep, slot, run_incl,
+                       read_locus, num_cells, B, key2_a, val2_a, t_read, sc);
     if (n_kept) {
         cub_cap = S[CUB].bytes;
         HIP_OK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_cap, key2_a, key2_b, val2_a, val2_b, (int)n_kept, 0,
                                                    bits_for(((unsigned long long)nb * L + L) * B + B), stream));
+        hipLaunchKernelGGL(k_group_counts, dim3(std::min<uint32_t>(2048, (n_kept + 4095) / 4096)), dim3(TPB), 0,
+                           stream, key2_b, n_kept, B, L, blk_cnt, per_cell_sq);
+        hipLaunchKernelGGL(k_max_u64, dim3(blocks_for((size_t)nb * B)), dim3(TPB), 0, stream, per_cell_sq, nb * B, sc);
     }
     cub_cap = S[CUB].bytes;
     HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
-    if (n_kept) {
-        hipLaunchKernelGGL(k_cell_squares, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, key2_b, n_kept, B, L, per_cell_sq);
-        hipLaunchKernelGGL(k_max_u64, dim3(blocks_for((size_t)nb * B)), dim3(TPB), 0, stream, per_cell_sq, nb * B, sc);
-    }
     hipLaunchKernelGGL(k_ranges, dim3(1), dim3(TPB), 0, stream, blk_off, nb, L, pk.cap_entries, pk.cap_loci,
                        pk.range_off.as<uint32_t>(), sc);
     HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
@@ -591,8 +631,9 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     pk.pair_bound = hsc.pair_bound;
     pk.num_ranges = hsc.num_ranges;
     if (n_kept) {
-        hipLaunchKernelGGL(k_gather, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, val2_b, n_kept, tmp,
-                           pk.range_off.as<uint32_t>(), pk.num_ranges, pk.entry.as<uint4>(),
+        hipLaunchKernelGGL(k_records, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, raw, key2_b, val2_b, n_kept,
+                           t_read, read_off, read_locus, read_base, run_rank, rbeg, flushed,
+                           pk.range_off.as<uint32_t>(), pk.num_ranges, B, pk.entry.as<uint4>(),
                            pk.entry32.as<uint32_t>(), pk.mask32.as<uint32_t>(), pk.entry_read.as<uint32_t>());
     }
     HIP_OK(hipGetLastError());
