@@ -318,38 +318,43 @@ __global__ void k_max_u64(const unsigned long long *a, uint32_t n, Scalars *sc) 
     if ((threadIdx.x & 63) == 0) atomicMax(&sc->pair_bound, best);
 }
 
-// greedy locus ranges (one partition for all cell blocks): the longest range from `s` in which no
-// block has more than cap_entries entries and that has at most cap_loci loci; a locus that exceeds
-// the cap alone becomes a single-locus range. One workgroup; feasibility is monotone in the end,
-// and the search starts from the previous range's length (ranges of a pileup are of similar size).
-__global__ __launch_bounds__(TPB) void k_ranges(const uint32_t *blk_off, uint32_t nb, uint32_t L,
-                                               uint32_t cap_entries, uint32_t cap_loci,
-                                               uint32_t *range_off, Scalars *sc) {
+// Locus ranges (one partition shared by all cell blocks). The loci are cut into segments of
+// cap_loci loci, one workgroup per segment; inside its segment a workgroup cuts greedily: the
+// longest range from `s` in which no block has more than cap_entries entries (feasibility is
+// monotone in the range end; the search gallops from the previous range's length); a locus that
+// exceeds the cap alone becomes a single-locus range. k_ranges_compact concatenates the segments.
+__global__ __launch_bounds__(TPB) void k_ranges_segment(const uint32_t *blk_off, uint32_t nb, uint32_t L,
+                                                       uint32_t cap_entries, uint32_t cap_loci,
+                                                       uint32_t *seg_ends, uint32_t *seg_count) {
     const size_t stride = (size_t)L + 1;
-    uint32_t s = 0, nr = 0, guess = 0;
-    if (threadIdx.x == 0) range_off[0] = 0;
+    const uint32_t seg = blockIdx.x;
+    const uint32_t seg_begin = seg * cap_loci, seg_end = min(L, seg_begin + cap_loci);
+    uint32_t *ends = seg_ends + (size_t)seg * cap_loci;  // at most cap_loci ranges per segment
+    uint32_t s = seg_begin, nr = 0, guess = 0;
     auto feasible = [&](uint32_t e) {
         int ok = 1;
         for (uint32_t b = threadIdx.x; b < nb; b += TPB)
             if (blk_off[b * stride + e] - blk_off[b * stride + s] > cap_entries) ok = 0;
         return __syncthreads_and(ok) != 0;
     };
-    while (s < L) {
+    while (s < seg_end) {
         uint32_t e = s + 1;
         if (feasible(e)) {
-            const uint32_t top = min(L, s + cap_loci);
+            const uint32_t top = seg_end;
             uint32_t lo = e, hi = top;  // lo feasible, answer in [lo, hi]
-            if (guess > 1 && s + guess <= top) {  // bracket around the previous length
+            if (feasible(top)) {
+                lo = top;
+            } else if (guess > 1 && s + guess < top) {  // bracket around the previous length
+                hi = top - 1;
                 const uint32_t g = s + guess;
                 if (feasible(g)) {
                     lo = g;
                     uint32_t step = max(guess / 8, 1u);
-                    while (lo < top) {  // gallop up
-                        const uint32_t nx = min(top, lo + step);
+                    while (lo < hi) {  // gallop up
+                        const uint32_t nx = min(hi, lo + step);
                         if (feasible(nx)) lo = nx; else { hi = nx - 1; break; }
                         step *= 2;
                     }
-                    if (lo == top) hi = top;
                 } else {
                     hi = g - 1;
                     uint32_t step = max(guess / 8, 1u);
@@ -360,6 +365,8 @@ __global__ __launch_bounds__(TPB) void k_ranges(const uint32_t *blk_off, uint32_
                         step *= 2;
                     }
                 }
+            } else {
+                hi = top - 1;
             }
             while (lo < hi) {
                 const uint32_t mid = lo + (hi - lo + 1) / 2;
@@ -368,11 +375,30 @@ __global__ __launch_bounds__(TPB) void k_ranges(const uint32_t *blk_off, uint32_
             e = lo;
         }
         guess = e - s;
+        if (threadIdx.x == 0) ends[nr] = e;
         ++nr;
-        if (threadIdx.x == 0) range_off[nr] = e;
         s = e;
     }
-    if (threadIdx.x == 0) sc->num_ranges = nr;
+    if (threadIdx.x == 0) seg_count[seg] = nr;
+}
+
+__global__ __launch_bounds__(TPB) void k_ranges_compact(const uint32_t *seg_ends, const uint32_t *seg_count,
+                                                       uint32_t n_seg, uint32_t cap_loci, uint32_t *range_off,
+                                                       Scalars *sc) {
+    __shared__ uint32_t s_base;
+    if (threadIdx.x == 0) {
+        s_base = 0;
+        range_off[0] = 0;
+    }
+    __syncthreads();
+    for (uint32_t seg = 0; seg < n_seg; ++seg) {
+        const uint32_t base = s_base, cnt = seg_count[seg];
+        for (uint32_t i = threadIdx.x; i < cnt; i += TPB) range_off[1 + base + i] = seg_ends[(size_t)seg * cap_loci + i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = base + cnt;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sc->num_ranges = s_base;
 }
 
 // entry records at their final (binned) position d: window masks from the per-read lists
@@ -483,7 +509,7 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     HIP_OK(S[KEY_B].ensure((size_t)E * 8));
     HIP_OK(S[VAL_A].ensure((size_t)E * 4));
     HIP_OK(S[VAL_B].ensure((size_t)E * 4));
-    HIP_OK(S[ELOC].ensure((size_t)E * 4));
+    HIP_OK(S[ELOC].ensure(std::max<size_t>((size_t)E * 4, ((size_t)L + 8192 + L / 64 + 16) * 4)));
     HIP_OK(S[WORK_A].ensure(((size_t)E + 1) * 4));
     HIP_OK(S[WORK_B].ensure(((size_t)E + 1) * 4));
     // RUNS: run_start[R+1] | first_entry[R] | start_pos[R] | run_rank[R] | starts_by_rank[R], R <= E
@@ -622,8 +648,18 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     }
     cub_cap = S[CUB].bytes;
     HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
-    hipLaunchKernelGGL(k_ranges, dim3(1), dim3(TPB), 0, stream, blk_off, nb, L, pk.cap_entries, pk.cap_loci,
-                       pk.range_off.as<uint32_t>(), sc);
+    {
+        const uint32_t n_seg = (L + pk.cap_loci - 1) / pk.cap_loci;
+        // segment scratch: ends[n_seg * cap_loci] | count[n_seg]  (VAL_B? no: sval lives there) -> WORK_A is
+        // `keep`, still needed by nothing after k_keys2; use ELOC (entry_locus is dead after k_csr)
+        HIP_OK(S[ELOC].ensure(std::max<size_t>((size_t)E * 4, ((size_t)n_seg * pk.cap_loci + n_seg + 2) * 4)));
+        uint32_t *seg_ends = S[ELOC].as<uint32_t>();
+        uint32_t *seg_count = seg_ends + (size_t)n_seg * pk.cap_loci;
+        hipLaunchKernelGGL(k_ranges_segment, dim3(n_seg), dim3(TPB), 0, stream, blk_off, nb, L, pk.cap_entries,
+                           pk.cap_loci, seg_ends, seg_count);
+        hipLaunchKernelGGL(k_ranges_compact, dim3(1), dim3(TPB), 0, stream, seg_ends, seg_count, n_seg, pk.cap_loci,
+                           pk.range_off.as<uint32_t>(), sc);
+    }
     HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
     if (hsc.error == 1) return "group id outside group_id_to_pos";
