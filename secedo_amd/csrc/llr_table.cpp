@@ -72,17 +72,26 @@ LlrTable make_llr_table(double eps, double h, double theta, uint64_t pair_bound)
         }
     }
     t.max_abs_per_locus = per_locus;
+    requantize(&t, llr_scale_for(t, pair_bound));
+    return t;
+}
+
+int llr_scale_for(const LlrTable &t, uint64_t pair_bound) {
     // |sum over one cell pair| <= per_locus * incidences; keep it below 2^62 (1.5x margin for the
     // terms beyond the table, which grow linearly in x_s + x_d as well)
-    const double bound = std::max(1.0, 1.5 * per_locus) * static_cast<double>(std::max<uint64_t>(pair_bound, 1));
+    const double bound = std::max(1.0, 1.5 * t.max_abs_per_locus) * static_cast<double>(std::max<uint64_t>(pair_bound, 1));
     int k = 44;
     while (k > 0 && std::ldexp(bound, k) >= std::ldexp(1.0, 62)) --k;
-    t.scale_log2 = k;
-    for (size_t i = 0; i < t.value.size(); ++i) {
-        const double v = t.value[i];
-        t.fixed[i] = std::isfinite(v) ? static_cast<int64_t>(std::llround(std::ldexp(v, k))) : 0;
+    return k;
+}
+
+void requantize(LlrTable *t, int k) {
+    t->scale_log2 = k;
+    t->fixed.assign(t->value.size(), 0);
+    for (size_t i = 0; i < t->value.size(); ++i) {
+        const double v = t->value[i];
+        t->fixed[i] = std::isfinite(v) ? static_cast<int64_t>(std::llround(std::ldexp(v, k))) : 0;
     }
-    return t;
 }
 
 }  // namespace secedo

@@ -44,4 +44,9 @@ struct LlrTable {
 LlrTable make_llr_table(double mutation_rate, double homozygous_rate, double seq_error_rate,
                         uint64_t pair_bound);
 
+// largest fixed-point scale (<= 44) for which an int64 accumulator cannot overflow given the bound
+int llr_scale_for(const LlrTable &t, uint64_t pair_bound);
+// re-derive t->fixed from t->value for another scale
+void requantize(LlrTable *t, int scale_log2);
+
 }  // namespace secedo

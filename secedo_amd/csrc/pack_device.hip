@@ -124,9 +124,10 @@ __global__ void k_run_starts(const uint32_t *head, const uint32_t *run_incl, uin
 }
 
 // per read: first entry, start position, span check; marks first entries for the appearance rank
-__global__ void k_run_info(Raw in, const uint32_t *run_start, uint32_t n_runs, const uint32_t *sval,
+__global__ void k_run_info(Raw in, const uint32_t *run_start, const uint32_t *n_runs_p, const uint32_t *sval,
                            const uint32_t *entry_locus, uint32_t mfl, uint32_t *first_entry,
                            uint32_t *start_pos, uint32_t *mark, Scalars *sc) {
+    const uint32_t n_runs = *n_runs_p;
     for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r < n_runs; r += gridDim.x * TPB) {
         const uint32_t e0 = sval[run_start[r]], e1 = sval[run_start[r + 1] - 1];
         const uint32_t p0 = in.locus_pos[entry_locus[e0]], p1 = in.locus_pos[entry_locus[e1]];
@@ -173,13 +174,15 @@ __global__ void k_csr(Raw in, const uint32_t *sval, const uint32_t *entry_locus,
 }
 
 __global__ void k_read_off(const uint32_t *run_start, const uint32_t *slot, const uint32_t *keep,
-                           uint32_t n_runs, uint32_t n, uint32_t *read_off) {
+                           const uint32_t *n_runs_p, uint32_t n, uint32_t *read_off) {
+    const uint32_t n_runs = *n_runs_p;
     for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r <= n_runs; r += gridDim.x * TPB) {
         read_off[r] = (r < n_runs) ? slot[run_start[r]] : slot[n - 1] + keep[n - 1];
     }
 }
 
-__global__ void k_multi(const uint32_t *read_off, uint32_t n_runs, Scalars *sc) {
+__global__ void k_multi(const uint32_t *read_off, const uint32_t *n_runs_p, Scalars *sc) {
+    const uint32_t n_runs = *n_runs_p;
     unsigned long long local = 0;
     for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r < n_runs; r += gridDim.x * TPB) {
         const uint32_t c = read_off[r + 1] - read_off[r];
@@ -191,8 +194,9 @@ __global__ void k_multi(const uint32_t *read_off, uint32_t n_runs, Scalars *sc) 
 
 // appearance rank of each read; read starts in rank order; per chromosome the first rank
 __global__ void k_ranks(Raw in, const uint32_t *first_entry, const uint32_t *start_pos,
-                        const uint32_t *arank, uint32_t n_runs, uint32_t *run_rank,
+                        const uint32_t *arank, const uint32_t *n_runs_p, uint32_t *run_rank,
                         uint32_t *starts_by_rank, uint32_t *rbeg) {
+    const uint32_t n_runs = *n_runs_p;
     for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r < n_runs; r += gridDim.x * TPB) {
         const uint32_t rk = arank[first_entry[r]];
         run_rank[r] = rk;
@@ -405,9 +409,10 @@ __global__ __launch_bounds__(TPB) void k_ranges_compact(const uint32_t *seg_ends
 __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_t *sval2, uint32_t n,
                           const uint32_t *t_read, const uint32_t *read_off, const uint32_t *read_locus,
                           const uint8_t *read_base, const uint32_t *run_rank, const uint32_t *rbeg,
-                          const uint32_t *flushed, const uint32_t *range_off, uint32_t n_ranges, uint32_t B,
+                          const uint32_t *flushed, const uint32_t *range_off, const Scalars *sc, uint32_t B,
                           uint4 *entry, uint32_t *entry32, uint32_t *mask32, uint32_t *entry_read) {
     const uint32_t L = in.n_loci;
+    const uint32_t n_ranges = sc->num_ranges;
     for (uint32_t d = blockIdx.x * TPB + threadIdx.x; d < n; d += gridDim.x * TPB) {
         const unsigned long long key = skey2[d];
         const uint32_t k = sval2[d];
@@ -545,21 +550,21 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     const uint32_t *sval = val_b;
 
     // ---- 2: reads = runs of equal key ------------------------------------------------------
-    uint32_t *head = work_a, *run_incl = work_b;  // run_incl stays alive until k_records
+    // (the number of reads R stays on the device until the read-back after step 4; buffers that are
+    // indexed by read are laid out for the upper bound E)
+    uint32_t *head = work_a, *run_incl = work_b;  // run_incl stays alive until k_keys2
     hipLaunchKernelGGL(k_heads, dim3(blocks_for(E)), dim3(TPB), 0, stream, skey, E, head);
     cub_cap = S[CUB].bytes;
     HIP_OK(hipcub::DeviceScan::InclusiveSum(cub_tmp, cub_cap, head, run_incl, (int)E, stream));
-    uint32_t R = 0;
-    HIP_OK(hipMemcpyAsync(&R, run_incl + (E - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));
+    const uint32_t *d_R = run_incl + (E - 1);
     uint32_t *run_start = S[RUNS].as<uint32_t>();
-    uint32_t *first_entry = run_start + R + 1, *start_pos = first_entry + R, *run_rank = start_pos + R,
-             *starts_by_rank = run_rank + R;
+    uint32_t *first_entry = run_start + E + 1, *start_pos = first_entry + E, *run_rank = start_pos + E,
+             *starts_by_rank = run_rank + E;
     hipLaunchKernelGGL(k_run_starts, dim3(blocks_for(E)), dim3(TPB), 0, stream, head, run_incl, E, run_start);
     uint32_t *mark = S[KEY_A].as<uint32_t>();  // the unsorted keys are dead
     uint32_t *arank = mark + (E + 1);
     HIP_OK(hipMemsetAsync(mark, 0, ((size_t)E + 1) * 4, stream));
-    hipLaunchKernelGGL(k_run_info, dim3(blocks_for(R)), dim3(TPB), 0, stream, raw, run_start, R, sval, eloc, mfl,
+    hipLaunchKernelGGL(k_run_info, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, run_start, d_R, sval, eloc, mfl,
                        first_entry, start_pos, mark, sc);
     uint32_t *keep = work_a;  // overwrites head (k_run_starts is done with it: same stream)
     hipLaunchKernelGGL(k_dup_rule, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sval, eloc, E, keep);
@@ -568,8 +573,33 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, keep, slot, (int)E, stream));
     cub_cap = S[CUB].bytes;
     HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, mark, arank, (int)E + 1, stream));
-    uint32_t last_slot = 0, last_keep = 0;
+
+    // ---- 3: per-read lists (sized for the upper bound E) --------------------------------------
+    HIP_OK(pk.read_off.ensure(((size_t)E + 1) * 4));
+    HIP_OK(pk.read_locus.ensure((size_t)E * 4));
+    HIP_OK(pk.read_base.ensure(E));
+    HIP_OK(pk.range_off.ensure(((size_t)L + 2) * 4));
+    HIP_OK(pk.entry.ensure((size_t)E * 16));
+    HIP_OK(pk.entry32.ensure((size_t)E * 4));
+    HIP_OK(pk.mask32.ensure((size_t)E * 4));
+    HIP_OK(pk.entry_read.ensure((size_t)E * 4));
+    HIP_OK(pk.blk_off.ensure((n_off_max + 1) * 4));
+    uint32_t *read_off = pk.read_off.as<uint32_t>(), *read_locus = pk.read_locus.as<uint32_t>();
+    uint8_t *read_base = pk.read_base.as<uint8_t>();
+    hipLaunchKernelGGL(k_csr, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, eloc, keep, slot, E, read_locus, read_base);
+    hipLaunchKernelGGL(k_read_off, dim3(blocks_for(E)), dim3(TPB), 0, stream, run_start, slot, keep, d_R, E, read_off);
+    hipLaunchKernelGGL(k_multi, dim3(blocks_for(E)), dim3(TPB), 0, stream, read_off, d_R, sc);
+
+    // ---- 4: appearance ranks, completed counts, flush chain ----------------------------------
+    hipLaunchKernelGGL(k_ranks, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, first_entry, start_pos, arank, d_R,
+                       run_rank, starts_by_rank, rbeg);
+    hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, starts_by_rank, rbeg, mfl, cnt);
+    hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, stream, raw, cnt, 4u * num_threads, flushed);
+
+    // the one mid-pipeline read-back: status flags, R, number of kept entries, multi-locus statistics
+    uint32_t R = 0, last_slot = 0, last_keep = 0;
     Scalars hsc;
+    HIP_OK(hipMemcpyAsync(&R, d_R, 4, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipMemcpyAsync(&last_slot, slot + (E - 1), 4, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipMemcpyAsync(&last_keep, keep + (E - 1), 4, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
@@ -581,31 +611,6 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     }
     const uint32_t n_kept = last_slot + last_keep;
     const size_t nk = std::max<uint32_t>(n_kept, 1);
-
-    // ---- 3: per-read lists ------------------------------------------------------------------
-    HIP_OK(pk.read_off.ensure(((size_t)R + 1) * 4));
-    HIP_OK(pk.read_locus.ensure(nk * 4));
-    HIP_OK(pk.read_base.ensure(nk));
-    HIP_OK(pk.range_off.ensure(((size_t)L + 2) * 4));
-    HIP_OK(pk.entry.ensure(nk * 16));
-    HIP_OK(pk.entry32.ensure(nk * 4));
-    HIP_OK(pk.mask32.ensure(nk * 4));
-    HIP_OK(pk.entry_read.ensure(nk * 4));
-    HIP_OK(pk.blk_off.ensure((n_off_max + 1) * 4));
-    uint32_t *read_off = pk.read_off.as<uint32_t>(), *read_locus = pk.read_locus.as<uint32_t>();
-    uint8_t *read_base = pk.read_base.as<uint8_t>();
-    hipLaunchKernelGGL(k_csr, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, eloc, keep, slot, E, read_locus, read_base);
-    hipLaunchKernelGGL(k_read_off, dim3(blocks_for(R + 1)), dim3(TPB), 0, stream, run_start, slot, keep, R, E, read_off);
-    hipLaunchKernelGGL(k_multi, dim3(blocks_for(R)), dim3(TPB), 0, stream, read_off, R, sc);
-
-    // ---- 4: appearance ranks, completed counts, flush chain ----------------------------------
-    hipLaunchKernelGGL(k_ranks, dim3(blocks_for(std::max(R, C + 1))), dim3(TPB), 0, stream, raw, first_entry,
-                       start_pos, arank, R, run_rank, starts_by_rank, rbeg);
-    hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, starts_by_rank, rbeg, mfl, cnt);
-    hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, stream, raw, cnt, 4u * num_threads, flushed);
-
-    HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));
     pk.multi_entries = hsc.multi_entries;
     if (block_cells == 0) {
         const StageGeometry g64 = geometry(64);
@@ -660,18 +665,18 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
         hipLaunchKernelGGL(k_ranges_compact, dim3(1), dim3(TPB), 0, stream, seg_ends, seg_count, n_seg, pk.cap_loci,
                            pk.range_off.as<uint32_t>(), sc);
     }
+    if (n_kept) {
+        hipLaunchKernelGGL(k_records, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, raw, key2_b, val2_b, n_kept,
+                           t_read, read_off, read_locus, read_base, run_rank, rbeg, flushed,
+                           pk.range_off.as<uint32_t>(), sc, B, pk.entry.as<uint4>(),
+                           pk.entry32.as<uint32_t>(), pk.mask32.as<uint32_t>(), pk.entry_read.as<uint32_t>());
+    }
     HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
     if (hsc.error == 1) return "group id outside group_id_to_pos";
     if (hsc.error == 2) return "group_id_to_pos maps outside the matrix";
     pk.pair_bound = hsc.pair_bound;
     pk.num_ranges = hsc.num_ranges;
-    if (n_kept) {
-        hipLaunchKernelGGL(k_records, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, raw, key2_b, val2_b, n_kept,
-                           t_read, read_off, read_locus, read_base, run_rank, rbeg, flushed,
-                           pk.range_off.as<uint32_t>(), pk.num_ranges, B, pk.entry.as<uint4>(),
-                           pk.entry32.as<uint32_t>(), pk.mask32.as<uint32_t>(), pk.entry_read.as<uint32_t>());
-    }
     HIP_OK(hipGetLastError());
     return std::string();
 }

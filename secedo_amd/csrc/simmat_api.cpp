@@ -86,10 +86,12 @@ struct secedo_simmat {
     DevBuf own_acc, own_out;  // used by the one-shot entry point only
 
     // LLR table of the last accumulate()
-    bool have_lut = false;
+    bool have_model = false, have_lut = false, have_slow = false;
     double lut_eps = 0, lut_h = 0, lut_theta = 0;
     int scale_log2 = 44;
     secedo::LlrModel model;
+    secedo::LlrTable table;
+    secedo::SlowPathArgs slow_host;
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timed = false;
@@ -374,7 +376,6 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
     HIP_TRY(h->counters.ensure(2 * sizeof(unsigned long long)));
     HIP_TRY(h->max_bits.ensure(sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(unsigned long long), s));
-    h->have_lut = false;
     h->prepared = true;
     h->timed = false;
     return SECEDO_OK;
@@ -407,32 +408,44 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
 
-    if (!h->have_lut || h->lut_eps != eps || h->lut_h != hr || h->lut_theta != theta) {
-        const secedo::LlrTable t = secedo::make_llr_table(eps, hr, theta, h->pk.pair_bound);
-        HIP_TRY(h->lut.ensure(t.fixed.size() * sizeof(int64_t)));
-        // pageable-memory copy on the same stream: complete before it returns
-        HIP_TRY(hipMemcpyAsync(h->lut.p, t.fixed.data(), t.fixed.size() * sizeof(int64_t),
-                               hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        h->model = t.model;
-        h->scale_log2 = t.scale_log2;
+    // LLR table: the doubles depend on the rates only, the fixed-point scale on the pileup's pair
+    // bound; upload (synchronously, it is rare) only what changed since the last call
+    if (!h->have_model || h->lut_eps != eps || h->lut_h != hr || h->lut_theta != theta) {
+        h->table = secedo::make_llr_table(eps, hr, theta, h->pk.pair_bound);
+        h->lut_eps = eps;
+        h->lut_h = hr;
+        h->lut_theta = theta;
+        h->have_model = true;
+        h->have_lut = false;
+    }
+    {
+        const int want_scale = secedo::llr_scale_for(h->table, h->pk.pair_bound);
+        if (!h->have_lut || want_scale != h->scale_log2) {
+            secedo::requantize(&h->table, want_scale);
+            HIP_TRY(h->lut.ensure(h->table.fixed.size() * sizeof(int64_t)));
+            HIP_TRY(hipMemcpy(h->lut.p, h->table.fixed.data(), h->table.fixed.size() * sizeof(int64_t),
+                              hipMemcpyHostToDevice));
+            h->scale_log2 = want_scale;
+            h->model = h->table.model;
+            h->have_lut = true;
+        }
         secedo::SlowPathArgs sp;
+        std::memset(&sp, 0, sizeof(sp));
         sp.entry = h->pk.entry.as<uint4>();
         sp.entry_read = h->pk.entry_read.as<uint32_t>();
         sp.read_off = h->pk.read_off.as<uint32_t>();
         sp.read_locus = h->pk.read_locus.as<uint32_t>();
         sp.read_base = h->pk.read_base.as<uint8_t>();
         sp.lut = h->lut.as<long long>();
-        sp.model = secedo::LlrModelDev{t.model.ln_u1, t.model.ln_v1, t.model.ln_u2, t.model.ln_v2,
-                                       t.model.ln_w1, t.model.ln_z1, t.model.ln_w2, t.model.ln_z2};
-        sp.scale_log2 = t.scale_log2;
-        HIP_TRY(h->slow_args.ensure(sizeof(sp)));
-        HIP_TRY(hipMemcpyAsync(h->slow_args.p, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        h->lut_eps = eps;
-        h->lut_h = hr;
-        h->lut_theta = theta;
-        h->have_lut = true;
+        const secedo::LlrModel &m = h->table.model;
+        sp.model = secedo::LlrModelDev{m.ln_u1, m.ln_v1, m.ln_u2, m.ln_v2, m.ln_w1, m.ln_z1, m.ln_w2, m.ln_z2};
+        sp.scale_log2 = h->scale_log2;
+        if (!h->have_slow || std::memcmp(&sp, &h->slow_host, sizeof(sp)) != 0) {
+            HIP_TRY(h->slow_args.ensure(sizeof(sp)));
+            HIP_TRY(hipMemcpy(h->slow_args.p, &sp, sizeof(sp), hipMemcpyHostToDevice));
+            h->slow_host = sp;
+            h->have_slow = true;
+        }
     }
 
     const uint32_t n_tiles = tile_end - tile_begin;

@@ -514,9 +514,16 @@ hipError_t launch_acc(const AccumulateArgs &args, uint32_t grid, hipStream_t str
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((CAPL + 2) % 4 == 0 && CAPJ % 8 == 0 && HCAP % 16 == 0, "alignment of the LDS carve-up");
     auto kern = &accumulate_tiles<B, THREADS, CAPJ, CAPL, HCAP, MASKS, COUNTS>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static thread_local int configured_device = -1;  // the attribute is per device and sticky
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    if (configured_device != dev) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        if (e != hipSuccess) return e;
+        configured_device = dev;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
     return hipGetLastError();
 }

@@ -210,3 +210,16 @@ def test_resident_pileup_and_fallback_to_host():
         plan.set_packing("device")
         with pytest.raises(secedo_amd.SecedoError):
             plan.prepare_resident(res, n, 150, 4)
+
+
+def test_more_than_16383_cells_u32_ids():
+    """Cell ids beyond the reference's 14-bit packing (sequenced_data.hpp:29-37): the
+    32-bit id_base variant of the C-ABI, 17000 cells (133 cell blocks, 8911 tiles). The oracle is the
+    checker here (the reference itself cannot represent these ids)."""
+    n = 17000
+    p = random_pileup(71, n, 2, 700, 60, 2500, dup_frac=0.02)
+    assert int(p.id_base.max()) > 0xFFFF
+    got = secedo_amd.compute_similarity_matrix(p, n, 1000, None, 0.01, 0.5, 0.01, 8, "", "ADD_MIN")
+    ref = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 8, "ADD_MIN")
+    assert gu.normwise_err(got, ref) <= TOL
+    assert np.array_equal(got, got.T)
