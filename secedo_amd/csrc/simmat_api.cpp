@@ -82,7 +82,8 @@ struct secedo_simmat {
     // the packed pileup in HBM + geometry
     secedo::DevicePacked pk;
     uint32_t num_tiles = 0;
-    DevBuf tile_row, tile_col, lut, counters, max_bits, slow_args;
+    DevBuf tile_row, tile_col, lut, counters, max_bits, slow_args, slab, plan_wg_tile, plan_wg_begin;
+    uint32_t plan_tile_begin = 0xFFFFFFFFu, plan_tile_end = 0, plan_ranges = 0, plan_blocks = 0, plan_workgroups = 0;
     DevBuf own_acc, own_out;  // used by the one-shot entry point only
 
     // LLR table of the last accumulate()
@@ -460,16 +461,54 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     a.tile_row = h->tile_row.as<uint16_t>();
     a.tile_col = h->tile_col.as<uint16_t>();
     a.tile_begin = tile_begin;
-    // enough workgroups to fill 256 CUs several times over; a workgroup walks whole locus ranges
-    uint32_t target_wgs = h->pk.block_cells == 128 ? 576 : 2048;  // 1024- vs 256-thread workgroups
-    if (const char *env = std::getenv("SECEDO_TARGET_WGS")) target_wgs = std::max(1, std::atoi(env));
-    uint32_t chunks = 1;
-    if (n_tiles && n_tiles < target_wgs) chunks = (target_wgs + n_tiles - 1) / n_tiles;
-    if (chunks > h->pk.num_ranges) chunks = h->pk.num_ranges ? h->pk.num_ranges : 1;
-    a.chunk_ranges = (h->pk.num_ranges + chunks - 1) / chunks;
-    if (a.chunk_ranges == 0) a.chunk_ranges = 1;
-    a.n_chunks = (h->pk.num_ranges + a.chunk_ranges - 1) / a.chunk_ranges;
-    if (a.n_chunks == 0) a.n_chunks = 1;
+    // Workgroups: every tile is cut into chunks of locus ranges so that the launch fills the 256 CUs
+    // in whole rounds of about equally loaded workgroups (a diagonal tile holds half the pairs of an
+    // off-diagonal one and gets half the chunks). Cached per tile range.
+    if (h->plan_tile_begin != tile_begin || h->plan_tile_end != tile_end || h->plan_ranges != h->pk.num_ranges
+        || h->plan_blocks != h->pk.num_blocks) {
+        const uint32_t wgs_per_round = h->pk.block_cells == 128 ? 256u : 1024u;  // 1 resp. 4 per CU
+        uint32_t rounds = 1;
+        if (const char *env = std::getenv("SECEDO_ROUNDS")) rounds = std::max(1, std::atoi(env));
+        std::vector<uint32_t> weight(n_tiles);
+        uint64_t total_weight = 0;
+        {
+            // tile index -> (row, col) of the upper triangle, row-major
+            uint32_t t = 0;
+            for (uint32_t i = 0; i < h->pk.num_blocks; ++i) {
+                for (uint32_t j = i; j < h->pk.num_blocks; ++j, ++t) {
+                    if (t >= tile_begin && t < tile_end) {
+                        weight[t - tile_begin] = (i == j) ? 1u : 2u;
+                        total_weight += weight[t - tile_begin];
+                    }
+                }
+            }
+        }
+        const uint64_t slots = static_cast<uint64_t>(wgs_per_round) * rounds;
+        std::vector<uint32_t> wg_begin(n_tiles + 1, 0);
+        std::vector<uint16_t> wg_tile;
+        for (uint32_t t = 0; t < n_tiles; ++t) {
+            uint64_t c = total_weight ? (weight[t] * slots + total_weight / 2) / total_weight : 1;
+            c = std::max<uint64_t>(1, std::min<uint64_t>(c, h->pk.num_ranges ? h->pk.num_ranges : 1));
+            // a chunk count that leaves the last chunk empty would waste a workgroup
+            const uint32_t per = (h->pk.num_ranges + static_cast<uint32_t>(c) - 1) / static_cast<uint32_t>(c);
+            if (per) c = (h->pk.num_ranges + per - 1) / per;
+            if (c == 0) c = 1;
+            wg_begin[t + 1] = wg_begin[t] + static_cast<uint32_t>(c);
+            for (uint64_t k = 0; k < c; ++k) wg_tile.push_back(static_cast<uint16_t>(t));
+        }
+        if (n_tiles > 65535) return fail(SECEDO_E_LIMIT, "more than 65535 tiles in one accumulate call: split the tile range");
+        HIP_TRY(h->plan_wg_tile.upload(wg_tile));
+        HIP_TRY(h->plan_wg_begin.upload(wg_begin));
+        h->plan_workgroups = wg_begin[n_tiles];
+        h->plan_tile_begin = tile_begin;
+        h->plan_tile_end = tile_end;
+        h->plan_ranges = h->pk.num_ranges;
+        h->plan_blocks = h->pk.num_blocks;
+    }
+    a.n_tiles = n_tiles;
+    a.n_workgroups = h->plan_workgroups;
+    a.wg_tile = h->plan_wg_tile.as<uint16_t>();
+    a.tile_wg_begin = h->plan_wg_begin.as<uint32_t>();
     a.debug = 0;
     if (const char *env = std::getenv("SECEDO_DEBUG_ABLATE")) a.debug = static_cast<uint32_t>(std::atoi(env));
     a.lut = h->lut.as<long long>();
@@ -482,6 +521,8 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     // 16-bit pair counters per cell pair are safe when no cell pair can collect 65536 pairs
     bool count_tile = !h->pk.stage_masks && h->pk.pair_bound < 65536;
     if (const char *env = std::getenv("SECEDO_COUNT_TILE")) count_tile = count_tile && std::atoi(env) != 0;
+    HIP_TRY(h->slab.ensure(secedo::accumulate_slab_bytes(h->pk.block_cells, count_tile, a.n_workgroups)));
+    a.slab = h->slab.p;
     HIP_TRY(secedo::launch_accumulate(a, h->pk.block_cells, h->pk.stage_masks, count_tile, n_tiles, s));
     HIP_TRY(hipEventRecord(h->ev_end, s));
     h->timed = true;

@@ -144,8 +144,13 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     uint2 *wrec = reinterpret_cast<uint2 *>(wave_base + HCAP);
     uint32_t *wm = reinterpret_cast<uint32_t *>(wave_base + HCAP + 64 * 8);
 
-    const uint32_t t = a.tile_begin + blockIdx.x / a.n_chunks;
-    const uint32_t chunk = blockIdx.x % a.n_chunks;
+    // workgroup -> (tile, chunk of the tile's locus ranges); diagonal tiles hold half the pairs and
+    // get half the chunks, so that all workgroups of a launch carry about the same work
+    const uint32_t t_local = a.wg_tile[blockIdx.x];
+    const uint32_t t = a.tile_begin + t_local;
+    const uint32_t chunk = blockIdx.x - a.tile_wg_begin[t_local];
+    const uint32_t n_chunks_t = a.tile_wg_begin[t_local + 1] - a.tile_wg_begin[t_local];
+    const uint32_t chunk_ranges = (a.num_ranges + n_chunks_t - 1) / n_chunks_t;
     const uint32_t I = a.tile_row[t], J = a.tile_col[t];
     const bool diag = (I == J);
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -160,8 +165,8 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
             sLut[i] = a.lut[(i / SLUT_DIM) * LUT_DIM + (i % SLUT_DIM)];
     }
 
-    const uint32_t r_begin = min(a.num_ranges, chunk * a.chunk_ranges);
-    const uint32_t r_end = min(a.num_ranges, r_begin + a.chunk_ranges);
+    const uint32_t r_begin = min(a.num_ranges, chunk * chunk_ranges);
+    const uint32_t r_end = min(a.num_ranges, r_begin + chunk_ranges);
     const uint32_t *offI = a.blk_off + (size_t)I * a.stride;
     const uint32_t *offJ = a.blk_off + (size_t)J * a.stride;
     const long long d10 = a.lut[1 * LUT_DIM + 0], d01 = a.lut[0 * LUT_DIM + 1];
@@ -413,16 +418,16 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     }
     __syncthreads();
 
-    // flush: always additive (joint terms and deep ranges may already have landed in HBM)
-    for (uint32_t i = tid; i < B * B; i += THREADS) {
-        unsigned long long v;
-        if (COUNTS) {
-            const uint32_t c = tile32[i];
-            v = (unsigned long long)((long long)(c & 0xFFFFu) * d10 + (long long)(c >> 16) * d01);
-        } else {
-            v = tile64[i];
-        }
-        if (v) atomicAdd(&dst[i], v);
+    // flush: the workgroup's tile goes to its own slab with plain coalesced stores; reduce_slabs adds
+    // the slabs of a tile into the accumulator (joint terms and deep ranges went there directly)
+    if (COUNTS) {
+        uint4 *out = reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(a.slab) + (size_t)blockIdx.x * B * B);
+        const uint4 *src = reinterpret_cast<const uint4 *>(tile32);
+        for (uint32_t i = tid; i < B * B / 4; i += THREADS) out[i] = src[i];
+    } else {
+        uint4 *out = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned long long *>(a.slab) + (size_t)blockIdx.x * B * B);
+        const uint4 *src = reinterpret_cast<const uint4 *>(tile64);
+        for (uint32_t i = tid; i < B * B / 2; i += THREADS) out[i] = src[i];
     }
 
     // work counters: wave reduction, one atomic per wave
@@ -434,6 +439,32 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
         atomicAdd(&a.counters[0], n_updates);
         atomicAdd(&a.counters[1], n_pairs);
     }
+}
+
+// acc[tile] += sum over the tile's workgroups of their slab (count slabs are converted with the two
+// single-locus ratios: exact integer arithmetic). One thread per cell pair of a tile.
+template <int B, bool COUNTS>
+__global__ __launch_bounds__(256) void reduce_slabs(const void *slab, const uint32_t *tile_wg_begin,
+                                                   uint32_t tile_begin, const long long *lut, long long *acc) {
+    const uint32_t t_local = blockIdx.x / (B * B / 256);
+    const uint32_t cell = (blockIdx.x % (B * B / 256)) * 256 + threadIdx.x;
+    const uint32_t w0 = tile_wg_begin[t_local], w1 = tile_wg_begin[t_local + 1];
+    long long sum = 0;
+    if (COUNTS) {
+        const long long d10 = lut[1 * LUT_DIM + 0], d01 = lut[0 * LUT_DIM + 1];
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(slab) + cell;
+        uint32_t same = 0, diff = 0;
+        for (uint32_t w = w0; w < w1; ++w) {
+            const uint32_t v = p[(size_t)w * B * B];
+            same += v & 0xFFFFu;
+            diff += v >> 16;
+        }
+        sum = (long long)same * d10 + (long long)diff * d01;
+    } else {
+        const long long *p = reinterpret_cast<const long long *>(slab) + cell;
+        for (uint32_t w = w0; w < w1; ++w) sum += p[(size_t)w * B * B];
+    }
+    if (sum) acc[(size_t)(tile_begin + t_local) * B * B + cell] += sum;
 }
 
 // upper-triangular tile index of (I <= J)
@@ -525,10 +556,17 @@ hipError_t launch_acc(const AccumulateArgs &args, uint32_t grid, hipStream_t str
         configured_device = dev;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
+    hipLaunchKernelGGL((reduce_slabs<B, COUNTS>), dim3(args.n_tiles * (B * B / 256)), dim3(256), 0, stream,
+                       args.slab, args.tile_wg_begin, args.tile_begin, args.lut,
+                       reinterpret_cast<long long *>(args.acc));
     return hipGetLastError();
 }
 
 }  // namespace
+
+size_t accumulate_slab_bytes(uint32_t block_cells, bool count_tile, uint32_t n_workgroups) {
+    return (size_t)n_workgroups * block_cells * block_cells * (count_tile ? 4 : 8);
+}
 
 StageGeometry stage_geometry(uint32_t block_cells) {
     if (block_cells == 128) return StageGeometry{kCapJ128, kCapL128, kCapJ128, kCapL128, 2.0 /* never */};
@@ -538,7 +576,7 @@ StageGeometry stage_geometry(uint32_t block_cells) {
 hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, bool stage_masks,
                              bool count_tile, uint32_t n_tiles, hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
-    const uint32_t grid = n_tiles * args.n_chunks;
+    const uint32_t grid = args.n_workgroups;
     if (block_cells == 128) {
         // the 128 KiB int64 tile leaves no room for the window masks: joint terms go through HBM
         if (count_tile) return launch_acc<128, 1024, kCapJ128, kCapL128, 1024, false, true>(args, grid, stream);

@@ -51,17 +51,23 @@ struct AccumulateArgs {
     const uint16_t *tile_row;
     const uint16_t *tile_col;
     uint32_t tile_begin;       // first tile of this launch
-    uint32_t n_chunks;         // workgroups per tile
-    uint32_t chunk_ranges;     // locus ranges per workgroup
+    uint32_t n_tiles;          // tiles of this launch
+    uint32_t n_workgroups;     // = tile_wg_begin[n_tiles]
+    const uint16_t *wg_tile;   // workgroup -> tile (relative to tile_begin)
+    const uint32_t *tile_wg_begin;  // n_tiles + 1: first workgroup of each tile (its chunks follow)
     uint32_t debug;            // ablation switches for profiling (0 in production)
     // log-likelihood ratios, fixed point
     const long long *lut;      // 65 x 65, row = x_s
     // outputs
     int64_t *acc;              // tile-major: [tile][B*B]
+    void *slab;                // one B*B tile (u32 counts or int64) per workgroup of the launch
     unsigned long long *counters;  // [0] incidences examined, [1] read pairs accumulated
 };
 
 StageGeometry stage_geometry(uint32_t block_cells);
+
+// workspace of one accumulate launch: a tile per workgroup (plain-store flush, then reduce_slabs)
+size_t accumulate_slab_bytes(uint32_t block_cells, bool count_tile, uint32_t n_workgroups);
 
 // stage_masks / count_tile: the kernel variants, see accumulate_tiles. count_tile requires fewer
 // than 65536 pairs per cell pair (PackedPileup::pair_bound) and !stage_masks; stage_masks exists
