@@ -325,31 +325,33 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                         // exec-mask bookkeeping.
                         uint32_t multi_seen = 0;
                         const uint32_t last = total - 1u;
-                        for (uint32_t base = 0; base < ((a.debug & 2u) ? 0u : total); base += 128u) {
-                            const uint32_t pa = base + lane, pb = pa + 64u;
-                            const uint32_t oa = owner[min(pa, last)], ob = owner[min(pb, last)];
-                            const uint2 ra = wrec[oa], rb = wrec[ob];
-                            const uint32_t wa = sJ[ra.y + min(pa, last)], wb = sJ[rb.y + min(pb, last)];
-                            const uint32_t xa = ra.x ^ wa, ba = ra.x & wa;
-                            const uint32_t xb = rb.x ^ wb, bb = rb.x & wb;
-                            // reads both never flushed do not pair (:407-408); inside a diagonal
-                            // tile equal cells do not pair (:215)
-                            const bool oka = pa < total && (ba & C_TAIL) == 0u && ((xa & cell_test) != 0u || !diag);
-                            const bool okb = pb < total && (bb & C_TAIL) == 0u && ((xb & cell_test) != 0u || !diag);
-                            upd += (oka ? 1u : 0u) + (okb ? 1u : 0u);
-                            multi_seen |= (oka ? ba : 0u) | (okb ? bb : 0u);
-                            if (a.debug & 1u) continue;
-                            if (oka && (ba & C_MULTI) == 0u) {
-                                const uint32_t cell = (ra.x >> 16) + (wa & C_CELL);
-                                const bool differ = (xa & (3u << C_BASE_SHIFT)) != 0u;
-                                if (COUNTS) atomicAdd(&tile32[cell], differ ? 0x10000u : 1u);
-                                else atomicAdd(&tile64[cell], (unsigned long long)(differ ? d01 : d10));
-                            }
-                            if (okb && (bb & C_MULTI) == 0u) {
-                                const uint32_t cell = (rb.x >> 16) + (wb & C_CELL);
-                                const bool differ = (xb & (3u << C_BASE_SHIFT)) != 0u;
-                                if (COUNTS) atomicAdd(&tile32[cell], differ ? 0x10000u : 1u);
-                                else atomicAdd(&tile64[cell], (unsigned long long)(differ ? d01 : d10));
+                        constexpr int PPL = 2;  // pairs per lane and trip: independent LDS read chains (4 is no faster)
+                        for (uint32_t base = 0; base < ((a.debug & 2u) ? 0u : total); base += 64u * PPL) {
+                            uint32_t pp[PPL], oo[PPL], ww[PPL];
+                            uint2 rr[PPL];
+#pragma unroll
+                            for (int u = 0; u < PPL; ++u) pp[u] = base + lane + 64u * u;
+#pragma unroll
+                            for (int u = 0; u < PPL; ++u) oo[u] = owner[min(pp[u], last)];
+#pragma unroll
+                            for (int u = 0; u < PPL; ++u) rr[u] = wrec[oo[u]];
+#pragma unroll
+                            for (int u = 0; u < PPL; ++u) ww[u] = sJ[rr[u].y + min(pp[u], last)];
+#pragma unroll
+                            for (int u = 0; u < PPL; ++u) {
+                                const uint32_t x = rr[u].x ^ ww[u], both = rr[u].x & ww[u];
+                                // reads both never flushed do not pair (:407-408); inside a diagonal
+                                // tile equal cells do not pair (:215)
+                                const bool ok = pp[u] < total && (both & C_TAIL) == 0u
+                                        && ((x & cell_test) != 0u || !diag);
+                                upd += ok ? 1u : 0u;
+                                multi_seen |= ok ? both : 0u;
+                                if ((a.debug & 1u) == 0u && ok && (both & C_MULTI) == 0u) {
+                                    const uint32_t cell = (rr[u].x >> 16) + (ww[u] & C_CELL);
+                                    const bool differ = (x & (3u << C_BASE_SHIFT)) != 0u;
+                                    if (COUNTS) atomicAdd(&tile32[cell], differ ? 0x10000u : 1u);
+                                    else atomicAdd(&tile64[cell], (unsigned long long)(differ ? d01 : d10));
+                                }
                             }
                         }
                         const bool any_multi = (multi_seen & C_MULTI) != 0u;
