@@ -50,6 +50,8 @@ def _load_oracle():
         lib.oracle_normalize.argtypes = [C.c_int, _f64p, C.c_uint32]
         lib.oracle_set_exact_binomials.restype = None
         lib.oracle_set_exact_binomials.argtypes = [C.c_int]
+        lib.oracle_set_direct_llr_sum.restype = None
+        lib.oracle_set_direct_llr_sum.argtypes = [C.c_int]
         lib.oracle_last_updates.restype = C.c_uint64
         lib.oracle_last_read_pairs.restype = C.c_uint64
         _oracle = lib
@@ -115,6 +117,12 @@ def oracle_compute(p, num_cells, max_fragment_length, group_id_to_pos=None, muta
 def set_exact_binomials(on: bool) -> None:
     """See simmat_oracle.h: reference formula without the u64 binomial wrap (x_s + x_d > ~48)."""
     _load_oracle().oracle_set_exact_binomials(1 if on else 0)
+
+
+def set_direct_llr_sum(on: bool) -> None:
+    """See simmat_oracle.c: per-pair (logP_diff - logP_same) sums, i.e. without the reference's
+    final-subtraction cancellation (for inputs with ~1e5+ pairs per cell pair)."""
+    _load_oracle().oracle_set_direct_llr_sum(1 if on else 0)
 
 
 def oracle_last_updates() -> int:

@@ -303,6 +303,16 @@ typedef struct {
 } Acc;
 
 static _Thread_local uint64_t g_last_updates, g_last_pairs;
+
+/* The reference sums log P_same and log P_diff in two matrices and subtracts at the end (:428). With
+ * very many pairs per cell pair (hundreds of thousands) the two sums reach ~1e6 while their
+ * difference stays ~1e2, and the subtraction loses digits: the reference's
+ * own output is then only good to ~1e-8 relative. oracle_set_direct_llr_sum(1) adds
+ * (log P_diff - log P_same) per pair into mat_diff instead -- the same terms without the
+ * cancellation -- so that a test can tell the reference's rounding noise from a real discrepancy.
+ * Default 0 = the reference's arithmetic. Thread-local. */
+static _Thread_local int g_direct_llr_sum = 0;
+void oracle_set_direct_llr_sum(int on) { g_direct_llr_sum = on; }
 uint64_t oracle_last_updates(void) { return g_last_updates; }
 uint64_t oracle_last_read_pairs(void) { return g_last_pairs; }
 
@@ -346,6 +356,11 @@ static void compare_with_later_reads(Acc *a, const Live *lv, uint32_t first) {
         a->pairs += 1;
         const uint64_t ij = (uint64_t)index1 * a->n_cells + index2;
         const uint64_t ji = (uint64_t)index2 * a->n_cells + index1;
+        if (g_direct_llr_sum) {
+            a->mat_diff[ij] += memo_diff(a, x_s, x_d) - memo_same(a, x_s, x_d);
+            a->mat_diff[ji] = a->mat_diff[ij];
+            continue;
+        }
         a->mat_same[ij] += memo_same(a, x_s, x_d); /* :249 */
         a->mat_same[ji] = a->mat_same[ij];         /* :250 */
         a->mat_diff[ij] += memo_diff(a, x_s, x_d);

@@ -70,6 +70,10 @@ double oracle_log_prob_diff(uint32_t x_s, uint32_t x_d, double mutation_rate,
  * Thread-local. */
 void oracle_set_exact_binomials(int on);
 
+/* 0 (default): two sums + final subtraction as in the reference (similarity_matrix.cpp:428).
+ * 1: add (log P_diff - log P_same) per pair (no cancellation); see simmat_oracle.c. Thread-local. */
+void oracle_set_direct_llr_sum(int on);
+
 /* In-place normalisation of an n x n matrix (similarity_matrix.cpp:271-293). */
 int oracle_normalize(int normalization, double *mat, uint32_t n);
 

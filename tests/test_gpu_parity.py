@@ -223,3 +223,47 @@ def test_more_than_16383_cells_u32_ids():
     ref = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 8, "ADD_MIN")
     assert gu.normwise_err(got, ref) <= TOL
     assert np.array_equal(got, got.T)
+
+
+def test_very_deep_loci_unstaged_ranges():
+    """A locus with more entries in one cell block than the LDS staging buffer holds (4096) becomes a
+    single-locus range that the kernel pairs straight from HBM; deep (but stageable) loci next to it
+    take the one-lane-per-entry path of a batch. 12 cells, three loci with ~5000 reads each."""
+    rng = np.random.default_rng(81)
+    n = 12
+    rows, rid = [], 0
+    pos = 1000
+    for l in range(40):
+        pos += int(rng.integers(50, 400))
+        cov = 5000 if l in (7, 8, 21) else int(rng.integers(20, 200))
+        ents = []
+        for _ in range(cov):
+            ents.append((rid, int(rng.integers(0, n)), int(rng.integers(0, 4)) if rng.random() < 0.3 else l % 4))
+            rid += 1
+        rows.append((pos, ents))
+    # far loci so that everything above completes and is flushed
+    for k in range(6):
+        pos += 3000
+        rows.append((pos, [(rid + k, 0, 0)]))
+    p = from_rows([rows])
+    # ~5e5 pairs per cell pair: the reference's two sums reach ~1e6 and its final subtraction
+    # (similarity_matrix.cpp:428) loses digits, so against its own arithmetic only ~1e-8 can be
+    # asked; against the same terms summed without that cancellation the 1e-9 bar holds.
+    # (EXPONENTIATE is left out: exp(-D) at D ~ 600 turns that absolute noise into relative error.)
+    for norm in ("ADD_MIN", "SCALE_MAX_1"):
+        got = secedo_amd.compute_similarity_matrix(p, n, 1000, None, 0.01, 0.5, 0.01, 1, "", norm)
+        ref = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 1, norm)
+        assert gu.normwise_err(got, ref) <= 5e-8
+        ob.set_direct_llr_sum(True)
+        try:
+            ref2 = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 1, norm)
+        finally:
+            ob.set_direct_llr_sum(False)
+        assert gu.normwise_err(got, ref2) <= TOL
+    ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 1, "ADD_MIN")
+    u_ref, pairs_ref = ob.oracle_last_updates(), ob.oracle_last_read_pairs()
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        plan.prepare(p, n, 1000, None, 1)
+        acc = plan.new_acc()
+        plan.accumulate(acc, 0.01, 0.5, 0.01)
+        assert plan.last_counts() == (u_ref, pairs_ref)
