@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3"])
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--clustered", action="store_true", help="gap_max=300 variant (~2.8 loci/read)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--packed-resident", action="store_true",
@@ -209,6 +209,8 @@ def main():
                 "normalization": norm, "max_fragment_length": mfl, "num_threads": threads,
                 "parallelism": "tiles/%d + all-gather" % world if world > 1 else "single GPU"},
             "wall_s_full_matrix": elapsed / args.steps,
+            "dense_equivalent_cell_pair_locus_slots_per_s":
+                n_cells * (n_cells - 1) / 2 * n_loci * args.steps / elapsed,
             "step_includes_packing": not args.packed_resident,
             "packing": "device" if plan.used_device_packing else "host",
             "phase_ms": {"pack": phase["pack_ms"], "accumulate": kern_ms, "finalize": phase["finalize_ms"]},
@@ -220,6 +222,11 @@ def main():
                          "algorithmic_bytes": b_alg},
         }
         if not args.no_cpu_baseline:
+            # the drop-in call itself: host buffers in, host matrix out (create, H2D, pack, accumulate,
+            # normalise, D2H, destroy) -- PCIe-inclusive, never `value`
+            t0 = time.perf_counter()
+            secedo_amd.compute_similarity_matrix(p, n_cells, mfl, None, *rates, threads, "", norm)
+            line["one_shot_host_call_s"] = time.perf_counter() - t0
             line["cpu_baseline"] = cpu_baseline(p, n_cells, mfl, rates, threads, 2.5e8)
         print(json.dumps(line))
     if world > 1:

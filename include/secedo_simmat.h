@@ -158,6 +158,40 @@ double secedo_simmat_llr(uint32_t x_s, uint32_t x_d, double mutation_rate, doubl
                          double seq_error_rate);
 
 /* ------------------------------------------------------------------------------------------
+ * Locus filter, the step immediately upstream of the similarity matrix.
+ * Replaces Filter::filter / Filter::is_significant (reference: util/is_significant.hpp:68-72,
+ * util/is_significant.cpp:149-193 and :78-138; caller spectral_clustering.cpp:336-337).
+ * id_to_pos[g] == 16383 (NO_POS, util/is_significant.hpp:11) marks a group outside the current
+ * sub-cluster: its entries are dropped; a locus is kept iff the base counts of the remaining entries
+ * pass the reference's significance test for sequencing error rate `seq_error_rate` and split
+ * `cell_proportion` (0..4 = 10-90 .. 50-50, util/is_significant.hpp:30-40). Outputs use the flat
+ * layout of the input and are caller-allocated with the input's capacities (n_chr + 1, L, L + 1, E, E;
+ * out_id_base has the width of the given id_base array). avg_coverage = kept entries / kept loci.
+ * The counting, the test and the compaction run on the GPU; loci whose statistic lies within 1e-9 of
+ * its threshold are re-decided on the host with the C library (decisions equal the reference's).
+ * ---------------------------------------------------------------------------------------- */
+int secedo_is_significant(const uint16_t *base_count /* A, C, G, T */, double seq_error_rate,
+                          uint32_t cell_proportion);
+
+/* host buffers in, host buffers out: what a binding of Filter::filter calls */
+int secedo_filter(const uint32_t *chr_locus_off, uint32_t n_chr, const uint32_t *locus_pos,
+                  const uint64_t *locus_entry_off, const uint32_t *read_ids, const uint16_t *id_base16,
+                  const uint32_t *id_base32, const uint32_t *id_to_pos, uint32_t n_groups,
+                  double seq_error_rate, uint32_t cell_proportion, uint32_t *out_chr_locus_off,
+                  uint32_t *out_locus_pos, uint64_t *out_locus_entry_off, uint32_t *out_read_ids,
+                  void *out_id_base, uint64_t *out_n_loci, uint64_t *out_n_entries, double *avg_coverage);
+
+/* device buffers in, device buffers out (pileup stays in HBM across recursion levels; the outputs
+ * feed secedo_simmat_set_pileup_device). Synchronises `stream`. */
+int secedo_filter_device(const uint32_t *d_chr_locus_off, uint32_t n_chr, const uint32_t *d_locus_pos,
+                         const uint64_t *d_locus_entry_off, const uint32_t *d_read_ids,
+                         const uint16_t *d_id_base16, const uint32_t *d_id_base32, const uint32_t *d_id_to_pos,
+                         uint32_t n_groups, uint32_t n_loci, uint64_t n_entries, double seq_error_rate,
+                         uint32_t cell_proportion, uint32_t *d_out_chr_locus_off, uint32_t *d_out_locus_pos,
+                         uint64_t *d_out_locus_entry_off, uint32_t *d_out_read_ids, void *d_out_id_base,
+                         uint64_t *out_n_loci, uint64_t *out_n_entries, double *avg_coverage, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * SYNTH-v1 synthetic pileup generator: bench and test utility, host only.
  * Call with all output pointers NULL to obtain the sizes, then again with buffers.
  * ---------------------------------------------------------------------------------------- */

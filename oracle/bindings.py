@@ -52,6 +52,17 @@ def _load_oracle():
         lib.oracle_set_exact_binomials.argtypes = [C.c_int]
         lib.oracle_set_direct_llr_sum.restype = None
         lib.oracle_set_direct_llr_sum.argtypes = [C.c_int]
+        lib.oracle_is_significant.restype = C.c_int
+        lib.oracle_is_significant.argtypes = [np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS"),
+                                              C.c_double, C.c_uint32]
+        lib.oracle_significance_terms.restype = None
+        lib.oracle_significance_terms.argtypes = [
+            np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS"), C.c_double, C.c_uint32,
+            C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        lib.oracle_filter.restype = C.c_int
+        lib.oracle_filter.argtypes = [_u32p, C.c_uint32, _u32p, _u64p, _u32p, _u32p, _u32p, C.c_uint32,
+                                      C.c_double, C.c_uint32, _u32p, _u32p, _u64p, _u32p, _u32p,
+                                      C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         lib.oracle_last_updates.restype = C.c_uint64
         lib.oracle_last_read_pairs.restype = C.c_uint64
         _oracle = lib
@@ -78,6 +89,13 @@ def _load_ref():
             C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint64),
             C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
         ]
+        lib.ref_is_significant.restype = C.c_int
+        lib.ref_is_significant.argtypes = [np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS"),
+                                           C.c_double, C.c_uint32]
+        lib.ref_filter.restype = C.c_int
+        lib.ref_filter.argtypes = [_u32p, C.c_uint32, _u32p, _u64p, _u32p, _u32p, _u32p, C.c_uint32,
+                                   C.c_double, C.c_uint32, C.c_uint32, _u32p, _u32p, _u64p, _u32p, _u32p,
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         lib.ref_read_pileup_fetch.restype = None
         lib.ref_read_pileup_fetch.argtypes = [_u32p, _u64p, _u32p, _u32p]
         _ref = lib
@@ -185,3 +203,51 @@ def ref_read_pileup(fname, merge_count=1, merge_file="", max_coverage=100):
     idb = np.zeros(ne.value, dtype=np.uint32)
     lib.ref_read_pileup_fetch(pos, off, rid, idb)
     return pos, off, rid, idb, nc.value, ml.value
+
+
+NO_POS = 16383  # util/is_significant.hpp:11
+
+
+def _counts(base_count):
+    return np.ascontiguousarray(base_count, dtype=np.uint16)
+
+
+def oracle_is_significant(base_count, theta, cell_proportion=4) -> bool:
+    return bool(_load_oracle().oracle_is_significant(_counts(base_count), theta, cell_proportion))
+
+
+def oracle_significance_terms(base_count, theta, cell_proportion=4):
+    s, k = C.c_double(), C.c_double()
+    _load_oracle().oracle_significance_terms(_counts(base_count), theta, cell_proportion, C.byref(s), C.byref(k))
+    return s.value, k.value
+
+
+def ref_is_significant(base_count, theta, cell_proportion=4) -> bool:
+    return bool(_load_ref().ref_is_significant(_counts(base_count), theta, cell_proportion))
+
+
+def _run_filter(fn, p, id_to_pos, theta, cell_proportion, extra=()):
+    i2p = np.ascontiguousarray(id_to_pos, dtype=np.uint32)
+    L, E = len(p.locus_pos), len(p.read_ids)
+    o_chr = np.zeros(len(p.chr_locus_off), dtype=np.uint32)
+    o_pos = np.zeros(max(L, 1), dtype=np.uint32)
+    o_off = np.zeros(L + 1, dtype=np.uint64)
+    o_rid = np.zeros(max(E, 1), dtype=np.uint32)
+    o_idb = np.zeros(max(E, 1), dtype=np.uint32)
+    nl, ne, cov = C.c_uint64(), C.c_uint64(), C.c_double()
+    rc = fn(p.chr_locus_off, len(p.chr_locus_off) - 1, p.locus_pos, p.locus_entry_off, p.read_ids, p.id_base,
+            i2p, len(i2p), theta, cell_proportion, *extra, o_chr, o_pos, o_off, o_rid, o_idb, C.byref(nl),
+            C.byref(ne), C.byref(cov))
+    if rc != 0:
+        raise RuntimeError("filter failed: %d" % rc)
+    return (o_chr, o_pos[:nl.value].copy(), o_off[:nl.value + 1].copy(), o_rid[:ne.value].copy(),
+            o_idb[:ne.value].copy(), cov.value)
+
+
+def oracle_filter(p, id_to_pos, theta, cell_proportion=4):
+    """-> (chr_locus_off, locus_pos, locus_entry_off, read_ids, id_base, avg_coverage)"""
+    return _run_filter(_load_oracle().oracle_filter, p, id_to_pos, theta, cell_proportion)
+
+
+def ref_filter(p, id_to_pos, theta, cell_proportion=4, num_threads=2):
+    return _run_filter(_load_ref().ref_filter, p, id_to_pos, theta, cell_proportion, extra=(num_threads,))

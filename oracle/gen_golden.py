@@ -210,13 +210,56 @@ def random_cases():
          + [case(12, 1000, 3, "ADD_MIN", theta=0.001)])
 
 
+def filter_cases():
+    """Locus filter (Filter::filter / is_significant) vectors from the compiled reference."""
+    rng = np.random.default_rng(7)
+    # (a) the known-answer strings of the reference's tests/test_is_significant.cpp:46-90 as base counts,
+    #     plus random counts, all decided by the reference
+    kat_counts = [[0, 51, 0, 1], [3, 44, 2, 3], [2, 0, 0, 57], [2, 39, 0, 0], [1, 0, 3, 0]]
+    kat_theta = [0.01, 0.01, 0.01, 0.001, 0.001]
+    counts, thetas, props, verdicts = [], [], [], []
+    for c, th in zip(kat_counts, kat_theta):
+        counts.append(c); thetas.append(th); props.append(4)
+        verdicts.append(ob.ref_is_significant(c, th, 4))
+    for t in range(3000):
+        cov = int(rng.integers(2, 260))
+        major = int(cov * rng.uniform(0.5, 1.0)); rest = cov - major
+        a = int(rng.integers(0, rest + 1)); b = int(rng.integers(0, rest - a + 1))
+        c = np.array([major, a, b, rest - a - b]); rng.shuffle(c)
+        th = [0.01, 0.001, 0.05][t % 3]; cp = t % 5
+        counts.append(c.tolist()); thetas.append(th); props.append(cp)
+        verdicts.append(ob.ref_is_significant(c, th, cp))
+    np.savez_compressed(os.path.join(GOLDEN, "filter_kat.npz"), counts=np.asarray(counts, dtype=np.uint16),
+                        theta=np.asarray(thetas), cell_proportion=np.asarray(props, dtype=np.uint32),
+                        significant=np.asarray(verdicts, dtype=np.uint8), n_reference_kats=len(kat_counts))
+    print("filter_kat: %d decisions, %d significant" % (len(verdicts), int(np.sum(verdicts))))
+    # (b) whole-pileup filtering with sub-cluster restriction
+    for name, seed, n, nchr, L, cov, err, theta, cp, frac_out in [
+            ("filter_60cells", 201, 60, 3, 300, 25, 0.15, 0.01, 4, 0.3),
+            ("filter_200cells_all_in", 202, 200, 2, 250, 60, 0.10, 0.001, 2, 0.0),
+            ("filter_40cells_deep", 203, 40, 1, 120, 150, 0.2, 0.05, 0, 0.5)]:
+        p = random_pileup(seed, n, nchr, L, cov, 400, err=err)
+        i2p = np.arange(n, dtype=np.uint32)
+        drop = rng.random(n) < frac_out
+        i2p[drop] = ob.NO_POS
+        i2p[~drop] = np.arange(int((~drop).sum()), dtype=np.uint32)
+        o_chr, o_pos, o_off, o_rid, o_idb, cov_avg = ob.ref_filter(p, i2p, theta, cp)
+        np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), chr_locus_off=p.chr_locus_off,
+                            locus_pos=p.locus_pos, locus_entry_off=p.locus_entry_off, read_ids=p.read_ids,
+                            id_base=p.id_base, id_to_pos=i2p, theta=theta, cell_proportion=cp,
+                            out_chr_locus_off=o_chr, out_locus_pos=o_pos, out_locus_entry_off=o_off,
+                            out_read_ids=o_rid, out_id_base=o_idb, avg_coverage=cov_avg)
+        print("%-26s loci %5d -> %5d entries %6d -> %6d avg cov %.3f" % (
+            name, p.n_loci, len(o_pos), p.n_entries, len(o_rid), cov_avg))
+
+
 def main():
     only = set(sys.argv[1:])
     if not ob.have_ref():
         sys.exit("oracle/_ref/libsecedo_ref.so missing: run `make -C oracle ref` in the container")
     os.makedirs(GOLDEN, exist_ok=True)
     for fn in (semantic_probes, kat_llr_table, reference_pileup_files, divide_clusters_shaped,
-               random_cases):
+               random_cases, filter_cases):
         if not only or fn.__name__ in only:
             fn()
 

@@ -10,8 +10,10 @@
  * The flat layout is the one of oracle/simmat_oracle.h.
  */
 #include "similarity_matrix.hpp"      // reference: computeSimilarityMatrix
+#include "util/is_significant.hpp"    // reference: Filter
 #include "util/pileup_reader.hpp"     // reference: read_pileup, get_grouping
 
+#include <array>
 #include <cstdint>
 #include <cstring>
 #include <iostream>
@@ -123,6 +125,62 @@ void ref_read_pileup_fetch(uint32_t *locus_pos, uint64_t *locus_entry_off, uint3
     }
     locus_entry_off[l] = e;
     g_read_result.clear();
+}
+
+// Filter::is_significant on base counts (util/is_significant.cpp:78-138).
+int ref_is_significant(const uint16_t *base_count, double theta, uint32_t cell_proportion) {
+    Filter filter(theta, static_cast<uint8_t>(cell_proportion));
+    std::array<uint16_t, 4> counts = { base_count[0], base_count[1], base_count[2], base_count[3] };
+    return filter.is_significant(counts) ? 1 : 0;
+}
+
+// Filter::filter (util/is_significant.cpp:149-193) on the flat layout; outputs caller-allocated with
+// the input's capacities. ids must fit the reference's 14 bits.
+int ref_filter(const uint32_t *chr_locus_off, uint32_t n_chr, const uint32_t *locus_pos,
+               const uint64_t *locus_entry_off, const uint32_t *read_ids, const uint32_t *id_base,
+               const uint32_t *id_to_pos, uint32_t n_groups, double theta, uint32_t cell_proportion,
+               uint32_t num_threads, uint32_t *out_chr_locus_off, uint32_t *out_locus_pos,
+               uint64_t *out_locus_entry_off, uint32_t *out_read_ids, uint32_t *out_id_base,
+               uint64_t *out_n_loci, uint64_t *out_n_entries, double *avg_coverage) {
+    std::vector<std::vector<PosData>> pos_data(n_chr);
+    for (uint32_t c = 0; c < n_chr; ++c) {
+        for (uint32_t l = chr_locus_off[c]; l < chr_locus_off[c + 1]; ++l) {
+            const uint64_t b = locus_entry_off[l], e = locus_entry_off[l + 1];
+            std::vector<uint32_t> ids(read_ids + b, read_ids + e);
+            std::vector<uint16_t> packed(e - b);
+            for (uint64_t i = b; i < e; ++i) {
+                if (id_base[i] > 0xFFFFu) return -3;
+                packed[i - b] = static_cast<uint16_t>(id_base[i]);
+            }
+            pos_data[c].emplace_back(locus_pos[l], std::move(ids), std::move(packed));
+        }
+    }
+    std::vector<uint32_t> i2p(id_to_pos, id_to_pos + n_groups);
+    try {
+        Filter filter(theta, static_cast<uint8_t>(cell_proportion));
+        auto [result, cov] = filter.filter(pos_data, i2p, "", num_threads);
+        uint64_t nl = 0, ne = 0;
+        out_chr_locus_off[0] = 0;
+        out_locus_entry_off[0] = 0;
+        for (uint32_t c = 0; c < n_chr; ++c) {
+            for (const PosData &pd : result[c]) {
+                out_locus_pos[nl] = pd.position;
+                for (uint32_t i = 0; i < pd.size(); ++i, ++ne) {
+                    out_read_ids[ne] = pd.read_ids[i];
+                    out_id_base[ne] = pd.group_ids_bases[i];
+                }
+                ++nl;
+                out_locus_entry_off[nl] = ne;
+            }
+            out_chr_locus_off[c + 1] = static_cast<uint32_t>(nl);
+        }
+        *out_n_loci = nl;
+        *out_n_entries = ne;
+        *avg_coverage = cov;
+    } catch (...) {
+        return -4;
+    }
+    return 0;
 }
 
 } // extern "C"

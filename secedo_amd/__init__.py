@@ -6,3 +6,4 @@ host-side mirror of the reference interface (similarity_matrix.py).
 from .pileup import FlatPileup, PosData, flatten  # noqa: F401
 from .similarity_matrix import (InvalidNormalization, NORMALIZATIONS, SecedoError,  # noqa: F401
                                 SimilarityMatrixPlan, compute_similarity_matrix, llr, to_enum)
+from .filter import Filter, NO_POS, filter_resident  # noqa: F401,E402

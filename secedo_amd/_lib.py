@@ -70,6 +70,12 @@ SIGNATURES = {
     "secedo_simmat_last_counts": (C.c_int, [_vp, _u64p, _u64p]),
     "secedo_simmat_last_accumulate_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "secedo_simmat_llr": (C.c_double, [C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double]),
+    "secedo_is_significant": (C.c_int, [_vp, C.c_double, C.c_uint32]),
+    "secedo_filter": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_double,
+                                C.c_uint32, _vp, _vp, _vp, _vp, _vp, _u64p, _u64p, _f64p]),
+    "secedo_filter_device": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32,
+                                       C.c_uint64, C.c_double, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _u64p,
+                                       _u64p, _f64p, _vp]),
     "secedo_synth_generate": (C.c_int, [C.POINTER(SynthSpec), _u64p, _u64p, _vp, _vp, _vp, _vp, _vp]),
 }
 

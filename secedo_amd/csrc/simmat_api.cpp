@@ -5,6 +5,8 @@
 // device is usable the entry points fail with SECEDO_E_NO_DEVICE.
 #include "secedo_simmat.h"
 
+#include "filter_device.hpp"
+#include "filter_host.hpp"
 #include "llr_table.hpp"
 #include "pack_device.hpp"
 #include "pack_host.hpp"
@@ -606,6 +608,96 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
     rc = secedo_simmat_finalize(h, normalization, h->own_acc.as<int64_t>(), h->own_out.as<double>(), nullptr);
     if (rc != SECEDO_OK) return rc;
     HIP_TRY(hipMemcpy(out, h->own_out.p, out_bytes, hipMemcpyDeviceToHost));
+    return SECEDO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Locus filter (reference util/is_significant.cpp)
+// ------------------------------------------------------------------------------------------------
+
+int secedo_is_significant(const uint16_t *base_count, double seq_error_rate, uint32_t cell_proportion) {
+    if (!base_count) return fail(SECEDO_E_INVALID_ARG, "base_count is null");
+    if (cell_proportion > 4) return fail(SECEDO_E_INVALID_ARG, "cell_proportion must be in [0, 4]");
+    return secedo::is_significant(base_count, seq_error_rate, cell_proportion);
+}
+
+int secedo_filter_device(const uint32_t *d_chr_locus_off, uint32_t n_chr, const uint32_t *d_locus_pos,
+                         const uint64_t *d_locus_entry_off, const uint32_t *d_read_ids,
+                         const uint16_t *d_id_base16, const uint32_t *d_id_base32, const uint32_t *d_id_to_pos,
+                         uint32_t n_groups, uint32_t n_loci, uint64_t n_entries, double seq_error_rate,
+                         uint32_t cell_proportion, uint32_t *d_out_chr_locus_off, uint32_t *d_out_locus_pos,
+                         uint64_t *d_out_locus_entry_off, uint32_t *d_out_read_ids, void *d_out_id_base,
+                         uint64_t *out_n_loci, uint64_t *out_n_entries, double *avg_coverage, void *stream) {
+    if (!d_chr_locus_off || !d_locus_entry_off || !d_out_chr_locus_off || !d_out_locus_entry_off || !out_n_loci
+        || !out_n_entries || !avg_coverage)
+        return fail(SECEDO_E_INVALID_ARG, "null argument");
+    if (secedo_simmat_device_count() <= 0)
+        return fail(SECEDO_E_NO_DEVICE, "no HIP device is visible: the locus filter has no CPU fallback");
+    secedo::DeviceFlatPileup in;
+    in.chr_locus_off = d_chr_locus_off;
+    in.n_chr = n_chr;
+    in.locus_pos = d_locus_pos;
+    in.locus_entry_off = d_locus_entry_off;
+    in.read_ids = d_read_ids;
+    in.id_base16 = d_id_base16;
+    in.id_base32 = d_id_base32;
+    in.group_id_to_pos = d_id_to_pos;
+    in.n_groups = n_groups;
+    in.n_loci = n_loci;
+    in.n_entries = n_entries;
+    secedo::FilterOut out{d_out_chr_locus_off, d_out_locus_pos, d_out_locus_entry_off, d_out_read_ids, d_out_id_base};
+    static thread_local secedo::FilterWorkspace ws;
+    const std::string err = secedo::filter_device(in, seq_error_rate, cell_proportion,
+                                                  static_cast<hipStream_t>(stream), &ws, out, out_n_loci,
+                                                  out_n_entries, avg_coverage);
+    if (!err.empty()) return fail(err.find("hip") == 0 ? SECEDO_E_HIP : SECEDO_E_INVALID_ARG, err);
+    return SECEDO_OK;
+}
+
+int secedo_filter(const uint32_t *chr_locus_off, uint32_t n_chr, const uint32_t *locus_pos,
+                  const uint64_t *locus_entry_off, const uint32_t *read_ids, const uint16_t *id_base16,
+                  const uint32_t *id_base32, const uint32_t *id_to_pos, uint32_t n_groups,
+                  double seq_error_rate, uint32_t cell_proportion, uint32_t *out_chr_locus_off,
+                  uint32_t *out_locus_pos, uint64_t *out_locus_entry_off, uint32_t *out_read_ids,
+                  void *out_id_base, uint64_t *out_n_loci, uint64_t *out_n_entries, double *avg_coverage) {
+    if (!chr_locus_off || !locus_entry_off) return fail(SECEDO_E_INVALID_ARG, "null offset arrays");
+    if ((id_base16 != nullptr) == (id_base32 != nullptr))
+        return fail(SECEDO_E_INVALID_ARG, "exactly one of id_base16 / id_base32 must be given");
+    if (secedo_simmat_device_count() <= 0)
+        return fail(SECEDO_E_NO_DEVICE, "no HIP device is visible: the locus filter has no CPU fallback");
+    int device = 0;
+    if (const char *env = std::getenv("SECEDO_DEVICE")) device = std::atoi(env);
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t L = chr_locus_off[n_chr];
+    const uint64_t E = locus_entry_off[L];
+    const size_t idw = id_base16 ? 2 : 4;
+    DevBuf d_chr, d_pos, d_off, d_rid, d_idb, d_i2p, o_chr, o_pos, o_off, o_rid, o_idb;
+    HIP_TRY(buf_upload(d_chr, chr_locus_off, (size_t)n_chr + 1));
+    HIP_TRY(buf_upload(d_pos, locus_pos, L));
+    HIP_TRY(buf_upload(d_off, locus_entry_off, (size_t)L + 1));
+    HIP_TRY(buf_upload(d_rid, read_ids, E));
+    if (id_base16) HIP_TRY(buf_upload(d_idb, id_base16, E));
+    else HIP_TRY(buf_upload(d_idb, id_base32, E));
+    HIP_TRY(buf_upload(d_i2p, id_to_pos, n_groups));
+    HIP_TRY(o_chr.ensure(((size_t)n_chr + 1) * 4));
+    HIP_TRY(o_pos.ensure((size_t)L * 4));
+    HIP_TRY(o_off.ensure(((size_t)L + 1) * 8));
+    HIP_TRY(o_rid.ensure(E * 4));
+    HIP_TRY(o_idb.ensure(E * idw));
+    const int rc = secedo_filter_device(
+            d_chr.as<uint32_t>(), n_chr, d_pos.as<uint32_t>(), d_off.as<uint64_t>(), d_rid.as<uint32_t>(),
+            id_base16 ? d_idb.as<uint16_t>() : nullptr, id_base16 ? nullptr : d_idb.as<uint32_t>(),
+            d_i2p.as<uint32_t>(), n_groups, L, E, seq_error_rate, cell_proportion, o_chr.as<uint32_t>(),
+            o_pos.as<uint32_t>(), o_off.as<uint64_t>(), o_rid.as<uint32_t>(), o_idb.p, out_n_loci, out_n_entries,
+            avg_coverage, nullptr);
+    if (rc != SECEDO_OK) return rc;
+    HIP_TRY(hipMemcpy(out_chr_locus_off, o_chr.p, ((size_t)n_chr + 1) * 4, hipMemcpyDeviceToHost));
+    if (*out_n_loci) HIP_TRY(hipMemcpy(out_locus_pos, o_pos.p, *out_n_loci * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_locus_entry_off, o_off.p, (*out_n_loci + 1) * 8, hipMemcpyDeviceToHost));
+    if (*out_n_entries) {
+        HIP_TRY(hipMemcpy(out_read_ids, o_rid.p, *out_n_entries * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_id_base, o_idb.p, *out_n_entries * idw, hipMemcpyDeviceToHost));
+    }
     return SECEDO_OK;
 }
 

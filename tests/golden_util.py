@@ -12,7 +12,20 @@ NORMS = ("ADD_MIN", "EXPONENTIATE", "SCALE_MAX_1")
 
 def fixture_names():
     return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz"))
-                  if not os.path.basename(f).startswith("kat_"))
+                  if not os.path.basename(f).startswith(("kat_", "filter_")))
+
+
+def filter_fixture_names():
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "filter_*.npz"))
+                  if not os.path.basename(f).startswith("filter_kat"))
+
+
+def load_filter(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    p = FlatPileup(z["chr_locus_off"], z["locus_pos"], z["locus_entry_off"], z["read_ids"], z["id_base"])
+    expect = (z["out_chr_locus_off"], z["out_locus_pos"], z["out_locus_entry_off"], z["out_read_ids"],
+              z["out_id_base"], float(z["avg_coverage"]))
+    return p, z["id_to_pos"], float(z["theta"]), int(z["cell_proportion"]), expect
 
 
 def load(name):
