@@ -487,7 +487,7 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
         }
         const uint64_t slots = static_cast<uint64_t>(wgs_per_round) * rounds;
         std::vector<uint32_t> wg_begin(n_tiles + 1, 0);
-        std::vector<uint16_t> wg_tile;
+        std::vector<uint32_t> wg_tile;
         for (uint32_t t = 0; t < n_tiles; ++t) {
             uint64_t c = total_weight ? (weight[t] * slots + total_weight / 2) / total_weight : 1;
             c = std::max<uint64_t>(1, std::min<uint64_t>(c, h->pk.num_ranges ? h->pk.num_ranges : 1));
@@ -496,9 +496,8 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
             if (per) c = (h->pk.num_ranges + per - 1) / per;
             if (c == 0) c = 1;
             wg_begin[t + 1] = wg_begin[t] + static_cast<uint32_t>(c);
-            for (uint64_t k = 0; k < c; ++k) wg_tile.push_back(static_cast<uint16_t>(t));
+            for (uint64_t k = 0; k < c; ++k) wg_tile.push_back(t);
         }
-        if (n_tiles > 65535) return fail(SECEDO_E_LIMIT, "more than 65535 tiles in one accumulate call: split the tile range");
         HIP_TRY(h->plan_wg_tile.upload(wg_tile));
         HIP_TRY(h->plan_wg_begin.upload(wg_begin));
         h->plan_workgroups = wg_begin[n_tiles];
@@ -509,7 +508,7 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     }
     a.n_tiles = n_tiles;
     a.n_workgroups = h->plan_workgroups;
-    a.wg_tile = h->plan_wg_tile.as<uint16_t>();
+    a.wg_tile = h->plan_wg_tile.as<uint32_t>();
     a.tile_wg_begin = h->plan_wg_begin.as<uint32_t>();
     a.debug = 0;
     if (const char *env = std::getenv("SECEDO_DEBUG_ABLATE")) a.debug = static_cast<uint32_t>(std::atoi(env));

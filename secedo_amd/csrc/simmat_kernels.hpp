@@ -53,7 +53,7 @@ struct AccumulateArgs {
     uint32_t tile_begin;       // first tile of this launch
     uint32_t n_tiles;          // tiles of this launch
     uint32_t n_workgroups;     // = tile_wg_begin[n_tiles]
-    const uint16_t *wg_tile;   // workgroup -> tile (relative to tile_begin)
+    const uint32_t *wg_tile;   // workgroup -> tile (relative to tile_begin)
     const uint32_t *tile_wg_begin;  // n_tiles + 1: first workgroup of each tile (its chunks follow)
     uint32_t debug;            // ablation switches for profiling (0 in production)
     // log-likelihood ratios, fixed point
