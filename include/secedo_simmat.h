@@ -192,6 +192,30 @@ int secedo_filter_device(const uint32_t *d_chr_locus_off, uint32_t n_chr, const 
                          uint64_t *out_n_loci, uint64_t *out_n_entries, double *avg_coverage, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Pileup files -> flat layout. Replaces read_pileup (reference:
+ * util/pileup_reader.hpp:33-39, util/pileup_reader.cpp:12-257) for one file = one chromosome: a path
+ * ending in ".bin" is the reference's binary format (u32 position, u16 coverage, u32 read_ids[],
+ * u16 cell<<2|base [] per locus), anything else its 6-column text format. Host only.
+ * id_to_group maps cell ids to groups (get_grouping, util/pileup_reader.cpp:273-291); loci with more
+ * than max_coverage entries are skipped; a non-empty sorted `positions` list restricts the loci;
+ * write_bin != 0 makes the text reader also write `path + ".bin"` as the reference always does.
+ * Call with the four arrays NULL to get the sizes in *info, then again with buffers
+ * (n_loci, n_loci + 1, n_entries, n_entries). Errors: SECEDO_E_INVALID_ARG + secedo_pileup_last_error().
+ * ---------------------------------------------------------------------------------------- */
+typedef struct secedo_pileup_info {
+    uint64_t n_loci;
+    uint64_t n_entries;
+    uint32_t num_cells;        /* distinct cell ids (text) resp. largest cell id + 1 (binary) */
+    uint32_t max_read_length;  /* longest (last - first) position of one read id; 1000 if not computed */
+} secedo_pileup_info;
+
+int secedo_pileup_read(const char *path, const uint16_t *id_to_group, uint32_t n_ids, uint32_t max_coverage,
+                       const uint32_t *positions, uint64_t n_positions, int compute_max_read_len,
+                       int write_bin, secedo_pileup_info *info, uint32_t *locus_pos,
+                       uint64_t *locus_entry_off, uint32_t *read_ids, uint16_t *id_base16);
+const char *secedo_pileup_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
  * SYNTH-v1 synthetic pileup generator: bench and test utility, host only.
  * Call with all output pointers NULL to obtain the sizes, then again with buffers.
  * ---------------------------------------------------------------------------------------- */

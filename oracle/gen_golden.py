@@ -253,13 +253,45 @@ def filter_cases():
             name, p.n_loci, len(o_pos), p.n_entries, len(o_rid), cov_avg))
 
 
+def reader_cases():
+    """Pileup reader vectors: the reference reader (util/pileup_reader.cpp) on the reference's own
+    tests/data/*.pileup files (text), and on the .bin files it writes next to them (binary; stored
+    too, they are the binary-format fixtures)."""
+    data = os.path.join(GOLDEN, "data")
+    with tempfile.TemporaryDirectory() as tmp:
+        for f in os.listdir(data):
+            if not f.endswith(".bin"):
+                shutil.copy(os.path.join(data, f), tmp)
+        out = {}
+        # (the text reader rewrites name.pileup.bin with the loci it kept: the max_coverage 60 case goes
+        # first so that the stored .bin fixtures are the complete ones)
+        combos = [("ten_rows", 1, "", 60), ("ten_rows", 1, "", 100), ("six_cells", 2, "", 100),
+                  ("six_cells", 1, "six_cells.pileup.group", 100), ("three_rows", 1, "", 100),
+                  ("one_row", 1, "", 100)]
+        for name, mc, mf, maxcov in combos:
+            mfp = os.path.join(tmp, mf) if mf else ""
+            for ext in ("", ".bin"):
+                path = os.path.join(tmp, name + ".pileup" + ext)
+                pos, off, rid, idb, ncell, mlen = ob.ref_read_pileup(path, mc, mfp, maxcov)
+                key = "%s|%d|%s|%d|%s" % (name, mc, mf, maxcov, "bin" if ext else "text")
+                out[key + "|pos"] = pos
+                out[key + "|off"] = off
+                out[key + "|rid"] = rid
+                out[key + "|idb"] = idb
+                out[key + "|meta"] = np.asarray([ncell, mlen], dtype=np.uint32)
+        for name in ("ten_rows", "six_cells", "three_rows", "one_row"):
+            shutil.copy(os.path.join(tmp, name + ".pileup.bin"), os.path.join(data, name + ".pileup.bin"))
+    np.savez_compressed(os.path.join(GOLDEN, "reader_vectors.npz"), **out)
+    print("reader_vectors: %d arrays" % len(out))
+
+
 def main():
     only = set(sys.argv[1:])
     if not ob.have_ref():
         sys.exit("oracle/_ref/libsecedo_ref.so missing: run `make -C oracle ref` in the container")
     os.makedirs(GOLDEN, exist_ok=True)
     for fn in (semantic_probes, kat_llr_table, reference_pileup_files, divide_clusters_shaped,
-               random_cases, filter_cases):
+               random_cases, filter_cases, reader_cases):
         if not only or fn.__name__ in only:
             fn()
 

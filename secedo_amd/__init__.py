@@ -7,3 +7,4 @@ from .pileup import FlatPileup, PosData, flatten  # noqa: F401
 from .similarity_matrix import (InvalidNormalization, NORMALIZATIONS, SecedoError,  # noqa: F401
                                 SimilarityMatrixPlan, compute_similarity_matrix, llr, to_enum)
 from .filter import Filter, NO_POS, filter_resident  # noqa: F401,E402
+from .pileup_reader import get_grouping, read_pileup  # noqa: F401,E402

@@ -29,6 +29,11 @@ _f64p = C.POINTER(C.c_double)
 _vp = C.c_void_p
 
 
+class PileupInfo(C.Structure):
+    _fields_ = [("n_loci", C.c_uint64), ("n_entries", C.c_uint64), ("num_cells", C.c_uint32),
+                ("max_read_length", C.c_uint32)]
+
+
 class SynthSpec(C.Structure):
     _fields_ = [
         ("num_cells", C.c_uint32), ("num_loci", C.c_uint32), ("num_chromosomes", C.c_uint32),
@@ -76,6 +81,9 @@ SIGNATURES = {
     "secedo_filter_device": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32,
                                        C.c_uint64, C.c_double, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _u64p,
                                        _u64p, _f64p, _vp]),
+    "secedo_pileup_read": (C.c_int, [C.c_char_p, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint64, C.c_int, C.c_int,
+                                     C.POINTER(PileupInfo), _vp, _vp, _vp, _vp]),
+    "secedo_pileup_last_error": (C.c_char_p, []),
     "secedo_synth_generate": (C.c_int, [C.POINTER(SynthSpec), _u64p, _u64p, _vp, _vp, _vp, _vp, _vp]),
 }
 
