@@ -270,7 +270,9 @@ def reader_cases():
                   ("one_row", 1, "", 100)]
         for name, mc, mf, maxcov in combos:
             mfp = os.path.join(tmp, mf) if mf else ""
-            for ext in ("", ".bin"):
+            # the .bin the text reader just wrote holds only the loci it kept (renumbered read ids), so
+            # the binary variant is recorded for the complete files only
+            for ext in (("", ".bin") if maxcov == 100 else ("",)):
                 path = os.path.join(tmp, name + ".pileup" + ext)
                 pos, off, rid, idb, ncell, mlen = ob.ref_read_pileup(path, mc, mfp, maxcov)
                 key = "%s|%d|%s|%d|%s" % (name, mc, mf, maxcov, "bin" if ext else "text")
