@@ -26,7 +26,8 @@ def sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate
     """Accumulate this rank's tiles into `acc` and all-gather the other ranks' tiles.
 
     `acc` must come from plan.new_acc(pad_tiles_to=world): every rank then owns an equally sized
-    slice and the all-gather is in place (each rank's input is its own slice of the output).
+    slice. The rank's slice is copied to a send buffer first: the collective's input and output do not
+    alias (1/world of the accumulator, negligible next to the gather itself).
     """
     import torch.distributed as dist
 
@@ -38,5 +39,11 @@ def sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate
     mine.zero_()
     plan.accumulate(acc, mutation_rate, homozygous_rate, seq_error_rate, lo, hi)
     if world > 1:
-        dist.all_gather_into_tensor(acc, mine, group=group)
+        if acc.is_cuda and dist.get_backend(group) != "nccl":
+            # rehearsal backends (gloo) move host memory: stage the slices through the CPU
+            gathered = acc.new_empty(acc.shape, device="cpu")
+            dist.all_gather_into_tensor(gathered, mine.cpu(), group=group)
+            acc.copy_(gathered)
+        else:
+            dist.all_gather_into_tensor(acc, mine.clone(), group=group)
     return acc
