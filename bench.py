@@ -74,6 +74,10 @@ def main():
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--clustered", action="store_true", help="gap_max=300 variant (~2.8 loci/read)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 "
+                         "flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--packed-resident", action="store_true",
                     help="keep the PACKED pileup resident and leave the packing out of the step "
                          "(steady state of repeated accumulations; default: the step starts from the raw "
@@ -90,11 +94,14 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     n_cells, n_loci, n_chr, gap, prob = CONFIGS[args.workload]
     mfl, threads, rates, norm = 1000, 8, (0.01, 0.5, 0.01), "ADD_MIN"
@@ -135,8 +142,9 @@ def main():
     # around the last launch of the timed region, plus torch events over a few more launches below
     last_ms = plan.last_accumulate_ms()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    cnt = torch.tensor([local_updates, local_pairs], dtype=torch.int64, device="cuda")
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    cnt = torch.tensor([local_updates, local_pairs], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
