@@ -655,8 +655,7 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
     {
         const uint32_t n_seg = (L + pk.cap_loci - 1) / pk.cap_loci;
-        // segment scratch: ends[n_seg * cap_loci] | count[n_seg]  (VAL_B? no: sval lives there) -> WORK_A is
-        // `keep`, still needed by nothing after k_keys2; use ELOC (entry_locus is dead after k_csr)
+        // segment scratch: ends[n_seg * cap_loci] | count[n_seg], in ELOC (entry_locus is dead after k_csr)
         HIP_OK(S[ELOC].ensure(std::max<size_t>((size_t)E * 4, ((size_t)n_seg * pk.cap_loci + n_seg + 2) * 4)));
         uint32_t *seg_ends = S[ELOC].as<uint32_t>();
         uint32_t *seg_count = seg_ends + (size_t)n_seg * pk.cap_loci;
