@@ -267,3 +267,56 @@ def test_very_deep_loci_unstaged_ranges():
         acc = plan.new_acc()
         plan.accumulate(acc, 0.01, 0.5, 0.01)
         assert plan.last_counts() == (u_ref, pairs_ref)
+
+
+def test_randomised_differential_sweep():
+    """Thirty random configurations (cells, chromosomes, coverage, locus spacing, fragment lengths,
+    max_fragment_length below and above the fragment spans, num_threads, duplicates, inserts, group maps
+    with shared rows, tile size, packing path) against the oracle: matrix and both work counters."""
+    rng = np.random.default_rng(2024)
+    for it in range(30):
+        n = int(rng.choice([3, 17, 64, 65, 130, 200, 333]))
+        nchr = int(rng.integers(1, 5))
+        L = int(rng.integers(40, 400))
+        cov = int(rng.integers(3, 40))
+        gap = int(rng.choice([6, 40, 300, 3000]))
+        fmax = int(rng.choice([120, 400, 600]))
+        mfl = int(rng.choice([90, 250, 1000]))
+        T = int(rng.choice([1, 2, 5, 8]))
+        n_groups = n + int(rng.integers(0, 6))
+        g2p = rng.integers(0, n, size=n_groups).astype(np.uint32)
+        p = random_pileup(7000 + it, n, nchr, L, cov, gap, frag_min=30, frag_max=fmax,
+                          dup_frac=float(rng.choice([0.0, 0.05])), triple_frac=0.3,
+                          skip_frac=float(rng.choice([0.0, 0.2])), n_groups=n_groups)
+        norm = secedo_amd.NORMALIZATIONS[it % 3]
+        block = int(rng.choice([0, 64, 128]))
+        mode = str(rng.choice(["auto", "host"]))
+        exact = gap <= 6 or (gap <= 40 and fmax >= 400)  # pairs may share > 48 loci: see simmat_oracle.h
+        ob.set_exact_binomials(exact)
+        try:
+            ref, raw = ob.oracle_compute(p, n, mfl, g2p, 0.01, 0.5, 0.02, T, norm, want_raw=True)
+            counts_ref = (ob.oracle_last_updates(), ob.oracle_last_read_pairs())
+            # the same terms without the reference's final-subtraction cancellation (simmat_oracle.c)
+            ob.set_direct_llr_sum(True)
+            _, raw_direct = ob.oracle_compute(p, n, mfl, g2p, 0.01, 0.5, 0.02, T, norm, want_raw=True)
+        finally:
+            ob.set_exact_binomials(False)
+            ob.set_direct_llr_sum(False)
+        # with >~1e4 pairs per cell pair the reference's two sums reach 1e5..1e6 and its own result is
+        # only good to ~1e-8 (SURVEY.md 7.2): the 1e-9 bar then applies against the direct sums
+        heavy = counts_ref[1] / max(1.0, n * (n - 1) / 2) > 1e4
+        tol_ref = 5e-8 if heavy else TOL
+        with secedo_amd.SimilarityMatrixPlan(0) as plan:
+            plan.set_packing(mode)
+            plan.prepare(p, n, mfl, g2p, T, block_cells=block)
+            acc = plan.new_acc()
+            plan.accumulate(acc, 0.01, 0.5, 0.02)
+            got = plan.finalize(acc, norm).cpu().numpy()
+            got_raw = plan.finalize_raw(acc).cpu().numpy()
+            assert plan.last_counts() == counts_ref, (it, n, nchr, L, cov, gap, fmax, mfl, T, block, mode)
+        ctx = (it, n, nchr, L, cov, gap, fmax, mfl, T, norm, block, mode)
+        assert gu.normwise_err(got_raw, raw_direct) <= TOL, ctx
+        assert gu.normwise_err(got_raw, raw) <= tol_ref, ctx
+        if np.all(np.isfinite(ref)) and not (norm == "EXPONENTIATE" and np.max(np.abs(raw)) > 30):
+            assert gu.normwise_err(got, ref) <= tol_ref, ctx
+        assert np.array_equal(got, got.T, equal_nan=True), ctx
