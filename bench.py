@@ -207,7 +207,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "int64 fixed-point accumulate, f64 output",
+            "dtype": "int64",
             "data": "synthetic (SYNTH-v1, seed 42)",
             "config": {"workload": "%s: %d cells x %d loci%s" % (
                 args.workload, n_cells, n_loci, " clustered" if args.clustered else ""),

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsecedo_simmat.so")
+LIB_PATH = os.environ.get("SECEDO_LIB_PATH") or os.path.join(HERE, "libsecedo_simmat.so")  # env: A/B builds
 
 OK = 0
 E_INVALID_ARG = -1
