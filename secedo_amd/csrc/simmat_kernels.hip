@@ -111,8 +111,8 @@ __device__ __noinline__ long long pair_value_full(const SlowPathArgs *sp, uint32
 //         to fixed point when it flushes (exact integer arithmetic, so the result is bit-identical
 //         to the int64 tile). Needs < 65536 pairs per cell pair, which the host guarantees from
 //         the pileup's pair bound; joint terms bypass the tile (global atomics).
-// HCAP:   pairs of one wave batch that are flattened over the lanes (below); deeper batches fall
-//         back to one lane per row-side entry.
+// HCAP:   size of the per-wave strip in which a batch's pairs are flattened over the lanes (below);
+//         deeper batches are flattened HCAP pairs at a time.
 //
 // Work distribution. A workgroup walks its locus ranges; per range the column side (block J) is
 // staged in LDS. Each wave then pulls batches of 64 consecutive row-side entries (block I). A lane's
@@ -382,8 +382,24 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                     }
                     __builtin_amdgcn_wave_barrier();  // the strip is reused by the next batch
                 } else {
-                    // a very deep batch: one lane per row-side entry
-                    for (uint32_t jc = j0; jc < j0 + c; ++jc) pair(rec, m1, sJ[jc], jc, ib + i, jb + jc);
+                    // a very deep batch (more than HCAP pairs): the same flattening, HCAP pairs at a
+                    // time -- pair p belongs to lane owner[p - win] -- with the general pair routine
+                    wrec[lane] = make_uint2(rec & 0xFFFFu, j0 - pex);
+                    if (MASKS) wm[lane] = m1;
+                    for (uint32_t win = 0; win < total; win += (uint32_t)HCAP) {
+                        const uint32_t wlen = min((uint32_t)HCAP, total - win);
+                        const uint32_t f0 = max(pex, win), f1 = min(pin, win + (uint32_t)HCAP);
+                        for (uint32_t p = f0; p < f1; ++p) owner[p - win] = (unsigned char)lane;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        for (uint32_t q = lane; q < wlen; q += 64u) {
+                            const uint32_t o = owner[q];
+                            const uint2 ro = wrec[o];
+                            const uint32_t jc = ro.y + win + q;
+                            pair(ro.x, MASKS ? wm[o] : 0u, sJ[jc], jc, ib + cur * 64u + o, jb + jc);
+                        }
+                        __builtin_amdgcn_wave_barrier();  // the strip is reused by the next window
+                    }
                 }
                 cur = nxt;
                 rec = rec_n;
