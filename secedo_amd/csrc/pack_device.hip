@@ -474,8 +474,8 @@ int bits_for(unsigned long long max_value) {
 
 std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, uint32_t mfl,
                                uint32_t num_threads, uint32_t block_cells,
-                               StageGeometry (*geometry)(uint32_t), hipStream_t stream,
-                               DevicePacked *out, bool *need_host) {
+                               StageGeometry (*geometry)(uint32_t), bool allow_count_tile,
+                               hipStream_t stream, DevicePacked *out, bool *need_host) {
     *need_host = false;
     if ((in.id_base16 != nullptr) == (in.id_base32 != nullptr))
         return "exactly one of id_base16 / id_base32 must be given";
@@ -626,8 +626,6 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     pk.num_entries = n_kept;
     pk.num_reads = R;
     pk.stage_masks = n_kept && (double)pk.multi_entries > geo.masks_threshold * (double)n_kept;
-    pk.cap_entries = pk.stage_masks ? geo.cap_entries_masks : geo.cap_entries_plain;
-    pk.cap_loci = pk.stage_masks ? geo.cap_loci_masks : geo.cap_loci_plain;
 
     // ---- 5: binning sort, offsets, bound, ranges, records ---------------------------------------
     uint32_t *t_read = S[TMP].as<uint32_t>();
@@ -653,6 +651,15 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     }
     cub_cap = S[CUB].bytes;
     HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
+    // the pair bound decides the tile variant, and the tile variant the staging limits of the ranges
+    HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    if (hsc.error == 1) return "group id outside group_id_to_pos";
+    if (hsc.error == 2) return "group_id_to_pos maps outside the matrix";
+    pk.pair_bound = hsc.pair_bound;
+    pk.count_tile = allow_count_tile && !pk.stage_masks && pk.pair_bound < kCountTileLimit;
+    pk.cap_entries = pk.stage_masks ? geo.cap_entries_masks : pk.count_tile ? geo.cap_entries_counts : geo.cap_entries_plain;
+    pk.cap_loci = pk.stage_masks ? geo.cap_loci_masks : pk.count_tile ? geo.cap_loci_counts : geo.cap_loci_plain;
     {
         const uint32_t n_seg = (L + pk.cap_loci - 1) / pk.cap_loci;
         // segment scratch: ends[n_seg * cap_loci] | count[n_seg], in ELOC (entry_locus is dead after k_csr)
@@ -672,9 +679,6 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     }
     HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
-    if (hsc.error == 1) return "group id outside group_id_to_pos";
-    if (hsc.error == 2) return "group_id_to_pos maps outside the matrix";
-    pk.pair_bound = hsc.pair_bound;
     pk.num_ranges = hsc.num_ranges;
     HIP_OK(hipGetLastError());
     return std::string();

@@ -47,6 +47,7 @@ struct DevicePacked {
     uint32_t num_cells = 0, block_cells = 0, num_blocks = 0, num_loci = 0, num_ranges = 0;
     uint64_t num_entries = 0, num_reads = 0, pair_bound = 0, multi_entries = 0;
     bool stage_masks = false;
+    bool count_tile = false;
     uint32_t cap_entries = 0, cap_loci = 0;
 };
 
@@ -56,6 +57,7 @@ struct DevicePacked {
 std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells,
                                uint32_t max_fragment_length, uint32_t num_threads,
                                uint32_t block_cells, StageGeometry (*geometry)(uint32_t),
-                               hipStream_t stream, DevicePacked *out, bool *need_host);
+                               bool allow_count_tile, hipStream_t stream, DevicePacked *out,
+                               bool *need_host);
 
 }  // namespace secedo

@@ -47,7 +47,8 @@ struct IdMap {
 
 std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t mfl,
                         uint32_t num_threads, uint32_t block_cells,
-                        StageGeometry (*geometry)(uint32_t block_cells), PackedPileup *out) {
+                        StageGeometry (*geometry)(uint32_t block_cells), bool allow_count_tile,
+                        PackedPileup *out) {
     if (!in.chr_locus_off || !in.locus_entry_off) return "null pileup arrays";
     if ((in.id_base16 != nullptr) == (in.id_base32 != nullptr))
         return "exactly one of id_base16 / id_base32 must be given";
@@ -192,10 +193,32 @@ std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t m
             run += c;
         }
     }
+    // ---- pair bound: max over cells of sum over loci of (entries of the cell at the locus)^2 -----
+    {
+        std::vector<uint64_t> sq(num_cells, 0);
+        std::vector<uint32_t> cnt(num_cells, 0);
+        std::vector<uint32_t> seen;
+        for (uint32_t l = 0; l < L; ++l) {
+            seen.clear();
+            for (uint64_t e = in.locus_entry_off[l]; e < in.locus_entry_off[l + 1]; ++e) {
+                if (!kept[e]) continue;
+                const uint32_t cell = segs[seg_of[e]].cell;
+                if (cnt[cell]++ == 0) seen.push_back(cell);
+            }
+            for (uint32_t cell : seen) {
+                sq[cell] += static_cast<uint64_t>(cnt[cell]) * cnt[cell];
+                cnt[cell] = 0;
+            }
+        }
+        pk.pair_bound = 0;
+        for (uint64_t v : sq) pk.pair_bound = std::max(pk.pair_bound, v);
+    }
+
     // ---- pass 3b: locus ranges for LDS staging (greedy; one partition shared by all blocks) ----
     pk.stage_masks = n_kept && static_cast<double>(pk.multi_entries) > geo.masks_threshold * static_cast<double>(n_kept);
-    pk.cap_entries = pk.stage_masks ? geo.cap_entries_masks : geo.cap_entries_plain;
-    pk.cap_loci = pk.stage_masks ? geo.cap_loci_masks : geo.cap_loci_plain;
+    pk.count_tile = allow_count_tile && !pk.stage_masks && pk.pair_bound < kCountTileLimit;
+    pk.cap_entries = pk.stage_masks ? geo.cap_entries_masks : pk.count_tile ? geo.cap_entries_counts : geo.cap_entries_plain;
+    pk.cap_loci = pk.stage_masks ? geo.cap_loci_masks : pk.count_tile ? geo.cap_loci_counts : geo.cap_loci_plain;
     if (pk.cap_entries == 0 || pk.cap_loci == 0 || pk.cap_loci > 65535 || pk.cap_entries > 65535)
         return "invalid staging geometry";
     pk.range_off.clear();
@@ -239,11 +262,7 @@ std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t m
     pk.mask32.resize(n_kept);
     pk.entry_read.resize(n_kept);
     std::vector<uint32_t> cursor(pk.blk_off);  // next free index per (block, locus)
-    std::vector<uint64_t> per_cell_sq(num_cells, 0);
-    std::vector<uint32_t> cell_cnt(num_cells, 0);
-    std::vector<uint32_t> touched;
     for (uint32_t l = 0; l < L; ++l) {
-        touched.clear();
         for (uint64_t e = in.locus_entry_off[l]; e < in.locus_entry_off[l + 1]; ++e) {
             if (!kept[e]) continue;
             const Segment &sg = segs[seg_of[e]];
@@ -287,15 +306,8 @@ std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t m
                     | ((l - range_begin_of[l]) << 16);
             pk.mask32[dst] = (a.masks & 0xFFu) | (((a.masks >> 16) & 0xFFu) << 8)
                     | ((a.bases & 0xFFu) << 16) | (((a.bases >> 16) & 0xFFu) << 24);
-            if (cell_cnt[sg.cell]++ == 0) touched.push_back(sg.cell);
-        }
-        for (uint32_t cell : touched) {
-            per_cell_sq[cell] += static_cast<uint64_t>(cell_cnt[cell]) * cell_cnt[cell];
-            cell_cnt[cell] = 0;
         }
     }
-    pk.pair_bound = 0;
-    for (uint64_t v : per_cell_sq) pk.pair_bound = std::max(pk.pair_bound, v);
     return std::string();
 }
 

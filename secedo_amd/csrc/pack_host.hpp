@@ -64,10 +64,14 @@ constexpr uint32_t kNarrowWindow = 8;
 
 // LDS staging limits of the accumulate kernel (simmat_kernels.hpp supplies them per tile size)
 struct StageGeometry {
-    uint32_t cap_entries_plain, cap_loci_plain;  // compact records only
-    uint32_t cap_entries_masks, cap_loci_masks;  // compact records + mask32 staged as well
-    double masks_threshold;                      // stage mask32 when this fraction of entries is multi
+    uint32_t cap_entries_plain, cap_loci_plain;    // compact records only, int64 tile
+    uint32_t cap_entries_masks, cap_loci_masks;    // compact records + mask32 staged as well
+    uint32_t cap_entries_counts, cap_loci_counts;  // compact records only, 2 x 16-bit count tile
+    double masks_threshold;                        // stage mask32 when this fraction of entries is multi
 };
+
+// 2 x 16-bit pair counters per cell pair are safe while no cell pair can collect this many pairs
+constexpr uint64_t kCountTileLimit = 65536;
 
 struct PackedPileup {
     uint32_t num_cells = 0;
@@ -81,6 +85,7 @@ struct PackedPileup {
     uint64_t multi_entries = 0; // entries of reads with more than one kept entry
     bool any_window_overflow = false;
     bool stage_masks = false;
+    bool count_tile = false;    // the accumulate kernel may use the 2 x 16-bit count tile
 
     // entries sorted by (cell block, locus, input order); blk_off[b * (L+1) + l] is the first
     // entry of block b at locus l, blk_off[b * (L+1) + L] the end of block b
@@ -104,8 +109,10 @@ struct PackedPileup {
 // Returns an empty string on success, else an error message (invalid input).
 // block_cells: 64 or 128, or 0 = choose: 128-cell tiles amortise the per-batch work best, but
 // only 64-cell tiles leave LDS room for the window masks that clustered loci need.
+// allow_count_tile = false forces the int64 tile (diagnostics)
 std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t max_fragment_length,
                         uint32_t num_threads, uint32_t block_cells,
-                        StageGeometry (*geometry)(uint32_t block_cells), PackedPileup *out);
+                        StageGeometry (*geometry)(uint32_t block_cells), bool allow_count_tile,
+                        PackedPileup *out);
 
 }  // namespace secedo

@@ -243,6 +243,8 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
             if (v == 64 || v == 128) block_cells = static_cast<uint32_t>(v);
         }
     }
+    bool allow_count_tile = true;  // SECEDO_COUNT_TILE=0 forces the int64 tile (diagnostics)
+    if (const char *env = std::getenv("SECEDO_COUNT_TILE")) allow_count_tile = std::atoi(env) != 0;
     int mode = h->packing_mode;
     if (const char *env = std::getenv("SECEDO_PACKING")) {
         if (!std::strcmp(env, "host")) mode = 1;
@@ -281,7 +283,7 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
         }
         const std::string err = secedo::pack_pileup_device(h->dview, num_cells, max_fragment_length,
                                                            num_threads, block_cells, &secedo::stage_geometry,
-                                                           s, &pk, &need_host);
+                                                           allow_count_tile, s, &pk, &need_host);
         if (!err.empty()) {
             h->have_host = h->have_device = false;
             return fail(err.find("hip") == 0 ? SECEDO_E_HIP : SECEDO_E_INVALID_ARG, err);
@@ -332,7 +334,8 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
         }
         secedo::PackedPileup hp_pk;
         const std::string err = secedo::pack_pileup(v, num_cells, max_fragment_length, num_threads,
-                                                    block_cells, &secedo::stage_geometry, &hp_pk);
+                                                    block_cells, &secedo::stage_geometry, allow_count_tile,
+                                                    &hp_pk);
         if (!err.empty()) {
             h->have_host = h->have_device = false;
             return fail(SECEDO_E_INVALID_ARG, err);
@@ -355,6 +358,7 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
         pk.pair_bound = hp_pk.pair_bound;
         pk.multi_entries = hp_pk.multi_entries;
         pk.stage_masks = hp_pk.stage_masks;
+        pk.count_tile = hp_pk.count_tile;
         pk.cap_entries = hp_pk.cap_entries;
         pk.cap_loci = hp_pk.cap_loci;
         pk.num_ranges = static_cast<uint32_t>(hp_pk.range_off.size()) - 1;
@@ -376,9 +380,9 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
         HIP_TRY(h->tile_row.upload(trow));
         HIP_TRY(h->tile_col.upload(tcol));
     }
-    HIP_TRY(h->counters.ensure(2 * sizeof(unsigned long long)));
+    HIP_TRY(h->counters.ensure(16 * sizeof(unsigned long long)));
     HIP_TRY(h->max_bits.ensure(sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(h->counters.p, 0, 16 * sizeof(unsigned long long), s));
     h->prepared = true;
     h->timed = false;
     return SECEDO_OK;
@@ -517,11 +521,10 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     a.acc = d_acc;
     a.counters = h->counters.as<unsigned long long>();
 
-    HIP_TRY(hipMemsetAsync(h->counters.p, 0, 2 * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(h->counters.p, 0, 16 * sizeof(unsigned long long), s));
     HIP_TRY(hipEventRecord(h->ev_begin, s));
     // 16-bit pair counters per cell pair are safe when no cell pair can collect 65536 pairs
-    bool count_tile = !h->pk.stage_masks && h->pk.pair_bound < 65536;
-    if (const char *env = std::getenv("SECEDO_COUNT_TILE")) count_tile = count_tile && std::atoi(env) != 0;
+    const bool count_tile = h->pk.count_tile;
     HIP_TRY(h->slab.ensure(secedo::accumulate_slab_bytes(h->pk.block_cells, count_tile, a.n_workgroups)));
     a.slab = h->slab.p;
     HIP_TRY(secedo::launch_accumulate(a, h->pk.block_cells, h->pk.stage_masks, count_tile, n_tiles, s));
@@ -561,6 +564,17 @@ int secedo_simmat_last_counts(secedo_simmat_t *h, uint64_t *updates, uint64_t *r
     HIP_TRY(hipMemcpy(c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost));
     if (updates) *updates = c[0];
     if (read_pairs) *read_pairs = c[1];
+    if (std::getenv("SECEDO_STAMPS_PRINT")) {  // diagnostic builds (-DSECEDO_STAMPS) only
+        unsigned long long st[16] = {0};
+        HIP_TRY(hipMemcpy(st, h->counters.p, sizeof(st), hipMemcpyDeviceToHost));
+        if (st[8]) {
+            std::fprintf(stderr, "[stamps] waves %llu batches %llu trips %llu | per wave: lifetime %.0f cyc, setup %.0f, "
+                                 "fill %.0f, trips %.0f | per batch: setup %.0f fill %.0f trips %.0f (%.2f trips)\n",
+                         st[8], st[5], st[6], (double)st[7] / st[8], (double)st[2] / st[8], (double)st[3] / st[8],
+                         (double)st[4] / st[8], (double)st[2] / st[5], (double)st[3] / st[5], (double)st[4] / st[5],
+                         (double)st[6] / st[5]);
+        }
+    }
     return SECEDO_OK;
 }
 

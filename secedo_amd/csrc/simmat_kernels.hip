@@ -34,6 +34,19 @@ __device__ __forceinline__ double log_add(double a, double b) {
     return hi + log1p(exp(lo - hi));
 }
 
+#ifdef SECEDO_STAMPS
+// diagnostic build only: cycle stamps around the phases of a wave batch (MI355X guide, "In-kernel
+// stamps"); sums leave through counters[2..], which nothing else reads
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define STAMP(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = stamp(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define STAMP(var)
+#endif
+
 // wave64 inclusive prefix sum in registers (DPP row shifts + row broadcasts; no LDS traffic)
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xF, 0xF, true);  // row_shr:1
@@ -172,6 +185,10 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     const long long d10 = a.lut[1 * LUT_DIM + 0], d01 = a.lut[0 * LUT_DIM + 1];
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B;
     unsigned long long n_updates = 0, n_pairs = 0;
+#ifdef SECEDO_STAMPS
+    unsigned long long st_setup = 0, st_fill = 0, st_trip = 0, st_batches = 0, st_trips = 0;
+    const unsigned long long st_begin = stamp();
+#endif
     uint32_t upd = 0, skipped = 0;  // per range, 32-bit, per lane
     uint32_t upd_w = 0;             // per range, wave-uniform (lane 0 reports it)
     // inside a diagonal tile pairs of the same cell are skipped (:215); elsewhere cells differ
@@ -221,6 +238,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
 
     // the next range's column side, in flight in registers while the current range is paired
     uint32_t pJ[JPT], pM[MASKS ? JPT : 1], pO[OPT];
+    uint32_t pRec = 0, pM1 = 0;  // this wave's first row-side batch of the next range
     uint32_t n_la = 0, n_lb = 0, n_ib = 0, n_ie = 0, n_jb = 0, n_je = 0;
     bool n_staged = false;
 
@@ -246,6 +264,12 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                 const uint32_t i = tid + k * THREADS;
                 if (i <= n_lb - n_la) pO[k] = offJ[n_la + i];
             }
+            pRec = 0;
+            pM1 = 0;
+            if (tid < n_ie - n_ib) {  // batch (tid >> 6), entry tid: batches 0..WAVES-1 are pre-assigned
+                pRec = a.entry32[n_ib + tid];
+                if (MASKS) pM1 = a.mask32[n_ib + tid];
+            }
         }
     };
 
@@ -270,6 +294,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
             }
         }
         if (tid == 0) *s_next = WAVES;  // batches 0..WAVES-1 are pre-assigned, one per wave
+        const uint32_t first_rec = pRec, first_m1 = pM1;
         __syncthreads();
         if (r + 1 < r_end) prefetch(r + 1);
 
@@ -280,12 +305,9 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
         if (staged) {
             const uint32_t n_batch = (nI + 63u) / 64u;
             uint32_t cur = tid >> 6;
-            uint32_t rec = 0, m1 = 0;
-            if (cur < n_batch && cur * 64u + lane < nI) {
-                rec = a.entry32[ib + cur * 64u + lane];
-                if (MASKS) m1 = a.mask32[ib + cur * 64u + lane];
-            }
+            uint32_t rec = first_rec, m1 = first_m1;  // loaded while the previous range was paired
             while (cur < n_batch) {
+                STAMP(t0);
                 uint32_t nxt = 0;
                 if (lane == 0) nxt = atomicAdd(s_next, 1u);
                 nxt = __builtin_amdgcn_readfirstlane(nxt);
@@ -307,6 +329,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                 const uint32_t total = __builtin_amdgcn_readlane(pin, 63);
                 const uint32_t pex = pin - c;
                 if (a.debug & 8u) { cur = nxt; rec = rec_n; m1 = m1_n; continue; }
+                STAMP(t1);
                 if (total <= (uint32_t)HCAP) {
                     // flatten: pair p of the batch belongs to lane owner[p]
                     if (!(a.debug & 4u))
@@ -317,6 +340,13 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                     if (MASKS) wm[lane] = m1;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    STAMP(t2);
+#ifdef SECEDO_STAMPS
+                    st_setup += t1 - t0;
+                    st_fill += t2 - t1;
+                    st_batches += 1;
+                    st_trips += (total + 127u) / 128u;
+#endif
                     if (!MASKS) {
                         // sparse-loci variants: single-locus pairs only in the hot loop; the (rare)
                         // pairs of two multi-locus reads are picked up by the second loop
@@ -354,6 +384,10 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                                 }
                             }
                         }
+                        STAMP(t3);
+#ifdef SECEDO_STAMPS
+                        st_trip += t3 - t2;
+#endif
                         const bool any_multi = (multi_seen & C_MULTI) != 0u;
                         if (__ballot(any_multi)) {
                             for (uint32_t p = lane; p < total; p += 64u) {
@@ -457,6 +491,17 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
         atomicAdd(&a.counters[0], n_updates);
         atomicAdd(&a.counters[1], n_pairs);
     }
+#ifdef SECEDO_STAMPS
+    if (lane == 0u) {
+        atomicAdd(&a.counters[2], st_setup);
+        atomicAdd(&a.counters[3], st_fill);
+        atomicAdd(&a.counters[4], st_trip);
+        atomicAdd(&a.counters[5], st_batches);
+        atomicAdd(&a.counters[6], st_trips);
+        atomicAdd(&a.counters[7], stamp() - st_begin);
+        atomicAdd(&a.counters[8], 1ull);
+    }
+#endif
 }
 
 // acc[tile] += sum over the tile's workgroups of their slab (count slabs are converted with the two
@@ -587,8 +632,9 @@ size_t accumulate_slab_bytes(uint32_t block_cells, bool count_tile, uint32_t n_w
 }
 
 StageGeometry stage_geometry(uint32_t block_cells) {
-    if (block_cells == 128) return StageGeometry{kCapJ128, kCapL128, kCapJ128, kCapL128, 2.0 /* never */};
-    return StageGeometry{kCapJ64, kCapL64, kCapJ64M, kCapL64M, kMasksThreshold};
+    if (block_cells == 128)
+        return StageGeometry{kCapJ128, kCapL128, kCapJ128, kCapL128, kCapJ128C, kCapL128C, 2.0 /* never */};
+    return StageGeometry{kCapJ64, kCapL64, kCapJ64M, kCapL64M, kCapJ64C, kCapL64C, kMasksThreshold};
 }
 
 hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, bool stage_masks,
@@ -597,11 +643,11 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
     const uint32_t grid = args.n_workgroups;
     if (block_cells == 128) {
         // the 128 KiB int64 tile leaves no room for the window masks: joint terms go through HBM
-        if (count_tile) return launch_acc<128, 1024, kCapJ128, kCapL128, 1024, false, true>(args, grid, stream);
+        if (count_tile) return launch_acc<128, 1024, kCapJ128C, kCapL128C, 1024, false, true>(args, grid, stream);
         return launch_acc<128, 1024, kCapJ128, kCapL128, 512, false, false>(args, grid, stream);
     }
     if (stage_masks) return launch_acc<64, 256, kCapJ64M, kCapL64M, 1024, true, false>(args, grid, stream);
-    if (count_tile) return launch_acc<64, 256, kCapJ64, kCapL64, 1024, false, true>(args, grid, stream);
+    if (count_tile) return launch_acc<64, 256, kCapJ64C, kCapL64C, 1024, false, true>(args, grid, stream);
     return launch_acc<64, 256, kCapJ64, kCapL64, 1024, false, false>(args, grid, stream);
 }
 

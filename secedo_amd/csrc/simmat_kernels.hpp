@@ -19,8 +19,9 @@ struct LlrModelDev {  // LlrModel of llr_table.hpp, by value into the kernel
 // LDS staging geometry of accumulate_tiles per tile size: column-side entries and loci per locus
 // range, without / with the 8-locus window masks staged too. pack_host.cpp cuts the locus ranges
 // to these limits. LDS per workgroup: B=64: 32 KiB tile + 12/28 KiB; B=128: 128 KiB tile + 24/28 KiB.
-constexpr uint32_t kCapJ64 = 4096, kCapL64 = 2046, kCapJ64M = 4096, kCapL64M = 2046;
+constexpr uint32_t kCapJ64 = 4096, kCapL64 = 2046, kCapJ64M = 4096, kCapL64M = 2046, kCapJ64C = 4096, kCapL64C = 2046;
 constexpr uint32_t kCapJ128 = 4096, kCapL128 = 2046, kCapJ128M = 4096, kCapL128M = 2046;
+constexpr uint32_t kCapJ128C = 8192, kCapL128C = 4094;  // the 64 KiB count tile leaves room for longer ranges
 constexpr double kMasksThreshold = 0.05;  // stage the masks when > 5 % of the entries are multi-locus
 
 // Everything only the rare paths touch lives in HBM behind one pointer, so that the kernel's
