@@ -573,6 +573,10 @@ int secedo_simmat_last_counts(secedo_simmat_t *h, uint64_t *updates, uint64_t *r
                          st[8], st[5], st[6], (double)st[7] / st[8], (double)st[2] / st[8], (double)st[3] / st[8],
                          (double)st[4] / st[8], (double)st[2] / st[5], (double)st[3] / st[5], (double)st[4] / st[5],
                          (double)st[6] / st[5]);
+            std::fprintf(stderr, "[stamps] per wave: barrier-1 wait %.0f, staging+barrier-2 %.0f, prefetch issue %.0f\n",
+                         (double)st[9] / st[8], (double)st[10] / st[8], (double)st[11] / st[8]);
+            std::fprintf(stderr, "[stamps] per wave: post-trip %.0f, batch loop total %.0f\n",
+                         (double)st[12] / st[8], (double)st[13] / st[8]);
         }
     }
     return SECEDO_OK;

@@ -116,6 +116,16 @@ __device__ __noinline__ long long pair_value_full(const SlowPathArgs *sp, uint32
     return slow_pair(sp, entry_read[g1], entry_read[g2], A1.w);
 }
 
+// Capacity of the per-wave list of deferred joint pairs (see accumulate_tiles): 192 where the LDS
+// budget allows, else 0 (the batch is rescanned for its joint pairs instead).
+template <int B, int THREADS, int CAPJ, int CAPL, int HCAP, bool MASKS, bool COUNTS>
+constexpr int joint_list_cap() {
+    if (MASKS) return 0;
+    constexpr size_t fixed = (size_t)B * B * (COUNTS ? 4 : 8) + (size_t)CAPJ * 2 + ((size_t)CAPL + 2) * 2 + 16
+            + (size_t)(THREADS / 64) * ((size_t)HCAP + 64 * 8);
+    return fixed + (size_t)(THREADS / 64) * 192 * 10 <= 160 * 1024 ? 192 : 0;
+}
+
 // MASKS:  the 8-locus window masks are staged too, so joint (x_s, x_d) terms of multi-locus read
 //         pairs are evaluated from LDS (clustered loci); otherwise such pairs go through the full
 //         entries in HBM (they are rare when loci are sparse).
@@ -140,10 +150,12 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     constexpr int WAVES = THREADS / 64;
     constexpr int JPT = (CAPJ + THREADS - 1) / THREADS;      // staged column entries per thread
     constexpr int OPT = (CAPL + 1 + THREADS - 1) / THREADS;  // staged offsets per thread
-    constexpr size_t WAVE_BYTES = (size_t)HCAP + 64 * 8 + (MASKS ? 64 * 4 : 0);
+    constexpr int MCAP = joint_list_cap<B, THREADS, CAPJ, CAPL, HCAP, MASKS, COUNTS>();
+    constexpr size_t WAVE_BYTES = (size_t)HCAP + 64 * 8 + (MASKS ? 64 * 4 : 0) + (size_t)MCAP * 10;
 
     // LDS: [ tile | sJ CAPJ u16 | sOff CAPL+2 u16 | sJm CAPJ u32, sLut (MASKS) | s_next | per wave:
-    //        owner HCAP u8, wrec 64 x {entry, j0 - P}, wm 64 u32 (MASKS) ]
+    //        owner HCAP u8, wrec 64 x {entry, j0 - P}, wm 64 u32 (MASKS),
+    //        mlist MCAP x {g1, g2}, mcell MCAP u16 (sparse-loci variants: deferred joint pairs) ]
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long *tile64 = reinterpret_cast<unsigned long long *>(lds_raw);
     uint32_t *tile32 = reinterpret_cast<uint32_t *>(lds_raw);
@@ -156,6 +168,8 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     unsigned char *owner = wave_base;
     uint2 *wrec = reinterpret_cast<uint2 *>(wave_base + HCAP);
     uint32_t *wm = reinterpret_cast<uint32_t *>(wave_base + HCAP + 64 * 8);
+    uint2 *mlist = reinterpret_cast<uint2 *>(wave_base + HCAP + 64 * 8);  // MASKS has no list
+    uint16_t *mcell = reinterpret_cast<uint16_t *>(wave_base + HCAP + 64 * 8 + (size_t)MCAP * 8);
 
     // workgroup -> (tile, chunk of the tile's locus ranges); diagonal tiles hold half the pairs and
     // get half the chunks, so that all workgroups of a launch carry about the same work
@@ -186,10 +200,28 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B;
     unsigned long long n_updates = 0, n_pairs = 0;
 #ifdef SECEDO_STAMPS
-    unsigned long long st_setup = 0, st_fill = 0, st_trip = 0, st_batches = 0, st_trips = 0;
+    unsigned long long st_setup = 0, st_fill = 0, st_trip = 0, st_batches = 0, st_trips = 0, st_bar1 = 0, st_stage = 0, st_pref = 0, st_post = 0, st_t3 = 0, st_loop = 0;
     const unsigned long long st_begin = stamp();
 #endif
     uint32_t upd = 0, skipped = 0;  // per range, 32-bit, per lane
+    uint32_t n_list = 0;            // deferred joint pairs in this wave's list (wave-uniform)
+    uint32_t skipped_list = 0;      // per lane, over the whole kernel
+    // Joint pairs (both reads cover further loci) are rare when loci are sparse, and evaluating one
+    // means dependent HBM reads: the hot loop only appends them to a per-wave list, and the list is
+    // worked off 64 pairs at a time -- every lane busy, one memory latency for 64 pairs.
+    auto flush_list = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t q = lane; q < n_list; q += 64u) {
+            const uint2 g = mlist[q];
+            const long long v = pair_value_full(a.slow, g.x, g.y);
+            if (v == NO_PAIR) ++skipped_list;
+            else if (COUNTS) atomicAdd(&dst[mcell[q]], (unsigned long long)v);
+            else atomicAdd(&tile64[mcell[q]], (unsigned long long)v);
+        }
+        __builtin_amdgcn_wave_barrier();
+        n_list = 0;
+    };
     uint32_t upd_w = 0;             // per range, wave-uniform (lane 0 reports it)
     // inside a diagonal tile pairs of the same cell are skipped (:215); elsewhere cells differ
     const uint32_t cell_test = diag ? C_CELL : 0u;
@@ -277,7 +309,9 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     for (uint32_t r = r_begin; r < r_end; ++r) {
         const uint32_t la = n_la, lb = n_lb, ib = n_ib, ie = n_ie, jb = n_jb, je = n_je;
         const bool staged = n_staged;
+        STAMP(tb0);
         __syncthreads();  // every wave is done with the previous range (first time: with zeroing)
+        STAMP(tb1);
         if (staged) {
 #pragma unroll
             for (int k = 0; k < JPT; ++k) {
@@ -296,7 +330,14 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
         if (tid == 0) *s_next = WAVES;  // batches 0..WAVES-1 are pre-assigned, one per wave
         const uint32_t first_rec = pRec, first_m1 = pM1;
         __syncthreads();
+        STAMP(tb2);
         if (r + 1 < r_end) prefetch(r + 1);
+        STAMP(tb3);
+#ifdef SECEDO_STAMPS
+        st_bar1 += tb1 - tb0;
+        st_stage += tb2 - tb1;
+        st_pref += tb3 - tb2;
+#endif
 
         const uint32_t nI = ie - ib;
         upd = 0;
@@ -357,6 +398,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                         const uint32_t last = total - 1u;
                         constexpr int PPL = 2;  // pairs per lane and trip: independent LDS read chains (4 is no faster)
                         for (uint32_t base = 0; base < ((a.debug & 2u) ? 0u : total); base += 64u * PPL) {
+                            if (MCAP > 0 && n_list > (uint32_t)(MCAP - 64 * PPL)) flush_list();
                             uint32_t pp[PPL], oo[PPL], ww[PPL];
                             uint2 rr[PPL];
 #pragma unroll
@@ -375,9 +417,23 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                                 const bool ok = pp[u] < total && (both & C_TAIL) == 0u
                                         && ((x & cell_test) != 0u || !diag);
                                 upd += ok ? 1u : 0u;
-                                multi_seen |= ok ? both : 0u;
+                                const uint32_t cell = (rr[u].x >> 16) + (ww[u] & C_CELL);
+                                if (MCAP > 0) {
+                                    const bool joint = ok && (both & C_MULTI) != 0u;
+                                    const unsigned long long bal = __ballot(joint);
+                                    if (bal) {
+                                        if (joint) {
+                                            const uint32_t slot = n_list + __builtin_amdgcn_mbcnt_hi(
+                                                    (uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                                            mlist[slot] = make_uint2(ib + cur * 64u + oo[u], jb + rr[u].y + pp[u]);
+                                            mcell[slot] = (uint16_t)cell;
+                                        }
+                                        n_list += (uint32_t)__popcll(bal);
+                                    }
+                                } else {
+                                    multi_seen |= ok ? both : 0u;
+                                }
                                 if ((a.debug & 1u) == 0u && ok && (both & C_MULTI) == 0u) {
-                                    const uint32_t cell = (rr[u].x >> 16) + (ww[u] & C_CELL);
                                     const bool differ = (x & (3u << C_BASE_SHIFT)) != 0u;
                                     if (COUNTS) atomicAdd(&tile32[cell], differ ? 0x10000u : 1u);
                                     else atomicAdd(&tile64[cell], (unsigned long long)(differ ? d01 : d10));
@@ -387,9 +443,10 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                         STAMP(t3);
 #ifdef SECEDO_STAMPS
                         st_trip += t3 - t2;
+                        st_t3 = t3;
 #endif
-                        const bool any_multi = (multi_seen & C_MULTI) != 0u;
-                        if (__ballot(any_multi)) {
+                        const bool any_multi = MCAP == 0 && (multi_seen & C_MULTI) != 0u;
+                        if (MCAP == 0 && __ballot(any_multi)) {
                             for (uint32_t p = lane; p < total; p += 64u) {
                                 const uint32_t o = owner[p];
                                 const uint2 ro = wrec[o];
@@ -415,6 +472,9 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                         }
                     }
                     __builtin_amdgcn_wave_barrier();  // the strip is reused by the next batch
+#ifdef SECEDO_STAMPS
+                    if (!MASKS) { STAMP(t4); st_post += t4 - st_t3; }
+#endif
                 } else {
                     // a very deep batch (more than HCAP pairs): the same flattening, HCAP pairs at a
                     // time -- pair p belongs to lane owner[p - win] -- with the general pair routine
@@ -464,10 +524,14 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                 }
             }
         }
+#ifdef SECEDO_STAMPS
+        { STAMP(te); st_loop += te - tb3; }
+#endif
         const uint32_t upd_all = upd + (lane == 0u ? upd_w : 0u);
         n_updates += upd_all;
         n_pairs += (unsigned long long)upd_all - skipped;
     }
+    if (MCAP > 0 && n_list) flush_list();
     __syncthreads();
 
     // flush: the workgroup's tile goes to its own slab with plain coalesced stores; reduce_slabs adds
@@ -483,6 +547,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     }
 
     // work counters: wave reduction, one atomic per wave
+    n_pairs -= skipped_list;
     for (int off = 32; off > 0; off >>= 1) {
         n_updates += __shfl_down(n_updates, off);
         n_pairs += __shfl_down(n_pairs, off);
@@ -500,6 +565,11 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
         atomicAdd(&a.counters[6], st_trips);
         atomicAdd(&a.counters[7], stamp() - st_begin);
         atomicAdd(&a.counters[8], 1ull);
+        atomicAdd(&a.counters[9], st_bar1);
+        atomicAdd(&a.counters[10], st_stage);
+        atomicAdd(&a.counters[11], st_pref);
+        atomicAdd(&a.counters[12], st_post);
+        atomicAdd(&a.counters[13], st_loop);
     }
 #endif
 }
@@ -604,7 +674,8 @@ template <int B, int THREADS, int CAPJ, int CAPL, int HCAP, bool MASKS, bool COU
 hipError_t launch_acc(const AccumulateArgs &args, uint32_t grid, hipStream_t stream) {
     constexpr size_t lds = (size_t)B * B * (COUNTS ? 4 : 8) + (size_t)CAPJ * 2 + ((size_t)CAPL + 2) * 2
             + (MASKS ? (size_t)CAPJ * 4 + SLUT_DIM * SLUT_DIM * 8 : 0) + 16
-            + (size_t)(THREADS / 64) * ((size_t)HCAP + 64 * 8 + (MASKS ? 64 * 4 : 0));
+            + (size_t)(THREADS / 64) * ((size_t)HCAP + 64 * 8 + (MASKS ? 64 * 4 : 0)
+                                        + (size_t)joint_list_cap<B, THREADS, CAPJ, CAPL, HCAP, MASKS, COUNTS>() * 10);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((CAPL + 2) % 4 == 0 && CAPJ % 8 == 0 && HCAP % 16 == 0, "alignment of the LDS carve-up");
     auto kern = &accumulate_tiles<B, THREADS, CAPJ, CAPL, HCAP, MASKS, COUNTS>;
