@@ -16,6 +16,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace secedo {
 
@@ -46,10 +47,24 @@ struct Scalars {
     uint32_t error;       // 1 group id outside group_id_to_pos, 2 row outside the matrix, 3 positions not increasing
     uint32_t need_host;
     uint32_t num_ranges;
+    uint32_t max_read_id;
+    uint32_t regroup;     // a group too long for the in-group ranking: redo with the radix sorts
     uint32_t pad;
+    unsigned long long id_space;  // sum over chromosomes of (largest - smallest read id + 1)
     unsigned long long multi_entries;
     unsigned long long pair_bound;
 };
+
+// Grouping without a sort (entries by read id, kept entries by (cell block, locus)): histogram of
+// the group sizes, exclusive scan, scatter with an atomic cursor (arbitrary order inside a group),
+// then every element finds its rank inside its group by scanning the group -- groups are short
+// (a read covers a few loci; a cell block has a few entries at a locus), so this costs a few cached
+// reads per element where a radix sort costs 4-7 passes over the data. The result is the order a
+// stable sort gives. A group longer than kRankScanLimit raises Scalars::regroup and the caller
+// falls back to the radix sorts.
+constexpr uint32_t kRankScanLimit = 8192;
+// the counting scheme for read ids needs a table over the id space: used while max id < factor * entries
+constexpr uint32_t kIdSpaceFactor = 4;
 
 struct Raw {  // by-value kernel argument: the raw pileup
     const uint32_t *chr_locus_off;
@@ -89,15 +104,115 @@ __device__ __forceinline__ uint32_t count_le(const uint32_t *a, uint32_t n, uint
     return lo;
 }
 
-__global__ void k_entry_keys(Raw in, uint32_t *entry_locus, unsigned long long *key, uint32_t *val) {
+// entry -> locus, one wave per locus (coalesced; empty loci cost nothing), and per chromosome the
+// largest and smallest read id (the latter as max of ~id, so that zero-filled memory is the neutral
+// element). A wave owns a contiguous slice of loci, so it meets few chromosomes: one pair of
+// atomics per (wave, chromosome).
+__global__ __launch_bounds__(TPB) void k_entry_locus(Raw in, uint32_t *entry_locus, uint32_t *id_max,
+                                                    uint32_t *id_negmin) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const uint32_t per = (in.n_loci + n_waves - 1) / n_waves;
+    const uint32_t l0 = min(in.n_loci, wave * per), l1 = min(in.n_loci, l0 + per);
+    if (l0 >= l1) return;
+    uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l0);
+    uint32_t c_end = in.chr_locus_off[c + 1];
+    uint32_t hi = 0, neg = 0;
+    bool any = false;
+    auto flush = [&]() {
+        for (int off = 32; off > 0; off >>= 1) {
+            hi = max(hi, (uint32_t)__shfl_down(hi, off));
+            neg = max(neg, (uint32_t)__shfl_down(neg, off));
+        }
+        if (lane == 0) {
+            atomicMax(&id_max[c], hi);
+            atomicMax(&id_negmin[c], neg);
+        }
+        hi = 0;
+        neg = 0;
+        any = false;
+    };
+    for (uint32_t l = l0; l < l1; ++l) {
+        if (l >= c_end) {
+            if (__any(any)) flush();
+            c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
+            c_end = in.chr_locus_off[c + 1];
+        }
+        const uint32_t b = (uint32_t)in.locus_entry_off[l], e = (uint32_t)in.locus_entry_off[l + 1];
+        for (uint32_t i = b + lane; i < e; i += 64u) {
+            entry_locus[i] = l;
+            const uint32_t id = in.read_ids[i];
+            hi = max(hi, id);
+            neg = max(neg, ~id);
+            any = true;
+        }
+    }
+    if (__any(any)) flush();
+}
+
+// dense numbering of (chromosome, read id): id_base[c] + id - smallest id of c
+__global__ void k_id_bases(uint32_t n_chr, const uint32_t *id_max, const uint32_t *id_negmin, uint32_t *id_base,
+                           Scalars *sc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long sum = 0;
+    uint32_t top = 0;
+    for (uint32_t c = 0; c < n_chr; ++c) {
+        id_base[c] = (uint32_t)min(sum, 0xFFFFFFFFull);
+        const uint32_t lo = ~id_negmin[c];
+        if ((id_max[c] | id_negmin[c]) != 0u) sum += (unsigned long long)(id_max[c] - lo) + 1ull;  // has entries
+        top = max(top, id_max[c]);
+    }
+    id_base[n_chr] = (uint32_t)min(sum, 0xFFFFFFFFull);
+    sc->id_space = sum;
+    sc->max_read_id = top;
+}
+
+// radix path: sort key (chromosome, read id) with the read id in id_bits bits
+__global__ void k_entry_keys(Raw in, const uint32_t *entry_locus, uint32_t id_bits, unsigned long long *key,
+                             uint32_t *val) {
     for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < in.n_entries; e += gridDim.x * TPB) {
-        // locus l with off[l] <= e < off[l+1]: the last offset <= e (empty loci share offsets; the
-        // last of them is the non-empty one)
-        const uint32_t l = last_le<uint64_t>(in.locus_entry_off, in.n_loci + 1, (uint64_t)e);
-        const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
-        entry_locus[e] = l;
-        key[e] = ((unsigned long long)c << 32) | in.read_ids[e];
+        const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, entry_locus[e]);
+        key[e] = ((unsigned long long)c << id_bits) | in.read_ids[e];
         val[e] = e;
+    }
+}
+
+// counting path, entries by (chromosome, read id) through the dense numbering
+__global__ void k_id_hist(Raw in, const uint32_t *entry_locus, const uint32_t *id_base, const uint32_t *id_negmin,
+                          uint32_t *dense, uint32_t *hist) {
+    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < in.n_entries; e += gridDim.x * TPB) {
+        const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, entry_locus[e]);
+        const uint32_t d = id_base[c] + (in.read_ids[e] - ~id_negmin[c]);
+        dense[e] = d;
+        atomicAdd(&hist[d], 1u);
+    }
+}
+
+__global__ void k_id_scatter(const uint32_t *dense, uint32_t n, const uint32_t *id_off, uint32_t *hist,
+                             uint32_t *grouped) {
+    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
+        const uint32_t d = dense[e];
+        grouped[id_off[d] + atomicSub(&hist[d], 1u) - 1u] = e;
+    }
+}
+
+// rank inside the read's group = number of its entries with a smaller index: the entries of a read
+// end up in pileup order (by locus), as a stable sort leaves them
+__global__ void k_id_rank(Raw in, const uint32_t *dense, const uint32_t *id_off, const uint32_t *grouped,
+                          unsigned long long *skey, uint32_t *sval, Scalars *sc) {
+    for (uint32_t p = blockIdx.x * TPB + threadIdx.x; p < in.n_entries; p += gridDim.x * TPB) {
+        const uint32_t e = grouped[p];
+        const uint32_t d = dense[e];
+        const uint32_t b = id_off[d], n = id_off[d + 1] - b;
+        uint32_t rank = p - b;
+        if (n > kRankScanLimit) {
+            sc->regroup = 1;
+        } else if (n > 1) {
+            rank = 0;
+            for (uint32_t q = b; q < b + n; ++q) rank += grouped[q] < e ? 1u : 0u;
+        }
+        skey[b + rank] = d;  // equal keys <=> same read; ascending in (chromosome, read id)
+        sval[b + rank] = e;
     }
 }
 
@@ -181,7 +296,9 @@ __global__ void k_read_off(const uint32_t *run_start, const uint32_t *slot, cons
     }
 }
 
-__global__ void k_multi(const uint32_t *read_off, const uint32_t *n_runs_p, Scalars *sc) {
+// entries of multi-locus reads (one atomic per workgroup: same-address atomics are slow)
+__global__ __launch_bounds__(TPB) void k_multi(const uint32_t *read_off, const uint32_t *n_runs_p, Scalars *sc) {
+    __shared__ unsigned long long part[TPB / 64];
     const uint32_t n_runs = *n_runs_p;
     unsigned long long local = 0;
     for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r < n_runs; r += gridDim.x * TPB) {
@@ -189,7 +306,13 @@ __global__ void k_multi(const uint32_t *read_off, const uint32_t *n_runs_p, Scal
         if (c > 1) local += c;
     }
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&sc->multi_entries, local);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long sum = 0;
+        for (int w = 0; w < TPB / 64; ++w) sum += part[w];
+        if (sum) atomicAdd(&sc->multi_entries, sum);
+    }
 }
 
 // appearance rank of each read; read starts in rank order; per chromosome the first rank
@@ -244,14 +367,26 @@ __global__ __launch_bounds__(TPB) void k_flush_chain(Raw in, const uint32_t *cnt
     if (threadIdx.x == 0) flushed_out[c] = s_flushed;
 }
 
+// The binning key: cell block | locus (lbits bits) | cell in block (7 bits) -- bit fields, so that
+// taking it apart costs shifts instead of 64-bit divisions.
+constexpr uint32_t kCibBits = 7;
+constexpr uint32_t kNoEntry = 0xFFFFFFFFu;
+__device__ __forceinline__ unsigned long long bin_key(uint32_t blk, uint32_t l, uint32_t cib, uint32_t lbits) {
+    return ((((unsigned long long)blk << lbits) | l) << kCibBits) | cib;
+}
+
 // binning key (cell block, locus, cell) of every kept entry, in per-read (CSR) order; validates the
 // group -> row mapping
 __global__ void k_keys2(Raw in, const uint32_t *sval, const uint32_t *keep, const uint32_t *slot,
                         const uint32_t *run_incl, const uint32_t *read_locus, uint32_t num_cells, uint32_t B,
-                        unsigned long long *key2, uint32_t *val2, uint32_t *t_read, Scalars *sc) {
-    const uint32_t n = in.n_entries, L = in.n_loci;
+                        uint32_t lbits, unsigned long long *key2, uint32_t *val2, uint32_t *t_read,
+                        uint32_t *entry_k, uint32_t *entry_cell, Scalars *sc) {
+    const uint32_t n = in.n_entries;
     for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
-        if (!keep[s]) continue;
+        if (!keep[s]) {
+            if (entry_k) entry_k[sval[s]] = kNoEntry;
+            continue;
+        }
         const uint32_t k = slot[s];
         const uint32_t group = in.id_base(sval[s]) >> 2;
         uint32_t cell = 0;
@@ -265,9 +400,125 @@ __global__ void k_keys2(Raw in, const uint32_t *sval, const uint32_t *keep, cons
             }
         }
         const uint32_t blk = cell / B, cib = cell - blk * B;
-        key2[k] = ((unsigned long long)blk * L + read_locus[k]) * B + cib;
+        key2[k] = bin_key(blk, read_locus[k], cib, lbits);
         val2[k] = k;
         t_read[k] = run_incl[s] - 1;
+        if (entry_k) {  // counting path: back in pileup order, where the entries of a locus are adjacent
+            entry_k[sval[s]] = k;
+            entry_cell[sval[s]] = (blk << kCibBits) | cib;
+        }
+    }
+}
+
+// counting path, kept entries by (cell block, locus). The entries of a locus are adjacent in the
+// pileup, so one wave per locus counts them per cell block in LDS and writes the locus' column of
+// the (block, locus) histogram with plain stores -- global atomics would all hit the handful of
+// addresses of the loci in flight.
+__global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, const uint32_t *entry_k,
+                                                 const uint32_t *entry_cell, uint32_t *blk_cnt) {
+    extern __shared__ uint32_t lds_hist[];
+    uint32_t *hist = lds_hist + (threadIdx.x >> 6) * nb;
+    const uint32_t lane = threadIdx.x & 63u, L = in.n_loci;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    for (uint32_t l = wave; l < L; l += n_waves) {
+        for (uint32_t b = lane; b < nb; b += 64u) hist[b] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
+        for (uint32_t e = e0 + lane; e < e1; e += 64u)
+            if (entry_k[e] != kNoEntry) atomicAdd(&hist[entry_cell[e] >> kCibBits], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t b = lane; b < nb; b += 64u) {
+            blk_cnt[(size_t)b * (L + 1) + l] = hist[b];
+            if (l == L - 1) blk_cnt[(size_t)b * (L + 1) + L] = 0;  // the closing slot of the block's row
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ... and places them: position = group offset + LDS cursor (arbitrary order inside the group).
+// grouped[pos] = cell-in-block << 32 | k, the final order inside a group being (cell, k)
+__global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, const uint32_t *entry_k,
+                                                  const uint32_t *entry_cell, const uint32_t *blk_off,
+                                                  unsigned long long *grouped) {
+    extern __shared__ uint32_t lds_hist[];
+    uint32_t *cursor = lds_hist + (threadIdx.x >> 6) * nb;
+    const uint32_t lane = threadIdx.x & 63u, L = in.n_loci;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    for (uint32_t l = wave; l < L; l += n_waves) {
+        for (uint32_t b = lane; b < nb; b += 64u) cursor[b] = blk_off[(size_t)b * (L + 1) + l];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
+        for (uint32_t e = e0 + lane; e < e1; e += 64u) {
+            const uint32_t k = entry_k[e];
+            if (k == kNoEntry) continue;
+            const uint32_t cc = entry_cell[e];
+            const uint32_t pos = atomicAdd(&cursor[cc >> kCibBits], 1u);
+            grouped[pos] = ((unsigned long long)(cc & ((1u << kCibBits) - 1u)) << 32) | k;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// rank inside the (block, locus) group by (cell, k) -> the order the binning sort gives; the first
+// entry of a cell at a locus also adds (entries of the cell at the locus)^2 to the cell's sum (the
+// Cauchy-Schwarz pair bound), through LDS: a workgroup's slice spans few cell blocks.
+__global__ __launch_bounds__(TPB) void k_bin_rank(const unsigned long long *key2, const unsigned long long *grouped,
+                                                 uint32_t n, uint32_t B, uint32_t L, uint32_t lbits,
+                                                 const uint32_t *blk_off, unsigned long long *skey2,
+                                                 uint32_t *sval2, unsigned long long *per_cell_sq, Scalars *sc) {
+    constexpr uint32_t SLOTS = 512;
+    __shared__ unsigned long long sq[SLOTS];
+    __shared__ uint32_t first_cell;
+    const uint32_t per_block = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t d0 = blockIdx.x * per_block, d1 = min(n, d0 + per_block);
+    for (uint32_t i = threadIdx.x; i < SLOTS; i += TPB) sq[i] = 0;
+    if (threadIdx.x == 0 && d0 < n) {
+        const unsigned long long key = key2[(uint32_t)grouped[d0]];
+        first_cell = (uint32_t)(key >> (kCibBits + lbits)) * B;
+    }
+    __syncthreads();
+    for (uint32_t p = d0 + threadIdx.x; p < d1; p += TPB) {
+        const unsigned long long mine = grouped[p];
+        const uint32_t k = (uint32_t)mine;
+        const unsigned long long key = key2[k];
+        const unsigned long long grp = key >> kCibBits;
+        const uint32_t blk = (uint32_t)(grp >> lbits), l = (uint32_t)grp & ((1u << lbits) - 1u);
+        const size_t g = (size_t)blk * (L + 1) + l;
+        const uint32_t b = blk_off[g], len = blk_off[g + 1] - b;
+        uint32_t rank = p - b, same = 1;
+        bool first = true;
+        if (len > kRankScanLimit) {
+            sc->regroup = 1;
+        } else if (len > 1) {
+            rank = 0;
+            same = 0;
+            for (uint32_t q = b; q < b + len; ++q) {
+                const unsigned long long other = grouped[q];
+                rank += other < mine ? 1u : 0u;
+                if ((other >> 32) == (mine >> 32)) {
+                    ++same;
+                    if (other < mine) first = false;
+                }
+            }
+        }
+        skey2[b + rank] = key;
+        sval2[b + rank] = k;
+        if (first) {
+            const uint32_t cell = blk * B + (uint32_t)(mine >> 32);
+            const uint32_t rel = cell - first_cell;
+            const unsigned long long v = (unsigned long long)same * same;
+            if (rel < SLOTS) atomicAdd(&sq[rel], v);
+            else atomicAdd(&per_cell_sq[cell], v);
+        }
+    }
+    __syncthreads();
+    if (d0 < n) {
+        for (uint32_t i = threadIdx.x; i < SLOTS; i += TPB) {
+            if (sq[i]) atomicAdd(&per_cell_sq[first_cell + i], sq[i]);
+        }
     }
 }
 
@@ -276,7 +527,7 @@ __global__ void k_keys2(Raw in, const uint32_t *sval, const uint32_t *keep, cons
 // Cauchy-Schwarz pair bound), accumulated in LDS per workgroup: a workgroup's slice of the sorted
 // order spans only a few cell blocks.
 __global__ __launch_bounds__(TPB) void k_group_counts(const unsigned long long *skey2, uint32_t n, uint32_t B,
-                                                     uint32_t L, uint32_t *blk_cnt,
+                                                     uint32_t L, uint32_t lbits, uint32_t *blk_cnt,
                                                      unsigned long long *per_cell_sq) {
     constexpr uint32_t SLOTS = 512;
     __shared__ unsigned long long sq[SLOTS];
@@ -286,22 +537,22 @@ __global__ __launch_bounds__(TPB) void k_group_counts(const unsigned long long *
     for (uint32_t i = threadIdx.x; i < SLOTS; i += TPB) sq[i] = 0;
     if (threadIdx.x == 0 && d0 < n) {
         const unsigned long long key = skey2[d0];
-        first_cell = (uint32_t)((key / B) / L) * B;  // first cell of the slice's first block
+        first_cell = (uint32_t)(key >> (kCibBits + lbits)) * B;  // first cell of the slice's first block
     }
     __syncthreads();
     for (uint32_t d = d0 + threadIdx.x; d < d1; d += TPB) {
         const unsigned long long key = skey2[d];
-        const unsigned long long grp = key / B;  // (block, locus)
-        if (d == 0 || skey2[d - 1] / B != grp) {
+        const unsigned long long grp = key >> kCibBits;  // (block, locus)
+        const uint32_t blk = (uint32_t)(grp >> lbits), l = (uint32_t)grp & ((1u << lbits) - 1u);
+        if (d == 0 || skey2[d - 1] >> kCibBits != grp) {
             uint32_t len = 1;
-            for (uint32_t t = d + 1; t < n && skey2[t] / B == grp; ++t) ++len;
-            const uint32_t blk = (uint32_t)(grp / L), l = (uint32_t)(grp % L);
+            for (uint32_t t = d + 1; t < n && skey2[t] >> kCibBits == grp; ++t) ++len;
             blk_cnt[(size_t)blk * (L + 1) + l] = len;
         }
         if (d == 0 || skey2[d - 1] != key) {
             unsigned long long cnt = 1;
             for (uint32_t t = d + 1; t < n && skey2[t] == key; ++t) ++cnt;
-            const uint32_t cell = (uint32_t)(grp / L) * B + (uint32_t)(key % B);
+            const uint32_t cell = blk * B + ((uint32_t)key & ((1u << kCibBits) - 1u));
             const uint32_t rel = cell - first_cell;
             if (rel < SLOTS) atomicAdd(&sq[rel], cnt * cnt);
             else atomicAdd(&per_cell_sq[cell], cnt * cnt);
@@ -327,11 +578,32 @@ __global__ void k_max_u64(const unsigned long long *a, uint32_t n, Scalars *sc) 
 // longest range from `s` in which no block has more than cap_entries entries (feasibility is
 // monotone in the range end; the search gallops from the previous range's length); a locus that
 // exceeds the cap alone becomes a single-locus range. k_ranges_compact concatenates the segments.
+//
+// The staging limits depend on the tile variant, and the tile variant on the pair bound, which is
+// still on the device: the kernels pick the limits themselves (CapChoice), the host learns the
+// outcome with the final read-back.
+struct CapChoice {
+    uint32_t entries_plain, loci_plain;    // int64 tile (or the masks variant)
+    uint32_t entries_counts, loci_counts;  // count tile
+    unsigned long long count_limit;        // count tile iff allow_counts and pair bound < count_limit
+    uint32_t allow_counts;
+    __device__ __forceinline__ bool counts(const Scalars *sc) const {
+        return allow_counts && sc->pair_bound < count_limit;
+    }
+};
+
 __global__ __launch_bounds__(TPB) void k_ranges_segment(const uint32_t *blk_off, uint32_t nb, uint32_t L,
-                                                       uint32_t cap_entries, uint32_t cap_loci,
+                                                       CapChoice caps, const Scalars *sc,
                                                        uint32_t *seg_ends, uint32_t *seg_count) {
+    const bool use_counts = caps.counts(sc);
+    const uint32_t cap_entries = use_counts ? caps.entries_counts : caps.entries_plain;
+    const uint32_t cap_loci = use_counts ? caps.loci_counts : caps.loci_plain;
     const size_t stride = (size_t)L + 1;
     const uint32_t seg = blockIdx.x;
+    if ((unsigned long long)seg * cap_loci >= L) {  // the grid is sized for the smaller of the two limits
+        if (threadIdx.x == 0) seg_count[seg] = 0;
+        return;
+    }
     const uint32_t seg_begin = seg * cap_loci, seg_end = min(L, seg_begin + cap_loci);
     uint32_t *ends = seg_ends + (size_t)seg * cap_loci;  // at most cap_loci ranges per segment
     uint32_t s = seg_begin, nr = 0, guess = 0;
@@ -387,8 +659,9 @@ __global__ __launch_bounds__(TPB) void k_ranges_segment(const uint32_t *blk_off,
 }
 
 __global__ __launch_bounds__(TPB) void k_ranges_compact(const uint32_t *seg_ends, const uint32_t *seg_count,
-                                                       uint32_t n_seg, uint32_t cap_loci, uint32_t *range_off,
+                                                       uint32_t n_seg, CapChoice caps, uint32_t *range_off,
                                                        Scalars *sc) {
+    const uint32_t cap_loci = caps.counts(sc) ? caps.loci_counts : caps.loci_plain;
     __shared__ uint32_t s_base;
     if (threadIdx.x == 0) {
         s_base = 0;
@@ -410,15 +683,14 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
                           const uint32_t *t_read, const uint32_t *read_off, const uint32_t *read_locus,
                           const uint8_t *read_base, const uint32_t *run_rank, const uint32_t *rbeg,
                           const uint32_t *flushed, const uint32_t *range_off, const Scalars *sc, uint32_t B,
-                          uint4 *entry, uint32_t *entry32, uint32_t *mask32, uint32_t *entry_read) {
-    const uint32_t L = in.n_loci;
+                          uint32_t lbits, uint4 *entry, uint32_t *entry32, uint32_t *mask32, uint32_t *entry_read) {
     const uint32_t n_ranges = sc->num_ranges;
     for (uint32_t d = blockIdx.x * TPB + threadIdx.x; d < n; d += gridDim.x * TPB) {
         const unsigned long long key = skey2[d];
         const uint32_t k = sval2[d];
-        const uint32_t cib = (uint32_t)(key % B);
-        const unsigned long long grp = key / B;
-        const uint32_t blk = (uint32_t)(grp / L), l = (uint32_t)(grp % L);
+        const uint32_t cib = (uint32_t)key & ((1u << kCibBits) - 1u);
+        const unsigned long long grp = key >> kCibBits;
+        const uint32_t blk = (uint32_t)(grp >> lbits), l = (uint32_t)grp & ((1u << lbits) - 1u);
         const uint32_t cell = blk * B + cib;
         const uint32_t r = t_read[k];
         const uint32_t lo = read_off[r], hi = read_off[r + 1];
@@ -470,51 +742,45 @@ int bits_for(unsigned long long max_value) {
         if (e__ != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(e__); \
     } while (0)
 
-}  // namespace
-
-std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, uint32_t mfl,
-                               uint32_t num_threads, uint32_t block_cells,
-                               StageGeometry (*geometry)(uint32_t), bool allow_count_tile,
-                               hipStream_t stream, DevicePacked *out, bool *need_host) {
-    *need_host = false;
-    if ((in.id_base16 != nullptr) == (in.id_base32 != nullptr))
-        return "exactly one of id_base16 / id_base32 must be given";
-    if (num_threads == 0) return "num_threads must be positive";
-    if (num_cells == 0 || num_cells > 65535) return "num_cells must be in [1, 65535]";
-    if (block_cells != 0 && block_cells != 64 && block_cells != 128) return "block_cells must be 0, 64 or 128";
-    const uint64_t E64 = in.n_entries;
+// One attempt at the pipeline. With force_radix == false the two groupings (entries by read,
+// kept entries by (cell block, locus)) use the counting scheme when its preconditions hold; a group
+// too long for it sets *retry and the caller runs the attempt again with the radix sorts.
+std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_t mfl, uint32_t num_threads,
+                         uint32_t block_cells, StageGeometry (*geometry)(uint32_t), bool allow_count_tile,
+                         bool force_radix, hipStream_t stream, DevicePacked *out, bool *need_host,
+                         bool *retry) {
+    *retry = false;
+    const uint32_t E = static_cast<uint32_t>(in.n_entries);
     const uint32_t L = in.n_loci, C = in.n_chr;
-    if (E64 >= (1ull << 31) || L == 0 || E64 == 0 || (uint64_t)4 * num_threads > 0xFFFFFFFFull) {
-        *need_host = true;  // sizes this path does not cover (incl. the empty pileup)
-        return std::string();
-    }
-    const uint32_t E = static_cast<uint32_t>(E64);
     DevicePacked &pk = *out;
     // worst-case block count (64-cell blocks) for buffers sized before the tile size is chosen
     const size_t n_off_max = (size_t)((num_cells + 63) / 64) * ((size_t)L + 1);
-    if (n_off_max >= (1ull << 31)) {
-        *need_host = true;
-        return std::string();
-    }
     enum { KEY_A, KEY_B, VAL_A, VAL_B, ELOC, WORK_A, WORK_B, RUNS, CUB, TMP, MISC, BIN };
     auto &S = pk.scratch;
+    // the counting scheme for read ids needs a table over the id space
+    const size_t id_space_cap = std::min<size_t>((size_t)kIdSpaceFactor * E + 1024, (size_t)1 << 30);
 
     Raw raw{in.chr_locus_off, C, in.locus_pos, in.locus_entry_off, in.read_ids, in.id_base16,
             in.id_base32, in.group_id_to_pos, in.n_groups, L, E};
 
     // ---- buffers (sized up front: a re-allocation in mid-pipeline would synchronise) -----------
-    // MISC: Scalars | rbeg[C+1] | flushed[C] | cnt[L]
-    HIP_OK(S[MISC].ensure(sizeof(Scalars) + sizeof(uint32_t) * ((size_t)2 * C + 2 + L) + 64));
+    // MISC: Scalars | id_max[C] | id_negmin[C] | id_base[C+1] | rbeg[C+1] | flushed[C] | cnt[L]
+    HIP_OK(S[MISC].ensure(sizeof(Scalars) + sizeof(uint32_t) * ((size_t)5 * C + 4 + L) + 64));
     Scalars *sc = S[MISC].as<Scalars>();
-    uint32_t *rbeg = reinterpret_cast<uint32_t *>(sc + 1);
+    uint32_t *id_max = reinterpret_cast<uint32_t *>(sc + 1);
+    uint32_t *id_negmin = id_max + C;
+    uint32_t *id_base = id_negmin + C;
+    uint32_t *rbeg = id_base + C + 1;
     uint32_t *flushed = rbeg + C + 1;
     uint32_t *cnt = flushed + C;
     // KEY_A: sort keys in, later mark[E+1] | arank[E+1], later the per-(block, locus) counts
     HIP_OK(S[KEY_A].ensure(std::max<size_t>({(size_t)E * 8, ((size_t)2 * E + 4) * 4, (n_off_max + 1) * 4})));
+    // KEY_B: sorted keys, later (counting path) the kept entries grouped by (block, locus)
     HIP_OK(S[KEY_B].ensure((size_t)E * 8));
     HIP_OK(S[VAL_A].ensure((size_t)E * 4));
     HIP_OK(S[VAL_B].ensure((size_t)E * 4));
-    HIP_OK(S[ELOC].ensure(std::max<size_t>((size_t)E * 4, ((size_t)L + 8192 + L / 64 + 16) * 4)));
+    // ELOC: entry -> locus, later the range segments (count[n_seg] | ends[n_seg * cap_loci])
+    HIP_OK(S[ELOC].ensure(std::max<size_t>((size_t)E * 4, ((size_t)2 * L + 4 * 8192 + L / 64 + 16) * 4)));
     HIP_OK(S[WORK_A].ensure(((size_t)E + 1) * 4));
     HIP_OK(S[WORK_B].ensure(((size_t)E + 1) * 4));
     // RUNS: run_start[R+1] | first_entry[R] | start_pos[R] | run_rank[R] | starts_by_rank[R], R <= E
@@ -525,27 +791,53 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     unsigned long long *key_a = S[KEY_A].as<unsigned long long>(), *key_b = S[KEY_B].as<unsigned long long>();
     uint32_t *val_a = S[VAL_A].as<uint32_t>(), *val_b = S[VAL_B].as<uint32_t>();
     uint32_t *eloc = S[ELOC].as<uint32_t>();
-    uint32_t *work_a = S[WORK_A].as<uint32_t>(), *work_b = S[WORK_B].as<uint32_t>();
     {
         size_t need = 0, most = 0;
         HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, key_a, key_b, val_a, val_b, (int)E, 0, 64, stream));
         most = std::max(most, need);
-        HIP_OK(hipcub::DeviceScan::InclusiveSum(nullptr, need, work_a, work_b, (int)E + 1, stream));
+        HIP_OK(hipcub::DeviceScan::InclusiveSum(nullptr, need, val_a, val_b, (int)E + 1, stream));
         most = std::max(most, need);
-        HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, work_a, work_b, (int)n_off_max, stream));
+        HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, val_a, val_b,
+                                                (int)std::max<size_t>(n_off_max, id_space_cap + 2), stream));
         most = std::max(most, need);
         HIP_OK(S[CUB].ensure(most + 1024));
     }
     void *cub_tmp = S[CUB].p;
     size_t cub_cap = 0;
-    HIP_OK(hipMemsetAsync(sc, 0, sizeof(Scalars), stream));
+    HIP_OK(hipMemsetAsync(sc, 0, sizeof(Scalars) + sizeof(uint32_t) * ((size_t)3 * C + 1), stream));
 
-    // ---- 1: keys + stable sort by (chromosome, read id) -------------------------------------
+    // ---- 1: entries grouped by (chromosome, read id), pileup order inside a read ---------------
     hipLaunchKernelGGL(k_check_positions, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, sc);
-    hipLaunchKernelGGL(k_entry_keys, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, key_a, val_a);
-    cub_cap = S[CUB].bytes;
-    HIP_OK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_cap, key_a, key_b, val_a, val_b, (int)E, 0,
-                                               32 + bits_for(C), stream));
+    hipLaunchKernelGGL(k_entry_locus, dim3(std::min<uint32_t>(blocks_for((uint64_t)L * 64), 2048)), dim3(TPB), 0,
+                       stream, raw, eloc, id_max, id_negmin);
+    hipLaunchKernelGGL(k_id_bases, dim3(1), dim3(64), 0, stream, C, id_max, id_negmin, id_base, sc);
+    Scalars hsc;
+    HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));  // read-back 1: the largest read id (size of the id space)
+    if (hsc.error == 3) return "positions must be strictly increasing within a chromosome";
+    const size_t id_space = (size_t)std::min<unsigned long long>(hsc.id_space, 1ull << 40);
+    const bool counting = !force_radix && id_space <= id_space_cap;
+    HIP_OK(S[WORK_A].ensure(std::max<size_t>((size_t)E + 1, counting ? id_space + 1 : 0) * 4));
+    HIP_OK(S[WORK_B].ensure(std::max<size_t>((size_t)E + 1, counting ? id_space + 1 : 0) * 4));
+    uint32_t *work_a = S[WORK_A].as<uint32_t>(), *work_b = S[WORK_B].as<uint32_t>();
+    if (counting) {
+        uint32_t *hist = work_a, *id_off = work_b, *grouped = val_a;
+        uint32_t *dense = S[KEY_A].as<uint32_t>();  // the radix path's unsorted keys live here
+        HIP_OK(hipMemsetAsync(hist, 0, (id_space + 1) * 4, stream));
+        hipLaunchKernelGGL(k_id_hist, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_base, id_negmin, dense,
+                           hist);
+        cub_cap = S[CUB].bytes;
+        HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, hist, id_off, (int)(id_space + 1), stream));
+        hipLaunchKernelGGL(k_id_scatter, dim3(blocks_for(E)), dim3(TPB), 0, stream, dense, E, id_off, hist, grouped);
+        hipLaunchKernelGGL(k_id_rank, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, dense, id_off, grouped, key_b,
+                           val_b, sc);
+    } else {
+        const uint32_t id_bits = (uint32_t)bits_for(hsc.max_read_id);
+        hipLaunchKernelGGL(k_entry_keys, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_bits, key_a, val_a);
+        cub_cap = S[CUB].bytes;
+        HIP_OK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_cap, key_a, key_b, val_a, val_b, (int)E, 0,
+                                                   (int)id_bits + bits_for(C), stream));
+    }
     const unsigned long long *skey = key_b;
     const uint32_t *sval = val_b;
 
@@ -588,7 +880,7 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     uint8_t *read_base = pk.read_base.as<uint8_t>();
     hipLaunchKernelGGL(k_csr, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, eloc, keep, slot, E, read_locus, read_base);
     hipLaunchKernelGGL(k_read_off, dim3(blocks_for(E)), dim3(TPB), 0, stream, run_start, slot, keep, d_R, E, read_off);
-    hipLaunchKernelGGL(k_multi, dim3(blocks_for(E)), dim3(TPB), 0, stream, read_off, d_R, sc);
+    hipLaunchKernelGGL(k_multi, dim3(std::min<uint32_t>(blocks_for(E), 1024)), dim3(TPB), 0, stream, read_off, d_R, sc);
 
     // ---- 4: appearance ranks, completed counts, flush chain ----------------------------------
     hipLaunchKernelGGL(k_ranks, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, first_entry, start_pos, arank, d_R,
@@ -596,15 +888,17 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, starts_by_rank, rbeg, mfl, cnt);
     hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, stream, raw, cnt, 4u * num_threads, flushed);
 
-    // the one mid-pipeline read-back: status flags, R, number of kept entries, multi-locus statistics
+    // read-back 2: status flags, R, number of kept entries, multi-locus statistics
     uint32_t R = 0, last_slot = 0, last_keep = 0;
-    Scalars hsc;
     HIP_OK(hipMemcpyAsync(&R, d_R, 4, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipMemcpyAsync(&last_slot, slot + (E - 1), 4, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipMemcpyAsync(&last_keep, keep + (E - 1), 4, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
-    if (hsc.error == 3) return "positions must be strictly increasing within a chromosome";
+    if (hsc.regroup) {
+        *retry = true;
+        return std::string();
+    }
     if (hsc.need_host) {
         *need_host = true;
         return std::string();
@@ -619,6 +913,7 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     }
     const StageGeometry geo = geometry(block_cells);
     const uint32_t B = block_cells, nb = (num_cells + B - 1) / B;
+    const uint32_t lbits = (uint32_t)bits_for(L - 1);
     pk.num_cells = num_cells;
     pk.block_cells = B;
     pk.num_blocks = nb;
@@ -627,7 +922,7 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     pk.num_reads = R;
     pk.stage_masks = n_kept && (double)pk.multi_entries > geo.masks_threshold * (double)n_kept;
 
-    // ---- 5: binning sort, offsets, bound, ranges, records ---------------------------------------
+    // ---- 5: kept entries grouped by (cell block, locus, cell), offsets, bound, ranges, records ----
     uint32_t *t_read = S[TMP].as<uint32_t>();
     unsigned long long *key2_a = S[BIN].as<unsigned long long>();
     unsigned long long *key2_b = key2_a + nk;
@@ -637,51 +932,113 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     const size_t n_off = (size_t)nb * ((size_t)L + 1);
     uint32_t *blk_off = pk.blk_off.as<uint32_t>();
     uint32_t *blk_cnt = S[KEY_A].as<uint32_t>();  // mark / arank are dead after k_ranks
-    HIP_OK(hipMemsetAsync(blk_cnt, 0, (n_off + 1) * 4, stream));
+    // counting path: per pileup entry its k and cell (entry -> locus and the per-read scratch are dead)
+    uint32_t *entry_k = force_radix ? nullptr : eloc;
+    uint32_t *entry_cell = force_radix ? nullptr : first_entry;
+    if (force_radix) HIP_OK(hipMemsetAsync(blk_cnt, 0, (n_off + 1) * 4, stream));
     HIP_OK(hipMemsetAsync(per_cell_sq, 0, ((size_t)nb * B + 1) * 8, stream));
     hipLaunchKernelGGL(k_keys2, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, keep, slot, run_incl,
-                       read_locus, num_cells, B, key2_a, val2_a, t_read, sc);
-    if (n_kept) {
+                       read_locus, num_cells, B, lbits, key2_a, val2_a, t_read, entry_k, entry_cell, sc);
+    const uint32_t slice_grid = std::min<uint32_t>(2048, (n_kept + 4095) / 4096);
+    if (force_radix) {
+        if (n_kept) {
+            cub_cap = S[CUB].bytes;
+            HIP_OK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_cap, key2_a, key2_b, val2_a, val2_b, (int)n_kept,
+                                                       0, (int)(kCibBits + lbits) + bits_for(nb - 1), stream));
+            hipLaunchKernelGGL(k_group_counts, dim3(slice_grid), dim3(TPB), 0, stream, key2_b, n_kept, B, L, lbits,
+                               blk_cnt, per_cell_sq);
+        }
         cub_cap = S[CUB].bytes;
-        HIP_OK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_cap, key2_a, key2_b, val2_a, val2_b, (int)n_kept, 0,
-                                                   bits_for(((unsigned long long)nb * L + L) * B + B), stream));
-        hipLaunchKernelGGL(k_group_counts, dim3(std::min<uint32_t>(2048, (n_kept + 4095) / 4096)), dim3(TPB), 0,
-                           stream, key2_b, n_kept, B, L, blk_cnt, per_cell_sq);
-        hipLaunchKernelGGL(k_max_u64, dim3(blocks_for((size_t)nb * B)), dim3(TPB), 0, stream, per_cell_sq, nb * B, sc);
+        HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
+    } else {
+        const uint32_t locus_grid = std::min<uint32_t>(blocks_for((uint64_t)L * 64), 8192);
+        const size_t lds = (size_t)(TPB / 64) * nb * 4;
+        hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_k, entry_cell, blk_cnt);
+        cub_cap = S[CUB].bytes;
+        HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
+        if (n_kept) {
+            unsigned long long *grouped = key_b;  // the sorted entry keys are dead after k_dup_rule
+            hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_k, entry_cell,
+                               blk_off, grouped);
+            hipLaunchKernelGGL(k_bin_rank, dim3(slice_grid), dim3(TPB), 0, stream, key2_a, grouped, n_kept, B, L,
+                               lbits, blk_off, key2_b, val2_b, per_cell_sq, sc);
+        }
     }
-    cub_cap = S[CUB].bytes;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
+    if (n_kept)
+        hipLaunchKernelGGL(k_max_u64, dim3(blocks_for((size_t)nb * B)), dim3(TPB), 0, stream, per_cell_sq, nb * B, sc);
     // the pair bound decides the tile variant, and the tile variant the staging limits of the ranges
-    HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));
-    if (hsc.error == 1) return "group id outside group_id_to_pos";
-    if (hsc.error == 2) return "group_id_to_pos maps outside the matrix";
-    pk.pair_bound = hsc.pair_bound;
-    pk.count_tile = allow_count_tile && !pk.stage_masks && pk.pair_bound < kCountTileLimit;
-    pk.cap_entries = pk.stage_masks ? geo.cap_entries_masks : pk.count_tile ? geo.cap_entries_counts : geo.cap_entries_plain;
-    pk.cap_loci = pk.stage_masks ? geo.cap_loci_masks : pk.count_tile ? geo.cap_loci_counts : geo.cap_loci_plain;
+    CapChoice caps;
+    caps.entries_plain = pk.stage_masks ? geo.cap_entries_masks : geo.cap_entries_plain;
+    caps.loci_plain = pk.stage_masks ? geo.cap_loci_masks : geo.cap_loci_plain;
+    caps.entries_counts = geo.cap_entries_counts;
+    caps.loci_counts = geo.cap_loci_counts;
+    caps.count_limit = kCountTileLimit;
+    caps.allow_counts = (allow_count_tile && !pk.stage_masks) ? 1u : 0u;
     {
-        const uint32_t n_seg = (L + pk.cap_loci - 1) / pk.cap_loci;
-        // segment scratch: ends[n_seg * cap_loci] | count[n_seg], in ELOC (entry_locus is dead after k_csr)
-        HIP_OK(S[ELOC].ensure(std::max<size_t>((size_t)E * 4, ((size_t)n_seg * pk.cap_loci + n_seg + 2) * 4)));
-        uint32_t *seg_ends = S[ELOC].as<uint32_t>();
-        uint32_t *seg_count = seg_ends + (size_t)n_seg * pk.cap_loci;
-        hipLaunchKernelGGL(k_ranges_segment, dim3(n_seg), dim3(TPB), 0, stream, blk_off, nb, L, pk.cap_entries,
-                           pk.cap_loci, seg_ends, seg_count);
-        hipLaunchKernelGGL(k_ranges_compact, dim3(1), dim3(TPB), 0, stream, seg_ends, seg_count, n_seg, pk.cap_loci,
+        const uint32_t lo_loci = caps.allow_counts ? std::min(caps.loci_plain, caps.loci_counts) : caps.loci_plain;
+        const uint32_t hi_loci = caps.allow_counts ? std::max(caps.loci_plain, caps.loci_counts) : caps.loci_plain;
+        const uint32_t n_seg = (L + lo_loci - 1) / lo_loci;
+        HIP_OK(S[ELOC].ensure(std::max<size_t>((size_t)E * 4, ((size_t)n_seg * hi_loci + n_seg + 2) * 4)));
+        uint32_t *seg_count = S[ELOC].as<uint32_t>();  // entry -> locus is dead after k_csr
+        uint32_t *seg_ends = seg_count + n_seg;
+        hipLaunchKernelGGL(k_ranges_segment, dim3(n_seg), dim3(TPB), 0, stream, blk_off, nb, L, caps, sc, seg_ends,
+                           seg_count);
+        hipLaunchKernelGGL(k_ranges_compact, dim3(1), dim3(TPB), 0, stream, seg_ends, seg_count, n_seg, caps,
                            pk.range_off.as<uint32_t>(), sc);
     }
     if (n_kept) {
         hipLaunchKernelGGL(k_records, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, raw, key2_b, val2_b, n_kept,
                            t_read, read_off, read_locus, read_base, run_rank, rbeg, flushed,
-                           pk.range_off.as<uint32_t>(), sc, B, pk.entry.as<uint4>(),
+                           pk.range_off.as<uint32_t>(), sc, B, lbits, pk.entry.as<uint4>(),
                            pk.entry32.as<uint32_t>(), pk.mask32.as<uint32_t>(), pk.entry_read.as<uint32_t>());
     }
+    // read-back 3: errors of the group mapping, pair bound (-> tile variant), number of ranges
     HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
+    if (hsc.error == 1) return "group id outside group_id_to_pos";
+    if (hsc.error == 2) return "group_id_to_pos maps outside the matrix";
+    if (hsc.regroup) {
+        *retry = true;
+        return std::string();
+    }
+    pk.pair_bound = hsc.pair_bound;
+    pk.count_tile = caps.allow_counts && pk.pair_bound < kCountTileLimit;
+    pk.cap_entries = pk.count_tile ? caps.entries_counts : caps.entries_plain;
+    pk.cap_loci = pk.count_tile ? caps.loci_counts : caps.loci_plain;
     pk.num_ranges = hsc.num_ranges;
     HIP_OK(hipGetLastError());
     return std::string();
+}
+
+}  // namespace
+
+std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, uint32_t mfl,
+                               uint32_t num_threads, uint32_t block_cells,
+                               StageGeometry (*geometry)(uint32_t), bool allow_count_tile,
+                               hipStream_t stream, DevicePacked *out, bool *need_host) {
+    *need_host = false;
+    if ((in.id_base16 != nullptr) == (in.id_base32 != nullptr))
+        return "exactly one of id_base16 / id_base32 must be given";
+    if (num_threads == 0) return "num_threads must be positive";
+    if (num_cells == 0 || num_cells > 65535) return "num_cells must be in [1, 65535]";
+    if (block_cells != 0 && block_cells != 64 && block_cells != 128) return "block_cells must be 0, 64 or 128";
+    const uint64_t E64 = in.n_entries;
+    const uint32_t L = in.n_loci;
+    const size_t n_off_max = (size_t)((num_cells + 63) / 64) * ((size_t)L + 1);
+    if (E64 >= (1ull << 31) || L == 0 || E64 == 0 || (uint64_t)4 * num_threads > 0xFFFFFFFFull
+        || n_off_max >= (1ull << 31)) {
+        *need_host = true;  // sizes this path does not cover (incl. the empty pileup)
+        return std::string();
+    }
+    bool force_radix = false;
+    if (const char *env = std::getenv("SECEDO_PACK_GROUPING")) force_radix = std::string(env) == "radix";
+    bool retry = false;
+    std::string err = pack_attempt(in, num_cells, mfl, num_threads, block_cells, geometry, allow_count_tile,
+                                   force_radix, stream, out, need_host, &retry);
+    if (err.empty() && retry)
+        err = pack_attempt(in, num_cells, mfl, num_threads, block_cells, geometry, allow_count_tile, true, stream,
+                           out, need_host, &retry);
+    return err;
 }
 
 }  // namespace secedo

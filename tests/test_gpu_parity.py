@@ -162,13 +162,16 @@ PACK_CASES = [
 ]
 
 
+@pytest.mark.parametrize("grouping", ["counting", "radix"])
 @pytest.mark.parametrize("seed,n,nchr,L,cov,gap,mfl,T,block", PACK_CASES)
-def test_device_packing_equals_host_packing(seed, n, nchr, L, cov, gap, mfl, T, block):
-    """The GPU packing pipeline (sort by read, duplicate rule, flush chain, masks, binning) must give
-    the same work counters and a bit-identical matrix as the sequential host emulation. (The raw
-    accumulators may differ inside diagonal tiles, where a pair lands at [r][c] or [c][r] depending on
-    the entry order inside a locus; finalize adds the two.)"""
+def test_device_packing_equals_host_packing(seed, n, nchr, L, cov, gap, mfl, T, block, grouping, monkeypatch):
+    """The GPU packing pipeline (grouping by read, duplicate rule, flush chain, masks, binning) must
+    give the same work counters and a bit-identical matrix as the sequential host emulation, with
+    either grouping scheme (histogram + scatter + in-group ranking, or the radix sorts it falls back
+    to). (The raw accumulators may differ inside diagonal tiles, where a pair lands at [r][c] or
+    [c][r] depending on the entry order inside a locus; finalize adds the two.)"""
     import torch
+    monkeypatch.setenv("SECEDO_PACK_GROUPING", grouping)
     fmax = 500 if gap < 20 else 600
     p = random_pileup(seed, n, nchr, L, cov, gap, frag_max=fmax, dup_frac=0.06, triple_frac=0.4,
                       skip_frac=0.1, n_groups=n + 3)
@@ -267,6 +270,52 @@ def test_very_deep_loci_unstaged_ranges():
         acc = plan.new_acc()
         plan.accumulate(acc, 0.01, 0.5, 0.01)
         assert plan.last_counts() == (u_ref, pairs_ref)
+
+
+def test_device_grouping_fallbacks():
+    """The counting scheme of the device packing gives way to the radix sorts when (a) the read ids
+    are sparse (id space > 4 x entries), (b) one read id has more entries than the in-group ranking
+    scans (8192), (c) one (cell block, locus) group is that long. All three must still match the
+    oracle and the host packing."""
+    rng = np.random.default_rng(91)
+    n = 40
+
+    def rows_with(deep_locus_cov, repeated_id_count, id_stride):
+        rows, rid, pos = [], 0, 500
+        for l in range(60):
+            pos += int(rng.integers(30, 300))
+            cov = deep_locus_cov if l == 20 else int(rng.integers(10, 80))
+            ents = []
+            for _ in range(cov):
+                ents.append((rid * id_stride, int(rng.integers(0, n)), int(rng.integers(0, 4))))
+                rid += 1
+            if l == 30:
+                # one read id over and over at one locus: the duplicate rule (:387-395) eats them in
+                # pairs/triples, the grouping still has to order them
+                ents += [(rid * id_stride, 3, int(rng.integers(0, 4))) for _ in range(repeated_id_count)]
+                rid += 1
+            rows.append((pos, ents))
+        for k in range(4):
+            pos += 3000
+            rows.append((pos, [((rid + k) * id_stride, 0, 0)]))
+        return from_rows([rows])
+
+    for deep, rep, stride in ((50, 0, 1000), (50, 9000, 1), (9000, 0, 1)):
+        p = rows_with(deep, rep, stride)
+        ref = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 2, "ADD_MIN")
+        u_ref, pairs_ref = ob.oracle_last_updates(), ob.oracle_last_read_pairs()
+        mats = []
+        for mode in ("host", "device"):
+            with secedo_amd.SimilarityMatrixPlan(0) as plan:
+                plan.set_packing(mode)
+                plan.prepare(p, n, 1000, None, 2)
+                assert plan.used_device_packing == (mode == "device")
+                acc = plan.new_acc()
+                plan.accumulate(acc, 0.01, 0.5, 0.01)
+                assert plan.last_counts() == (u_ref, pairs_ref)
+                mats.append(plan.finalize(acc, "ADD_MIN").cpu().numpy())
+        assert np.array_equal(mats[0], mats[1])
+        assert gu.normwise_err(mats[1], ref) <= 5e-8
 
 
 def test_randomised_differential_sweep():
