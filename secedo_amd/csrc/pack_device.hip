@@ -24,6 +24,12 @@ DeviceArena::~DeviceArena() {
     if (p) (void)hipFree(p);
 }
 
+DevicePacked::~DevicePacked() {
+    if (side) (void)hipStreamDestroy(side);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+}
+
 hipError_t DeviceArena::ensure(size_t n) {
     if (n <= bytes && p) return hipSuccess;
     if (p) (void)hipFree(p);
@@ -104,50 +110,63 @@ __device__ __forceinline__ uint32_t count_le(const uint32_t *a, uint32_t n, uint
     return lo;
 }
 
-// entry -> locus, one wave per locus (coalesced; empty loci cost nothing), and per chromosome the
-// largest and smallest read id (the latter as max of ~id, so that zero-filled memory is the neutral
-// element). A wave owns a contiguous slice of loci, so it meets few chromosomes: one pair of
-// atomics per (wave, chromosome).
-__global__ __launch_bounds__(TPB) void k_entry_locus(Raw in, uint32_t *entry_locus, uint32_t *id_max,
-                                                    uint32_t *id_negmin) {
+// entry -> locus, one wave per locus (coalesced; empty loci cost nothing)
+__global__ __launch_bounds__(TPB) void k_entry_locus(Raw in, uint32_t *entry_locus) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
-    const uint32_t per = (in.n_loci + n_waves - 1) / n_waves;
-    const uint32_t l0 = min(in.n_loci, wave * per), l1 = min(in.n_loci, l0 + per);
-    if (l0 >= l1) return;
-    uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l0);
-    uint32_t c_end = in.chr_locus_off[c + 1];
-    uint32_t hi = 0, neg = 0;
-    bool any = false;
-    auto flush = [&]() {
+    for (uint32_t l = wave; l < in.n_loci; l += n_waves) {
+        const uint32_t b = (uint32_t)in.locus_entry_off[l], e = (uint32_t)in.locus_entry_off[l + 1];
+        for (uint32_t i = b + lane; i < e; i += 64u) entry_locus[i] = l;
+    }
+}
+
+// per chromosome the largest and the smallest read id (the latter as max of ~id, so that zero-filled
+// memory is the neutral element). A workgroup owns a contiguous chunk of entries and cuts it at the
+// chromosome boundaries: one pair of atomics per (workgroup, chromosome) -- same-address atomics
+// are slow.
+__global__ __launch_bounds__(TPB) void k_id_range(Raw in, uint32_t *id_max, uint32_t *id_negmin) {
+    __shared__ uint32_t s_hi[TPB / 64], s_neg[TPB / 64];
+    const uint32_t E = in.n_entries;
+    const uint32_t chunk = (E + gridDim.x - 1) / gridDim.x;
+    uint32_t cur = min(E, blockIdx.x * chunk);
+    const uint32_t e1 = min(E, cur + chunk);
+    if (cur >= e1) return;
+    uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1,
+                                   last_le<uint64_t>(in.locus_entry_off, in.n_loci + 1, (uint64_t)cur));
+    while (cur < e1) {
+        // entries of chromosome c end where its last locus ends (skip chromosomes without entries)
+        uint32_t c_end = (uint32_t)in.locus_entry_off[in.chr_locus_off[c + 1]];
+        while (c_end <= cur && c + 1 < in.n_chr) {
+            ++c;
+            c_end = (uint32_t)in.locus_entry_off[in.chr_locus_off[c + 1]];
+        }
+        const uint32_t seg_end = (c + 1 < in.n_chr) ? min(e1, c_end) : e1;
+        uint32_t hi = 0, neg = 0;
+        for (uint32_t e = cur + threadIdx.x; e < seg_end; e += TPB) {
+            const uint32_t id = in.read_ids[e];
+            hi = max(hi, id);
+            neg = max(neg, ~id);
+        }
         for (int off = 32; off > 0; off >>= 1) {
             hi = max(hi, (uint32_t)__shfl_down(hi, off));
             neg = max(neg, (uint32_t)__shfl_down(neg, off));
         }
-        if (lane == 0) {
+        __syncthreads();  // the previous segment's partials have been read
+        if ((threadIdx.x & 63u) == 0) {
+            s_hi[threadIdx.x >> 6] = hi;
+            s_neg[threadIdx.x >> 6] = neg;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < TPB / 64; ++w) {
+                hi = max(hi, s_hi[w]);
+                neg = max(neg, s_neg[w]);
+            }
             atomicMax(&id_max[c], hi);
             atomicMax(&id_negmin[c], neg);
         }
-        hi = 0;
-        neg = 0;
-        any = false;
-    };
-    for (uint32_t l = l0; l < l1; ++l) {
-        if (l >= c_end) {
-            if (__any(any)) flush();
-            c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
-            c_end = in.chr_locus_off[c + 1];
-        }
-        const uint32_t b = (uint32_t)in.locus_entry_off[l], e = (uint32_t)in.locus_entry_off[l + 1];
-        for (uint32_t i = b + lane; i < e; i += 64u) {
-            entry_locus[i] = l;
-            const uint32_t id = in.read_ids[i];
-            hi = max(hi, id);
-            neg = max(neg, ~id);
-            any = true;
-        }
+        cur = seg_end;
     }
-    if (__any(any)) flush();
 }
 
 // dense numbering of (chromosome, read id): id_base[c] + id - smallest id of c
@@ -465,7 +484,8 @@ __global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, const ui
 // rank inside the (block, locus) group by (cell, k) -> the order the binning sort gives; the first
 // entry of a cell at a locus also adds (entries of the cell at the locus)^2 to the cell's sum (the
 // Cauchy-Schwarz pair bound), through LDS: a workgroup's slice spans few cell blocks.
-__global__ __launch_bounds__(TPB) void k_bin_rank(const unsigned long long *key2, const unsigned long long *grouped,
+constexpr int TPB_RANK = 1024;  // many entries in flight per workgroup: the loop is a chain of gathers
+__global__ __launch_bounds__(TPB_RANK) void k_bin_rank(const unsigned long long *key2, const unsigned long long *grouped,
                                                  uint32_t n, uint32_t B, uint32_t L, uint32_t lbits,
                                                  const uint32_t *blk_off, unsigned long long *skey2,
                                                  uint32_t *sval2, unsigned long long *per_cell_sq, Scalars *sc) {
@@ -474,13 +494,13 @@ __global__ __launch_bounds__(TPB) void k_bin_rank(const unsigned long long *key2
     __shared__ uint32_t first_cell;
     const uint32_t per_block = (n + gridDim.x - 1) / gridDim.x;
     const uint32_t d0 = blockIdx.x * per_block, d1 = min(n, d0 + per_block);
-    for (uint32_t i = threadIdx.x; i < SLOTS; i += TPB) sq[i] = 0;
+    for (uint32_t i = threadIdx.x; i < SLOTS; i += TPB_RANK) sq[i] = 0;
     if (threadIdx.x == 0 && d0 < n) {
         const unsigned long long key = key2[(uint32_t)grouped[d0]];
         first_cell = (uint32_t)(key >> (kCibBits + lbits)) * B;
     }
     __syncthreads();
-    for (uint32_t p = d0 + threadIdx.x; p < d1; p += TPB) {
+    for (uint32_t p = d0 + threadIdx.x; p < d1; p += TPB_RANK) {
         const unsigned long long mine = grouped[p];
         const uint32_t k = (uint32_t)mine;
         const unsigned long long key = key2[k];
@@ -516,7 +536,7 @@ __global__ __launch_bounds__(TPB) void k_bin_rank(const unsigned long long *key2
     }
     __syncthreads();
     if (d0 < n) {
-        for (uint32_t i = threadIdx.x; i < SLOTS; i += TPB) {
+        for (uint32_t i = threadIdx.x; i < SLOTS; i += TPB_RANK) {
             if (sq[i]) atomicAdd(&per_cell_sq[first_cell + i], sq[i]);
         }
     }
@@ -678,13 +698,22 @@ __global__ __launch_bounds__(TPB) void k_ranges_compact(const uint32_t *seg_ends
     if (threadIdx.x == 0) sc->num_ranges = s_base;
 }
 
+// per locus: its chromosome and its index inside its locus range (k_records looks both up per entry)
+__global__ void k_locus_info(Raw in, const uint32_t *range_off, const Scalars *sc, uint32_t *locus_chr,
+                             uint32_t *locus_rel) {
+    const uint32_t n_ranges = sc->num_ranges;
+    for (uint32_t l = blockIdx.x * TPB + threadIdx.x; l < in.n_loci; l += gridDim.x * TPB) {
+        locus_chr[l] = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
+        locus_rel[l] = l - range_off[last_le<uint32_t>(range_off, n_ranges + 1, l)];
+    }
+}
+
 // entry records at their final (binned) position d: window masks from the per-read lists
 __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_t *sval2, uint32_t n,
                           const uint32_t *t_read, const uint32_t *read_off, const uint32_t *read_locus,
                           const uint8_t *read_base, const uint32_t *run_rank, const uint32_t *rbeg,
-                          const uint32_t *flushed, const uint32_t *range_off, const Scalars *sc, uint32_t B,
+                          const uint32_t *flushed, const uint32_t *locus_chr, const uint32_t *locus_rel, uint32_t B,
                           uint32_t lbits, uint4 *entry, uint32_t *entry32, uint32_t *mask32, uint32_t *entry_read) {
-    const uint32_t n_ranges = sc->num_ranges;
     for (uint32_t d = blockIdx.x * TPB + threadIdx.x; d < n; d += gridDim.x * TPB) {
         const unsigned long long key = skey2[d];
         const uint32_t k = sval2[d];
@@ -695,7 +724,7 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
         const uint32_t r = t_read[k];
         const uint32_t lo = read_off[r], hi = read_off[r + 1];
         const uint32_t base = read_base[k];
-        const uint32_t chr = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
+        const uint32_t chr = locus_chr[l];
         const bool tail = run_rank[r] - rbeg[chr] >= flushed[chr];
         uint32_t meta = cell | (base << kMetaBaseShift) | (tail ? kMetaTail : 0u);
         uint32_t masks = 0, bases = 0;
@@ -720,10 +749,9 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
             bases |= (uint32_t)(read_base[j] & 1u) << (dist - 1);
             bases |= (uint32_t)((read_base[j] >> 1) & 1u) << (16 + dist - 1);
         }
-        const uint32_t rg = last_le<uint32_t>(range_off, n_ranges + 1, l);
         entry[d] = make_uint4(meta, masks, bases, l);
         entry32[d] = cib | (base << kC_BaseShift) | (tail ? kC_Tail : 0u) | (hi - lo > 1 ? kC_Multi : 0u)
-                | (wide ? kC_Wide : 0u) | ((l - range_off[rg]) << 16);
+                | (wide ? kC_Wide : 0u) | (locus_rel[l] << 16);
         mask32[d] = (masks & 0xFFu) | (((masks >> 16) & 0xFFu) << 8) | ((bases & 0xFFu) << 16)
                 | (((bases >> 16) & 0xFFu) << 24);
         entry_read[d] = r;
@@ -764,8 +792,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             in.id_base32, in.group_id_to_pos, in.n_groups, L, E};
 
     // ---- buffers (sized up front: a re-allocation in mid-pipeline would synchronise) -----------
-    // MISC: Scalars | id_max[C] | id_negmin[C] | id_base[C+1] | rbeg[C+1] | flushed[C] | cnt[L]
-    HIP_OK(S[MISC].ensure(sizeof(Scalars) + sizeof(uint32_t) * ((size_t)5 * C + 4 + L) + 64));
+    // MISC: Scalars | id_max[C] | id_negmin[C] | id_base[C+1] | rbeg[C+1] | flushed[C] | cnt[L] |
+    //       locus_chr[L] | locus_rel[L]
+    HIP_OK(S[MISC].ensure(sizeof(Scalars) + sizeof(uint32_t) * ((size_t)5 * C + 4 + (size_t)3 * L) + 64));
     Scalars *sc = S[MISC].as<Scalars>();
     uint32_t *id_max = reinterpret_cast<uint32_t *>(sc + 1);
     uint32_t *id_negmin = id_max + C;
@@ -773,6 +802,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *rbeg = id_base + C + 1;
     uint32_t *flushed = rbeg + C + 1;
     uint32_t *cnt = flushed + C;
+    uint32_t *locus_chr = cnt + L, *locus_rel = locus_chr + L;
     // KEY_A: sort keys in, later mark[E+1] | arank[E+1], later the per-(block, locus) counts
     HIP_OK(S[KEY_A].ensure(std::max<size_t>({(size_t)E * 8, ((size_t)2 * E + 4) * 4, (n_off_max + 1) * 4})));
     // KEY_B: sorted keys, later (counting path) the kept entries grouped by (block, locus)
@@ -808,8 +838,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
 
     // ---- 1: entries grouped by (chromosome, read id), pileup order inside a read ---------------
     hipLaunchKernelGGL(k_check_positions, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, sc);
-    hipLaunchKernelGGL(k_entry_locus, dim3(std::min<uint32_t>(blocks_for((uint64_t)L * 64), 2048)), dim3(TPB), 0,
-                       stream, raw, eloc, id_max, id_negmin);
+    hipLaunchKernelGGL(k_entry_locus, dim3(blocks_for((uint64_t)L * 64)), dim3(TPB), 0, stream, raw, eloc);
+    hipLaunchKernelGGL(k_id_range, dim3(std::min<uint32_t>(1024, (E + 4095) / 4096)), dim3(TPB), 0, stream, raw,
+                       id_max, id_negmin);
     hipLaunchKernelGGL(k_id_bases, dim3(1), dim3(64), 0, stream, C, id_max, id_negmin, id_base, sc);
     Scalars hsc;
     HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
@@ -885,8 +916,23 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     // ---- 4: appearance ranks, completed counts, flush chain ----------------------------------
     hipLaunchKernelGGL(k_ranks, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, first_entry, start_pos, arank, d_R,
                        run_rank, starts_by_rank, rbeg);
-    hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, starts_by_rank, rbeg, mfl, cnt);
-    hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, stream, raw, cnt, 4u * num_threads, flushed);
+    // The flush chain is sequential (one lane per chromosome) and only the final gather needs its
+    // result: it runs on a side stream, next to the grouping of the kept entries.
+    if (!pk.side) {
+        HIP_OK(hipStreamCreateWithFlags(&pk.side, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&pk.ev_fork, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&pk.ev_join, hipEventDisableTiming));
+    }
+    HIP_OK(hipEventRecord(pk.ev_fork, stream));
+    HIP_OK(hipStreamWaitEvent(pk.side, pk.ev_fork, 0));
+    hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, pk.side, raw, starts_by_rank, rbeg, mfl, cnt);
+    hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, pk.side, raw, cnt, 4u * num_threads, flushed);
+    HIP_OK(hipEventRecord(pk.ev_join, pk.side));
+    struct SideJoin {  // every way out of this function leaves the side stream idle
+        hipStream_t side;
+        bool joined = false;
+        ~SideJoin() { if (!joined) (void)hipStreamSynchronize(side); }
+    } side_join{pk.side};
 
     // read-back 2: status flags, R, number of kept entries, multi-locus statistics
     uint32_t R = 0, last_slot = 0, last_keep = 0;
@@ -960,8 +1006,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             unsigned long long *grouped = key_b;  // the sorted entry keys are dead after k_dup_rule
             hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_k, entry_cell,
                                blk_off, grouped);
-            hipLaunchKernelGGL(k_bin_rank, dim3(slice_grid), dim3(TPB), 0, stream, key2_a, grouped, n_kept, B, L,
-                               lbits, blk_off, key2_b, val2_b, per_cell_sq, sc);
+            hipLaunchKernelGGL(k_bin_rank, dim3(std::min<uint32_t>(1u << 16, (n_kept + 4095) / 4096)), dim3(TPB_RANK), 0,
+                               stream, key2_a, grouped, n_kept, B, L, lbits, blk_off, key2_b, val2_b, per_cell_sq, sc);
         }
     }
     if (n_kept)
@@ -986,10 +1032,14 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         hipLaunchKernelGGL(k_ranges_compact, dim3(1), dim3(TPB), 0, stream, seg_ends, seg_count, n_seg, caps,
                            pk.range_off.as<uint32_t>(), sc);
     }
+    HIP_OK(hipStreamWaitEvent(stream, pk.ev_join, 0));
+    side_join.joined = true;
     if (n_kept) {
+        hipLaunchKernelGGL(k_locus_info, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, pk.range_off.as<uint32_t>(), sc,
+                           locus_chr, locus_rel);
         hipLaunchKernelGGL(k_records, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, raw, key2_b, val2_b, n_kept,
-                           t_read, read_off, read_locus, read_base, run_rank, rbeg, flushed,
-                           pk.range_off.as<uint32_t>(), sc, B, lbits, pk.entry.as<uint4>(),
+                           t_read, read_off, read_locus, read_base, run_rank, rbeg, flushed, locus_chr, locus_rel, B,
+                           lbits, pk.entry.as<uint4>(),
                            pk.entry32.as<uint32_t>(), pk.mask32.as<uint32_t>(), pk.entry_read.as<uint32_t>());
     }
     // read-back 3: errors of the group mapping, pair bound (-> tile variant), number of ranges

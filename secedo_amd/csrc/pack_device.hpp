@@ -49,6 +49,14 @@ struct DevicePacked {
     bool stage_masks = false;
     bool count_tile = false;
     uint32_t cap_entries = 0, cap_loci = 0;
+    // side stream for the branch of the pipeline nothing else waits for until the final gather
+    // (completed counts + flush chain); created on first use
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DevicePacked() = default;
+    DevicePacked(const DevicePacked &) = delete;
+    DevicePacked &operator=(const DevicePacked &) = delete;
+    ~DevicePacked();
 };
 
 // Returns "" on success. On success with *need_host == true nothing usable was produced and the
