@@ -245,41 +245,31 @@ __global__ void k_check_positions(Raw in, Scalars *sc) {
     }
 }
 
-__global__ void k_heads(const unsigned long long *skey, uint32_t n, uint32_t *head) {
-    for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB)
-        head[s] = (s == 0 || skey[s] != skey[s - 1]) ? 1u : 0u;
-}
-
-__global__ void k_run_starts(const uint32_t *head, const uint32_t *run_incl, uint32_t n, uint32_t *run_start) {
-    for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
-        if (head[s]) run_start[run_incl[s] - 1] = s;
-        if (s == n - 1) run_start[run_incl[s]] = n;
+// Input of the one scan over the sorted order: low word = first entry of a read (head of a run of
+// equal keys), high word = the entry survives the duplicate rule. The inclusive sums give, per
+// position, the 1-based read number and the number of kept entries up to and including it.
+struct HeadKeepOp {
+    const unsigned long long *skey;
+    const uint32_t *keep;
+    __device__ __forceinline__ unsigned long long operator()(uint32_t s) const {
+        const unsigned long long head = (s == 0 || skey[s] != skey[s - 1]) ? 1ull : 0ull;
+        return head | ((unsigned long long)keep[s] << 32);
     }
-}
+};
+__device__ __forceinline__ uint32_t incl_reads(unsigned long long v) { return (uint32_t)v; }
+__device__ __forceinline__ uint32_t incl_kept(unsigned long long v) { return (uint32_t)(v >> 32); }
 
-// per read: first entry, start position, span check; marks first entries for the appearance rank
-__global__ void k_run_info(Raw in, const uint32_t *run_start, const uint32_t *n_runs_p, const uint32_t *sval,
-                           const uint32_t *entry_locus, uint32_t mfl, uint32_t *first_entry,
-                           uint32_t *start_pos, uint32_t *mark, Scalars *sc) {
-    const uint32_t n_runs = *n_runs_p;
-    for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r < n_runs; r += gridDim.x * TPB) {
-        const uint32_t e0 = sval[run_start[r]], e1 = sval[run_start[r + 1] - 1];
-        const uint32_t p0 = in.locus_pos[entry_locus[e0]], p1 = in.locus_pos[entry_locus[e1]];
-        // a read whose entries reach start + mfl can be flushed before its last entry arrives and is
-        // then re-opened as a new read (:368-371, :379-382): that schedule is emulated on the host
-        if (p1 - p0 >= mfl || (unsigned long long)p1 + mfl > 0xFFFFFFFFull) sc->need_host = 1;
-        first_entry[r] = e0;
-        start_pos[r] = p0;
-        mark[e0] = 1u;
-    }
-}
-
-// duplicate-position rule (:387-395) per (read, locus) group of the sorted order
-__global__ void k_dup_rule(Raw in, const unsigned long long *skey, const uint32_t *sval,
-                           const uint32_t *entry_locus, uint32_t n, uint32_t *keep) {
+// duplicate-position rule (:387-395) per (read, locus) group of the sorted order, and the mark of
+// every read's first entry (in pileup order) for the appearance rank
+__global__ void k_dup_mark(Raw in, const unsigned long long *skey, const uint32_t *sval,
+                           const uint32_t *entry_locus, uint32_t n, uint32_t *keep, uint32_t *mark) {
     for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
-        const uint32_t l = entry_locus[sval[s]];
-        if (s > 0 && skey[s] == skey[s - 1] && entry_locus[sval[s - 1]] == l) continue;  // not a group head
+        const uint32_t e = sval[s];
+        const uint32_t l = entry_locus[e];
+        const bool same_read = s > 0 && skey[s] == skey[s - 1];
+        mark[e] = same_read ? 0u : 1u;
+        if (s == 0) mark[n] = 0u;
+        if (same_read && entry_locus[sval[s - 1]] == l) continue;  // not a group head
         uint32_t stored = s;  // position of the stored entry of this (read, locus)
         bool have = true;
         keep[s] = 0u;
@@ -297,55 +287,59 @@ __global__ void k_dup_rule(Raw in, const unsigned long long *skey, const uint32_
     }
 }
 
-__global__ void k_csr(Raw in, const uint32_t *sval, const uint32_t *entry_locus, const uint32_t *keep,
-                      const uint32_t *slot, uint32_t n, uint32_t *read_locus, uint8_t *read_base) {
+// run starts (reads) and the per-read lists of kept entries (CSR payload)
+__global__ void k_runs_csr(Raw in, const unsigned long long *incl, const uint32_t *sval,
+                           const uint32_t *entry_locus, uint32_t n, uint32_t *run_start, uint32_t *read_locus,
+                           uint8_t *read_base) {
     for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
-        if (!keep[s]) continue;
-        const uint32_t e = sval[s];
-        read_locus[slot[s]] = entry_locus[e];
-        read_base[slot[s]] = (uint8_t)(in.id_base(e) & 3u);
+        const unsigned long long cur = incl[s], prev = s ? incl[s - 1] : 0ull;
+        if (incl_reads(cur) != incl_reads(prev)) run_start[incl_reads(cur) - 1] = s;
+        if (s == n - 1) run_start[incl_reads(cur)] = n;
+        if (incl_kept(cur) != incl_kept(prev)) {
+            const uint32_t e = sval[s], k = incl_kept(prev);
+            read_locus[k] = entry_locus[e];
+            read_base[k] = (uint8_t)(in.id_base(e) & 3u);
+        }
     }
 }
 
-__global__ void k_read_off(const uint32_t *run_start, const uint32_t *slot, const uint32_t *keep,
-                           const uint32_t *n_runs_p, uint32_t n, uint32_t *read_off) {
-    const uint32_t n_runs = *n_runs_p;
-    for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r <= n_runs; r += gridDim.x * TPB) {
-        read_off[r] = (r < n_runs) ? slot[run_start[r]] : slot[n - 1] + keep[n - 1];
-    }
-}
-
-// entries of multi-locus reads (one atomic per workgroup: same-address atomics are slow)
-__global__ __launch_bounds__(TPB) void k_multi(const uint32_t *read_off, const uint32_t *n_runs_p, Scalars *sc) {
+// per read: span check, offsets into the per-read lists, appearance rank, start position in rank
+// order, entries of multi-locus reads; per chromosome the first rank
+__global__ __launch_bounds__(TPB) void k_read_info(Raw in, const unsigned long long *incl, const uint32_t *run_start,
+                                                  const uint32_t *sval, const uint32_t *entry_locus,
+                                                  const uint32_t *arank, uint32_t mfl, uint32_t *run_rank,
+                                                  uint32_t *starts_by_rank, uint32_t *rbeg, uint32_t *read_off,
+                                                  Scalars *sc) {
     __shared__ unsigned long long part[TPB / 64];
-    const uint32_t n_runs = *n_runs_p;
-    unsigned long long local = 0;
+    const uint32_t n = in.n_entries;
+    const uint32_t n_runs = incl_reads(incl[n - 1]);
+    unsigned long long multi = 0;
     for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r < n_runs; r += gridDim.x * TPB) {
-        const uint32_t c = read_off[r + 1] - read_off[r];
-        if (c > 1) local += c;
+        const uint32_t s0 = run_start[r], s1 = run_start[r + 1];
+        const uint32_t e0 = sval[s0], e1 = sval[s1 - 1];
+        const uint32_t p0 = in.locus_pos[entry_locus[e0]], p1 = in.locus_pos[entry_locus[e1]];
+        // a read whose entries reach start + mfl can be flushed before its last entry arrives and is
+        // then re-opened as a new read (:368-371, :379-382): that schedule is emulated on the host
+        if (p1 - p0 >= mfl || (unsigned long long)p1 + mfl > 0xFFFFFFFFull) sc->need_host = 1;
+        const uint32_t rk = arank[e0];
+        run_rank[r] = rk;
+        starts_by_rank[rk] = p0;
+        const uint32_t k0 = s0 ? incl_kept(incl[s0 - 1]) : 0u, k1 = incl_kept(incl[s1 - 1]);
+        read_off[r] = k0;
+        if (r == n_runs - 1) read_off[n_runs] = k1;
+        if (k1 - k0 > 1) multi += k1 - k0;
     }
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+    for (uint32_t c = blockIdx.x * TPB + threadIdx.x; c <= in.n_chr; c += gridDim.x * TPB) {
+        rbeg[c] = arank[(uint32_t)in.locus_entry_off[in.chr_locus_off[c]]];
+    }
+    // one atomic per workgroup: same-address atomics are slow
+    for (int off = 32; off > 0; off >>= 1) multi += __shfl_down(multi, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = multi;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long sum = 0;
         for (int w = 0; w < TPB / 64; ++w) sum += part[w];
         if (sum) atomicAdd(&sc->multi_entries, sum);
-    }
-}
-
-// appearance rank of each read; read starts in rank order; per chromosome the first rank
-__global__ void k_ranks(Raw in, const uint32_t *first_entry, const uint32_t *start_pos,
-                        const uint32_t *arank, const uint32_t *n_runs_p, uint32_t *run_rank,
-                        uint32_t *starts_by_rank, uint32_t *rbeg) {
-    const uint32_t n_runs = *n_runs_p;
-    for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r < n_runs; r += gridDim.x * TPB) {
-        const uint32_t rk = arank[first_entry[r]];
-        run_rank[r] = rk;
-        starts_by_rank[rk] = start_pos[r];
-    }
-    for (uint32_t c = blockIdx.x * TPB + threadIdx.x; c <= in.n_chr; c += gridDim.x * TPB) {
-        rbeg[c] = arank[(uint32_t)in.locus_entry_off[in.chr_locus_off[c]]];
     }
 }
 
@@ -396,17 +390,18 @@ __device__ __forceinline__ unsigned long long bin_key(uint32_t blk, uint32_t l, 
 
 // binning key (cell block, locus, cell) of every kept entry, in per-read (CSR) order; validates the
 // group -> row mapping
-__global__ void k_keys2(Raw in, const uint32_t *sval, const uint32_t *keep, const uint32_t *slot,
-                        const uint32_t *run_incl, const uint32_t *read_locus, uint32_t num_cells, uint32_t B,
+__global__ void k_keys2(Raw in, const uint32_t *sval, const unsigned long long *incl,
+                        const uint32_t *read_locus, uint32_t num_cells, uint32_t B,
                         uint32_t lbits, unsigned long long *key2, uint32_t *val2, uint32_t *t_read,
                         uint32_t *entry_k, uint32_t *entry_cell, Scalars *sc) {
     const uint32_t n = in.n_entries;
     for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
-        if (!keep[s]) {
+        const unsigned long long cur = incl[s], prev = s ? incl[s - 1] : 0ull;
+        if (incl_kept(cur) == incl_kept(prev)) {
             if (entry_k) entry_k[sval[s]] = kNoEntry;
             continue;
         }
-        const uint32_t k = slot[s];
+        const uint32_t k = incl_kept(prev);
         const uint32_t group = in.id_base(sval[s]) >> 2;
         uint32_t cell = 0;
         if (group >= in.n_groups) {
@@ -421,7 +416,7 @@ __global__ void k_keys2(Raw in, const uint32_t *sval, const uint32_t *keep, cons
         const uint32_t blk = cell / B, cib = cell - blk * B;
         key2[k] = bin_key(blk, read_locus[k], cib, lbits);
         val2[k] = k;
-        t_read[k] = run_incl[s] - 1;
+        t_read[k] = incl_reads(cur) - 1;
         if (entry_k) {  // counting path: back in pileup order, where the entries of a locus are adjacent
             entry_k[sval[s]] = k;
             entry_cell[sval[s]] = (blk << kCibBits) | cib;
@@ -812,9 +807,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     // ELOC: entry -> locus, later the range segments (count[n_seg] | ends[n_seg * cap_loci])
     HIP_OK(S[ELOC].ensure(std::max<size_t>((size_t)E * 4, ((size_t)2 * L + 4 * 8192 + L / 64 + 16) * 4)));
     HIP_OK(S[WORK_A].ensure(((size_t)E + 1) * 4));
-    HIP_OK(S[WORK_B].ensure(((size_t)E + 1) * 4));
-    // RUNS: run_start[R+1] | first_entry[R] | start_pos[R] | run_rank[R] | starts_by_rank[R], R <= E
-    HIP_OK(S[RUNS].ensure(((size_t)5 * E + 8) * 4));
+    HIP_OK(S[WORK_B].ensure(((size_t)2 * E + 2) * 4));
+    // RUNS: run_start[R+1] | run_rank[R] | starts_by_rank[R] | entry_cell[E], R <= E
+    HIP_OK(S[RUNS].ensure(((size_t)4 * E + 8) * 4));
     // TMP: read index per kept entry; BIN: key2 x2, val2 x2, per-cell squares
     HIP_OK(S[TMP].ensure((size_t)E * 4 + 64));
     HIP_OK(S[BIN].ensure((size_t)E * 24 + ((size_t)num_cells + 130) * 8 + 64));
@@ -825,7 +820,14 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         size_t need = 0, most = 0;
         HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, key_a, key_b, val_a, val_b, (int)E, 0, 64, stream));
         most = std::max(most, need);
-        HIP_OK(hipcub::DeviceScan::InclusiveSum(nullptr, need, val_a, val_b, (int)E + 1, stream));
+        {
+            hipcub::CountingInputIterator<uint32_t> positions(0u);
+            hipcub::TransformInputIterator<unsigned long long, HeadKeepOp, hipcub::CountingInputIterator<uint32_t>>
+                    flags(positions, HeadKeepOp{key_b, val_a});
+            HIP_OK(hipcub::DeviceScan::InclusiveSum(nullptr, need, flags, key_a, (int)E, stream));
+            most = std::max(most, need);
+        }
+        HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, val_a, val_b, (int)E + 1, stream));
         most = std::max(most, need);
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, val_a, val_b,
                                                 (int)std::max<size_t>(n_off_max, id_space_cap + 2), stream));
@@ -849,7 +851,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     const size_t id_space = (size_t)std::min<unsigned long long>(hsc.id_space, 1ull << 40);
     const bool counting = !force_radix && id_space <= id_space_cap;
     HIP_OK(S[WORK_A].ensure(std::max<size_t>((size_t)E + 1, counting ? id_space + 1 : 0) * 4));
-    HIP_OK(S[WORK_B].ensure(std::max<size_t>((size_t)E + 1, counting ? id_space + 1 : 0) * 4));
+    HIP_OK(S[WORK_B].ensure(std::max<size_t>((size_t)2 * E + 2, counting ? id_space + 1 : 0) * 4));
     uint32_t *work_a = S[WORK_A].as<uint32_t>(), *work_b = S[WORK_B].as<uint32_t>();
     if (counting) {
         uint32_t *hist = work_a, *id_off = work_b, *grouped = val_a;
@@ -872,32 +874,25 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     const unsigned long long *skey = key_b;
     const uint32_t *sval = val_b;
 
-    // ---- 2: reads = runs of equal key ------------------------------------------------------
-    // (the number of reads R stays on the device until the read-back after step 4; buffers that are
-    // indexed by read are laid out for the upper bound E)
-    uint32_t *head = work_a, *run_incl = work_b;  // run_incl stays alive until k_keys2
-    hipLaunchKernelGGL(k_heads, dim3(blocks_for(E)), dim3(TPB), 0, stream, skey, E, head);
-    cub_cap = S[CUB].bytes;
-    HIP_OK(hipcub::DeviceScan::InclusiveSum(cub_tmp, cub_cap, head, run_incl, (int)E, stream));
-    const uint32_t *d_R = run_incl + (E - 1);
-    uint32_t *run_start = S[RUNS].as<uint32_t>();
-    uint32_t *first_entry = run_start + E + 1, *start_pos = first_entry + E, *run_rank = start_pos + E,
-             *starts_by_rank = run_rank + E;
-    hipLaunchKernelGGL(k_run_starts, dim3(blocks_for(E)), dim3(TPB), 0, stream, head, run_incl, E, run_start);
-    uint32_t *mark = S[KEY_A].as<uint32_t>();  // the unsorted keys are dead
+    // ---- 2-4: duplicate rule, reads = runs of equal key, per-read lists, appearance ranks ------
+    // (the number of reads R stays on the device until read-back 2; buffers indexed by read are laid
+    // out for the upper bound E)
+    uint32_t *keep = work_a;
+    unsigned long long *incl = reinterpret_cast<unsigned long long *>(work_b);  // alive until k_keys2
+    uint32_t *mark = S[KEY_A].as<uint32_t>();  // the unsorted keys / dense ids are dead
     uint32_t *arank = mark + (E + 1);
-    HIP_OK(hipMemsetAsync(mark, 0, ((size_t)E + 1) * 4, stream));
-    hipLaunchKernelGGL(k_run_info, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, run_start, d_R, sval, eloc, mfl,
-                       first_entry, start_pos, mark, sc);
-    uint32_t *keep = work_a;  // overwrites head (k_run_starts is done with it: same stream)
-    hipLaunchKernelGGL(k_dup_rule, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sval, eloc, E, keep);
-    uint32_t *slot = val_a;  // the unsorted values are dead
-    cub_cap = S[CUB].bytes;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, keep, slot, (int)E, stream));
+    uint32_t *run_start = S[RUNS].as<uint32_t>();
+    uint32_t *run_rank = run_start + E + 1, *starts_by_rank = run_rank + E, *entry_cell_buf = starts_by_rank + E;
+    hipLaunchKernelGGL(k_dup_mark, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sval, eloc, E, keep, mark);
+    {
+        hipcub::CountingInputIterator<uint32_t> positions(0u);
+        hipcub::TransformInputIterator<unsigned long long, HeadKeepOp, hipcub::CountingInputIterator<uint32_t>> flags(
+                positions, HeadKeepOp{skey, keep});
+        cub_cap = S[CUB].bytes;
+        HIP_OK(hipcub::DeviceScan::InclusiveSum(cub_tmp, cub_cap, flags, incl, (int)E, stream));
+    }
     cub_cap = S[CUB].bytes;
     HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, mark, arank, (int)E + 1, stream));
-
-    // ---- 3: per-read lists (sized for the upper bound E) --------------------------------------
     HIP_OK(pk.read_off.ensure(((size_t)E + 1) * 4));
     HIP_OK(pk.read_locus.ensure((size_t)E * 4));
     HIP_OK(pk.read_base.ensure(E));
@@ -909,13 +904,11 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     HIP_OK(pk.blk_off.ensure((n_off_max + 1) * 4));
     uint32_t *read_off = pk.read_off.as<uint32_t>(), *read_locus = pk.read_locus.as<uint32_t>();
     uint8_t *read_base = pk.read_base.as<uint8_t>();
-    hipLaunchKernelGGL(k_csr, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, eloc, keep, slot, E, read_locus, read_base);
-    hipLaunchKernelGGL(k_read_off, dim3(blocks_for(E)), dim3(TPB), 0, stream, run_start, slot, keep, d_R, E, read_off);
-    hipLaunchKernelGGL(k_multi, dim3(std::min<uint32_t>(blocks_for(E), 1024)), dim3(TPB), 0, stream, read_off, d_R, sc);
+    hipLaunchKernelGGL(k_runs_csr, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, incl, sval, eloc, E, run_start,
+                       read_locus, read_base);
+    hipLaunchKernelGGL(k_read_info, dim3(std::min<uint32_t>(blocks_for(E), 2048)), dim3(TPB), 0, stream, raw, incl,
+                       run_start, sval, eloc, arank, mfl, run_rank, starts_by_rank, rbeg, read_off, sc);
 
-    // ---- 4: appearance ranks, completed counts, flush chain ----------------------------------
-    hipLaunchKernelGGL(k_ranks, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, first_entry, start_pos, arank, d_R,
-                       run_rank, starts_by_rank, rbeg);
     // The flush chain is sequential (one lane per chromosome) and only the final gather needs its
     // result: it runs on a side stream, next to the grouping of the kept entries.
     if (!pk.side) {
@@ -935,10 +928,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     } side_join{pk.side};
 
     // read-back 2: status flags, R, number of kept entries, multi-locus statistics
-    uint32_t R = 0, last_slot = 0, last_keep = 0;
-    HIP_OK(hipMemcpyAsync(&R, d_R, 4, hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipMemcpyAsync(&last_slot, slot + (E - 1), 4, hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipMemcpyAsync(&last_keep, keep + (E - 1), 4, hipMemcpyDeviceToHost, stream));
+    unsigned long long totals = 0;  // reads | kept entries << 32
+    HIP_OK(hipMemcpyAsync(&totals, incl + (E - 1), 8, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
     if (hsc.regroup) {
@@ -949,7 +940,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         *need_host = true;
         return std::string();
     }
-    const uint32_t n_kept = last_slot + last_keep;
+    const uint32_t R = (uint32_t)totals, n_kept = (uint32_t)(totals >> 32);
     const size_t nk = std::max<uint32_t>(n_kept, 1);
     pk.multi_entries = hsc.multi_entries;
     if (block_cells == 0) {
@@ -980,11 +971,11 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *blk_cnt = S[KEY_A].as<uint32_t>();  // mark / arank are dead after k_ranks
     // counting path: per pileup entry its k and cell (entry -> locus and the per-read scratch are dead)
     uint32_t *entry_k = force_radix ? nullptr : eloc;
-    uint32_t *entry_cell = force_radix ? nullptr : first_entry;
+    uint32_t *entry_cell = force_radix ? nullptr : entry_cell_buf;
     if (force_radix) HIP_OK(hipMemsetAsync(blk_cnt, 0, (n_off + 1) * 4, stream));
     HIP_OK(hipMemsetAsync(per_cell_sq, 0, ((size_t)nb * B + 1) * 8, stream));
-    hipLaunchKernelGGL(k_keys2, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, keep, slot, run_incl,
-                       read_locus, num_cells, B, lbits, key2_a, val2_a, t_read, entry_k, entry_cell, sc);
+    hipLaunchKernelGGL(k_keys2, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, incl, read_locus, num_cells, B,
+                       lbits, key2_a, val2_a, t_read, entry_k, entry_cell, sc);
     const uint32_t slice_grid = std::min<uint32_t>(2048, (n_kept + 4095) / 4096);
     if (force_radix) {
         if (n_kept) {
