@@ -538,9 +538,9 @@ static int finalize_mode(secedo_simmat_t *h, int mode, const int64_t *d_acc, dou
     if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
     if (!h->have_lut) return fail(SECEDO_E_STATE, "accumulate was not called");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(secedo::launch_finalize(d_acc, h->pk.num_cells, h->pk.num_blocks, h->pk.block_cells, h->scale_log2,
-                                    mode, h->max_bits.as<unsigned long long>(), d_out,
-                                    static_cast<hipStream_t>(stream)));
+    HIP_TRY(secedo::launch_finalize(d_acc, h->tile_row.as<uint16_t>(), h->tile_col.as<uint16_t>(), h->num_tiles,
+                                    h->pk.num_cells, h->pk.block_cells, h->scale_log2, mode,
+                                    h->max_bits.as<unsigned long long>(), d_out, static_cast<hipStream_t>(stream)));
     return SECEDO_OK;
 }
 

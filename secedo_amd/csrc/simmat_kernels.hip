@@ -600,73 +600,81 @@ __global__ __launch_bounds__(256) void reduce_slabs(const void *slab, const uint
     if (sum) acc[(size_t)(tile_begin + t_local) * B * B + cell] += sum;
 }
 
-// upper-triangular tile index of (I <= J)
-__device__ __forceinline__ size_t tile_index(uint32_t I, uint32_t J, uint32_t nb) {
-    return (size_t)I * nb - (size_t)I * (I - 1) / 2 + (J - I);
-}
-
-// D[i][j] (i != j) from the tile-major accumulator, as an exact integer
-template <int B>
-__device__ __forceinline__ long long acc_value(const long long *acc, uint32_t nb, uint32_t i, uint32_t j) {
-    uint32_t I = i / B, J = j / B, r = i % B, c = j % B;
-    if (I > J) {
-        uint32_t tI = I; I = J; J = tI;
-        uint32_t tr = r; r = c; c = tr;
-    }
-    const long long *tile = acc + tile_index(I, J, nb) * B * B;
-    long long v = tile[r * B + c];
-    if (I == J) v += tile[c * B + r];  // a diagonal tile holds each pair in either orientation
-    return v;
-}
-
 // max over i < j of D[i][j], clamped at 0 (the diagonal is zero): bits of a non-negative double
-// order like unsigned integers, so atomicMax on the bit pattern is exact
+// order like unsigned integers, so atomicMax on the bit pattern is exact. Walks the tile-major
+// accumulator linearly (cells beyond num_cells hold zero and do not move a maximum clamped at 0).
 template <int B>
-__global__ __launch_bounds__(256) void reduce_max(const long long *acc, uint32_t n, uint32_t nb,
-                                                  double scale, unsigned long long *out_bits) {
-    const size_t total = (size_t)n * n;
-    double best = 0.0;
+__global__ __launch_bounds__(256) void reduce_max(const long long *acc, const uint16_t *tile_row,
+                                                  const uint16_t *tile_col, uint32_t n_tiles, double scale,
+                                                  unsigned long long *out_bits) {
+    const size_t total = (size_t)n_tiles * B * B;
+    long long best = 0;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const uint32_t i = idx / n, j = idx % n;
-        if (i < j) {
-            const double d = (double)acc_value<B>(acc, nb, i, j) * scale;
-            best = fmax(best, d);
+        const uint32_t t = (uint32_t)(idx / (B * B)), rc = (uint32_t)(idx % (B * B));
+        long long v = acc[idx];
+        if (tile_row[t] == tile_col[t]) {  // a diagonal tile holds each pair in either orientation
+            const uint32_t r = rc / B, c = rc % B;
+            v = r < c ? v + acc[(size_t)t * B * B + c * B + r] : 0;
         }
+        best = max(best, v);
     }
-    for (int off = 32; off > 0; off >>= 1) best = fmax(best, __shfl_down(best, off));
-    __shared__ double part[4];
+    for (int off = 32; off > 0; off >>= 1) best = max(best, (long long)__shfl_down(best, off));
+    __shared__ long long part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
-        best = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
-        atomicMax(out_bits, (unsigned long long)__double_as_longlong(best));
+        best = max(max(part[0], part[1]), max(part[2], part[3]));
+        // (double)int64 * 2^-k is monotone, so the max of the integers gives the max of the doubles
+        atomicMax(out_bits, (unsigned long long)__double_as_longlong((double)best * scale));
     }
 }
 
-// mode: 0 ADD_MIN, 1 EXPONENTIATE, 2 SCALE_MAX_1, 3 raw D (reference: similarity_matrix.cpp:271-293)
+// mode: 0 ADD_MIN, 1 EXPONENTIATE, 2 SCALE_MAX_1, 3 raw D (reference: similarity_matrix.cpp:271-293).
+// One workgroup per 32 x 32 sub-block of an (upper-triangular) accumulator tile: the sub-block is
+// read once with coalesced loads, normalised into LDS, and written twice -- as out[i][j] straight,
+// as out[j][i] transposed through LDS -- so both the reads and the writes are full 256-byte rows.
 template <int B>
-__global__ __launch_bounds__(256) void write_matrix(const long long *acc, uint32_t n, uint32_t nb,
-                                                    double scale, int mode,
+__global__ __launch_bounds__(256) void write_matrix(const long long *acc, const uint16_t *tile_row,
+                                                    const uint16_t *tile_col, uint32_t n, double scale, int mode,
                                                     const unsigned long long *max_bits, double *out) {
-    const size_t total = (size_t)n * n;
+    constexpr uint32_t SB = 32, PER = B / SB;
+    __shared__ double V[SB][SB + 1];
+    const uint32_t t = blockIdx.x / (PER * PER), sub = blockIdx.x % (PER * PER);
+    const uint32_t a = sub / PER, b = sub % PER;
+    const uint32_t I = tile_row[t], J = tile_col[t];
+    const bool diag = (I == J);
+    if (diag && a > b) return;  // covered by the mirror of (b, a)
     const double mx = (mode == 0 || mode == 2) ? __longlong_as_double((long long)*max_bits) : 0.0;
     // ADD_MIN: sim = -D; sim += |min(sim)|, and min(sim) = -max(D) with the zero diagonal included
     // SCALE_MAX_1: sim = D * (1 / max(D)) with the zero diagonal included (1/0 = inf as in the reference)
     const double add = fabs(-mx);
     const double inv = 1.0 / mx;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const uint32_t i = idx / n, j = idx % n;
-        double v = 0.0;
-        if (i != j) {
-            const double d = (double)acc_value<B>(acc, nb, i, j) * scale;
-            switch (mode) {
-                case 0: v = (d * -1.0) + add; break;
-                case 1: v = 1.0 / (exp(d) + 1.0); break;
-                case 2: v = d * inv; break;
-                default: v = d; break;
-            }
+    const long long *tile = acc + (size_t)t * B * B;
+    const uint32_t tx = threadIdx.x % SB, ty = threadIdx.x / SB;  // 32 x 8
+    const uint32_t i0 = I * B + a * SB, j0 = J * B + b * SB;
+#pragma unroll
+    for (uint32_t k = 0; k < SB; k += 8) {
+        const uint32_t r = ty + k, c = tx;
+        long long v = tile[(a * SB + r) * B + b * SB + c];
+        if (diag) v += tile[(b * SB + c) * B + a * SB + r];
+        const double d = (double)v * scale;
+        double w;
+        switch (mode) {
+            case 0: w = (d * -1.0) + add; break;
+            case 1: w = 1.0 / (exp(d) + 1.0); break;
+            case 2: w = d * inv; break;
+            default: w = d; break;
         }
-        out[idx] = v;
+        if (i0 + r == j0 + c) w = 0.0;
+        V[r][c] = w;
+        if (i0 + r < n && j0 + c < n) out[(size_t)(i0 + r) * n + j0 + c] = w;
+    }
+    if (diag && a == b) return;  // the sub-block is symmetric in itself
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < SB; k += 8) {
+        const uint32_t c = ty + k, r = tx;  // out[j0 + c][i0 + r], r fastest
+        if (i0 + r < n && j0 + c < n) out[(size_t)(j0 + c) * n + i0 + r] = V[r][c];
     }
 }
 
@@ -722,26 +730,31 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
     return launch_acc<64, 256, kCapJ64, kCapL64, 1024, false, false>(args, grid, stream);
 }
 
-hipError_t launch_finalize(const int64_t *acc, uint32_t n, uint32_t nb, uint32_t block_cells,
-                           int scale_log2, int mode, unsigned long long *d_max_bits, double *out,
-                           hipStream_t stream) {
+hipError_t launch_finalize(const int64_t *acc, const uint16_t *tile_row, const uint16_t *tile_col, uint32_t n_tiles,
+                           uint32_t n, uint32_t block_cells, int scale_log2, int mode,
+                           unsigned long long *d_max_bits, double *out, hipStream_t stream) {
     const double scale = ldexp(1.0, -scale_log2);
-    const size_t total = (size_t)n * n;
+    const size_t total = (size_t)n_tiles * block_cells * block_cells;
     const uint32_t grid = (uint32_t)std::min<size_t>((total + 255) / 256, 256 * 8);
     const long long *a = reinterpret_cast<const long long *>(acc);
+    if (n_tiles == 0) return hipSuccess;
     if (mode == 0 || mode == 2) {
         hipError_t e = hipMemsetAsync(d_max_bits, 0, sizeof(unsigned long long), stream);
         if (e != hipSuccess) return e;
         if (block_cells == 128) {
-            hipLaunchKernelGGL((reduce_max<128>), dim3(grid), dim3(256), 0, stream, a, n, nb, scale, d_max_bits);
+            hipLaunchKernelGGL((reduce_max<128>), dim3(grid), dim3(256), 0, stream, a, tile_row, tile_col, n_tiles,
+                               scale, d_max_bits);
         } else {
-            hipLaunchKernelGGL((reduce_max<64>), dim3(grid), dim3(256), 0, stream, a, n, nb, scale, d_max_bits);
+            hipLaunchKernelGGL((reduce_max<64>), dim3(grid), dim3(256), 0, stream, a, tile_row, tile_col, n_tiles,
+                               scale, d_max_bits);
         }
     }
     if (block_cells == 128) {
-        hipLaunchKernelGGL((write_matrix<128>), dim3(grid), dim3(256), 0, stream, a, n, nb, scale, mode, d_max_bits, out);
+        hipLaunchKernelGGL((write_matrix<128>), dim3(n_tiles * 16), dim3(256), 0, stream, a, tile_row, tile_col, n,
+                           scale, mode, d_max_bits, out);
     } else {
-        hipLaunchKernelGGL((write_matrix<64>), dim3(grid), dim3(256), 0, stream, a, n, nb, scale, mode, d_max_bits, out);
+        hipLaunchKernelGGL((write_matrix<64>), dim3(n_tiles * 4), dim3(256), 0, stream, a, tile_row, tile_col, n,
+                           scale, mode, d_max_bits, out);
     }
     return hipGetLastError();
 }
