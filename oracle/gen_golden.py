@@ -287,13 +287,25 @@ def reader_cases():
     print("reader_vectors: %d arrays" % len(out))
 
 
+def laplacian_kat():
+    """The one known-answer vector the reference holds for the spectral step: the input matrix and the
+    expected Laplacian of TEST(Laplacian, SomeMatrix) (tests/test_spectral_clustering.cpp:15-26; the
+    test compares with 1e-3). Data of the reference's test, not an output of a run."""
+    a = np.array([[0, .5, .2], [.5, 0, .5], [.2, .5, 0]], dtype=np.float64)
+    expected = np.array([[1., -0.5976143, -0.28571429], [-0.5976143, 1., -0.5976143],
+                         [-0.28571429, -0.5976143, 1.]], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLDEN, "laplacian_kat.npz"), a=a, expected=expected,
+                        tolerance=np.float64(1e-3))
+    print("laplacian_kat: 3 x 3")
+
+
 def main():
     only = set(sys.argv[1:])
     if not ob.have_ref():
         sys.exit("oracle/_ref/libsecedo_ref.so missing: run `make -C oracle ref` in the container")
     os.makedirs(GOLDEN, exist_ok=True)
     for fn in (semantic_probes, kat_llr_table, reference_pileup_files, divide_clusters_shaped,
-               random_cases, filter_cases, reader_cases):
+               random_cases, filter_cases, reader_cases, laplacian_kat):
         if not only or fn.__name__ in only:
             fn()
 

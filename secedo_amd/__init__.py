@@ -8,3 +8,4 @@ from .similarity_matrix import (InvalidNormalization, NORMALIZATIONS, SecedoErro
                                 SimilarityMatrixPlan, compute_similarity_matrix, llr, to_enum)
 from .filter import Filter, NO_POS, filter_resident  # noqa: F401,E402
 from .pileup_reader import get_grouping, read_pileup  # noqa: F401,E402
+from .spectral import laplacian, smallest_eigenpairs  # noqa: F401,E402

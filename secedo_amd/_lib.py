@@ -34,6 +34,12 @@ class PileupInfo(C.Structure):
                 ("max_read_length", C.c_uint32)]
 
 
+class SpectralInfo(C.Structure):
+    _fields_ = [("cycles", C.c_uint32), ("block_products", C.c_uint32), ("converged", C.c_uint32),
+                ("reserved", C.c_uint32), ("max_residual_vectors", C.c_double),
+                ("max_residual_values", C.c_double)]
+
+
 class SynthSpec(C.Structure):
     _fields_ = [
         ("num_cells", C.c_uint32), ("num_loci", C.c_uint32), ("num_chromosomes", C.c_uint32),
@@ -43,7 +49,7 @@ class SynthSpec(C.Structure):
     ]
 
 
-# name -> (restype, argtypes): every symbol include/secedo_simmat.h declares
+# name -> (restype, argtypes): every symbol include/secedo_simmat.h and include/secedo_spectral.h declare
 SIGNATURES = {
     "secedo_simmat_normalization_from_string": (C.c_int, [C.c_char_p]),
     "secedo_simmat_last_error": (C.c_char_p, []),
@@ -85,6 +91,11 @@ SIGNATURES = {
                                      C.POINTER(PileupInfo), _vp, _vp, _vp, _vp]),
     "secedo_pileup_last_error": (C.c_char_p, []),
     "secedo_synth_generate": (C.c_int, [C.POINTER(SynthSpec), _u64p, _u64p, _vp, _vp, _vp, _vp, _vp]),
+    "secedo_laplacian_device": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
+    "secedo_spectral_eigs_device": (C.c_int, [C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
+                                              C.c_uint32, _vp, _vp, C.POINTER(SpectralInfo), _vp]),
+    "secedo_spectral_eigs": (C.c_int, [C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32,
+                                       _vp, _vp, C.POINTER(SpectralInfo)]),
 }
 
 _lib = None

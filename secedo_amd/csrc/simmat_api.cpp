@@ -118,6 +118,11 @@ hipError_t buf_upload(DevBuf &b, const T *src, size_t n) {
 
 }  // namespace
 
+namespace secedo {
+// for the other translation units of the library (spectral_api.cpp): one error slot per thread
+int api_fail(int code, const std::string &msg) { return fail(code, msg); }
+}  // namespace secedo
+
 extern "C" {
 
 const char *secedo_simmat_last_error(void) { return g_last_error.c_str(); }

@@ -1,0 +1,331 @@
+// spectral_api.cpp -- host side of include/secedo_spectral.h.
+//
+// Smallest eigenpairs of L = I - D^-1/2 A D^-1/2 (reference: laplacian() + arma::eig_sym,
+// spectral_clustering.cpp:33-52, :127-138) without forming L and without the O(N^3) decomposition.
+// The wanted pairs are the LARGEST of T = (I + D^-1/2 A D^-1/2) / 2 (spectrum in [0, 1],
+// lambda_L = 2 (1 - tau)), found by a restarted block Lanczos iteration:
+//   * blocks of 32 vectors: one pass over the N x N matrix serves 32 vectors (apply_operator runs on
+//     the fp64 matrix cores and is bound by the 8 N^2 bytes of A);
+//   * full re-orthogonalisation against the cycle's basis (classical Gram-Schmidt twice) and a
+//     Cholesky QR of each new block, with dependent columns dropped -- so eigenvalue multiplicity
+//     up to 32 (disconnected cell graphs) and N < 32 need no special case;
+//   * Rayleigh-Ritz on the (6 x 32)-dimensional projection every cycle, on the host (sym_eig.cpp);
+//     residuals from the last coupling block; restart from the 32 best Ritz vectors.
+// The first start vector is D^1/2 1, the known eigenvector of eigenvalue 0.
+// The cell-cluster eigenvectors converge in the first cycle or two. The rest of the 20 values the
+// reference logs (and of the 7 vectors it uses when there are fewer clusters than that) sit at the
+// dense edge of the bulk of the spectrum, where the residual halves per cycle; a Chebyshev filter on
+// the bulk was tried and only pays from degree 32 on, where its products cost more than the cycles
+// they save (N = 8000: 0.36 s against 0.18 s) -- it is not in the code.
+#include "secedo_simmat.h"
+#include "secedo_spectral.h"
+#include "spectral_kernels.hpp"
+#include "sym_eig.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace secedo {
+int api_fail(int code, const std::string &msg);  // simmat_api.cpp: sets secedo_simmat_last_error()
+}
+
+namespace {
+
+using secedo::spectral::kBlockWidth;
+constexpr uint32_t BW = kBlockWidth;
+constexpr uint32_t kCycleBlocks = 6;  // Krylov blocks per restart cycle: a 192-dimensional projection
+
+struct Buf {
+    void *p = nullptr;
+    ~Buf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    double *d() const { return static_cast<double *>(p); }
+};
+
+#define SP_TRY(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess)                                                                            \
+            return secedo::api_fail(SECEDO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));    \
+    } while (0)
+
+// W^T W = R^T R with the columns scaled to unit norm first. A column whose norm is rounding noise,
+// or whose part outside the span of the columns before it is below 1e-5 of its norm, is dropped: it
+// keeps its coefficients on the surviving directions in R (W = Q R still holds up to the dropped
+// remainder), its row of R and its row and column of R^-1 are zero, so the orthonormalised block
+// Q = W R^-1 has a zero column there. Returns R (upper triangular, row-major), R^-1, and who survived.
+void cholesky_drop(const std::vector<double> &G, std::vector<double> &R, std::vector<double> &Rinv,
+                   std::vector<char> &alive) {
+    const int n = (int)BW;
+    std::vector<double> d(n, 0.0), S((size_t)n * n, 0.0);
+    alive.assign(n, 1);
+    for (int c = 0; c < n; ++c) {
+        const double g = G[(size_t)c * n + c];
+        if (g > 1e-26) d[c] = std::sqrt(g);  // norm above 1e-13
+        else alive[c] = 0;                   // an exhausted direction
+    }
+    for (int c = 0; c < n; ++c) {
+        if (!alive[c]) continue;
+        double piv = 1.0;
+        for (int k = 0; k < c; ++k) {
+            if (!alive[k]) continue;
+            double v = G[(size_t)k * n + c] / (d[k] * d[c]);
+            for (int t = 0; t < k; ++t) v -= S[(size_t)t * n + k] * S[(size_t)t * n + c];
+            v /= S[(size_t)k * n + k];
+            S[(size_t)k * n + c] = v;
+            piv -= v * v;
+        }
+        if (piv <= 1e-10) alive[c] = 0;  // dependent on the columns before it
+        else S[(size_t)c * n + c] = std::sqrt(piv);
+    }
+    R.assign((size_t)n * n, 0.0);
+    Rinv.assign((size_t)n * n, 0.0);
+    for (int r = 0; r < n; ++r)
+        for (int c = r; c < n; ++c) R[(size_t)r * n + c] = S[(size_t)r * n + c] * d[c];
+    // inverse of the surviving triangle by back substitution
+    for (int c = 0; c < n; ++c) {
+        if (!alive[c]) continue;
+        Rinv[(size_t)c * n + c] = 1.0 / R[(size_t)c * n + c];
+        for (int r = c - 1; r >= 0; --r) {
+            if (!alive[r]) continue;
+            double v = 0.0;
+            for (int t = r + 1; t <= c; ++t)
+                if (alive[t]) v -= R[(size_t)r * n + t] * Rinv[(size_t)t * n + c];
+            Rinv[(size_t)r * n + c] = v / R[(size_t)r * n + r];
+        }
+    }
+}
+
+std::vector<double> matmul32(const std::vector<double> &a, const std::vector<double> &b) {
+    std::vector<double> c((size_t)BW * BW, 0.0);
+    for (uint32_t i = 0; i < BW; ++i)
+        for (uint32_t k = 0; k < BW; ++k) {
+            const double v = a[(size_t)i * BW + k];
+            if (v == 0.0) continue;
+            for (uint32_t j = 0; j < BW; ++j) c[(size_t)i * BW + j] += v * b[(size_t)k * BW + j];
+        }
+    return c;
+}
+
+struct Solver {
+    uint32_t n = 0;
+    hipStream_t stream = nullptr;
+    const double *A = nullptr;
+    Buf s, root, Q, W, Z, P, Gp, G, M;
+    size_t blk_stride = 0;
+
+    int setup(const double *d_sim, uint32_t n_, hipStream_t st) {
+        using namespace secedo::spectral;
+        n = n_;
+        stream = st;
+        A = d_sim;
+        blk_stride = (size_t)n * BW;
+        SP_TRY(s.alloc((size_t)n * 8));
+        SP_TRY(root.alloc((size_t)n * 8));
+        SP_TRY(Q.alloc((kCycleBlocks + 1) * blk_stride * 8));
+        SP_TRY(W.alloc(blk_stride * 8));
+        SP_TRY(Z.alloc((size_t)pad16(n) * BW * 8));
+        SP_TRY(P.alloc((size_t)product_segments(n) * pad16(n) * BW * 8));
+        SP_TRY(Gp.alloc((size_t)gram_chunks(n) * (kCycleBlocks + 1) * BW * BW * 8));
+        SP_TRY(G.alloc((size_t)(kCycleBlocks + 1) * BW * BW * 8));
+        SP_TRY(M.alloc((size_t)(kCycleBlocks + 1) * BW * BW * 8));
+        return SECEDO_OK;
+    }
+    double *block(uint32_t b) const { return Q.d() + b * blk_stride; }
+    // G[blk] = Q[blk]^T w for blk < nblk, to the host
+    int gram_host(uint32_t nblk, const double *basis, const double *w, std::vector<double> &out) {
+        SP_TRY(secedo::spectral::gram(n, basis, blk_stride, nblk, w, Gp.d(), G.d(), stream));
+        out.resize((size_t)nblk * BW * BW);
+        SP_TRY(hipMemcpyAsync(out.data(), G.d(), out.size() * 8, hipMemcpyDeviceToHost, stream));
+        SP_TRY(hipStreamSynchronize(stream));
+        return SECEDO_OK;
+    }
+    int upload_small(const std::vector<double> &m) {
+        SP_TRY(hipMemcpyAsync(M.d(), m.data(), m.size() * 8, hipMemcpyHostToDevice, stream));
+        return SECEDO_OK;
+    }
+    // dst = orthonormalised src (Cholesky QR, twice); R with src = dst R. src is overwritten.
+    int orthonormalise(double *src, double *dst, std::vector<double> &R, std::vector<char> &alive) {
+        std::vector<double> g, r1, r1inv, r2, r2inv;
+        std::vector<char> alive1;
+        int rc = gram_host(1, src, src, g);
+        if (rc) return rc;
+        cholesky_drop(g, r1, r1inv, alive1);
+        if ((rc = upload_small(r1inv))) return rc;
+        SP_TRY(secedo::spectral::block_combine(n, src, blk_stride, 1, M.d(), 1.0, 0.0, dst, stream));
+        if ((rc = gram_host(1, dst, dst, g))) return rc;
+        cholesky_drop(g, r2, r2inv, alive);
+        if ((rc = upload_small(r2inv))) return rc;
+        SP_TRY(secedo::spectral::block_combine(n, dst, blk_stride, 1, M.d(), 1.0, 0.0, src, stream));
+        SP_TRY(hipMemcpyAsync(dst, src, blk_stride * 8, hipMemcpyDeviceToDevice, stream));
+        R = matmul32(r2, r1);
+        return SECEDO_OK;
+    }
+};
+
+int solve(int device_id, const double *d_sim, uint32_t n, uint32_t n_values, uint32_t n_vectors, double tol,
+          uint32_t max_cycles, double *eigenvalues, double *d_eigenvectors, secedo_spectral_info *info,
+          hipStream_t stream) {
+    using namespace secedo::spectral;
+    if (!d_sim || !eigenvalues) return secedo::api_fail(SECEDO_E_INVALID_ARG, "null argument");
+    if (n == 0) return secedo::api_fail(SECEDO_E_INVALID_ARG, "the similarity matrix is empty");
+    if (n_values == 0 || n_values > std::min<uint32_t>(n, SECEDO_SPECTRAL_MAX_VALUES))
+        return secedo::api_fail(SECEDO_E_INVALID_ARG, "n_values must be in [1, min(n, 32)]");
+    if (n_vectors > n_values) return secedo::api_fail(SECEDO_E_INVALID_ARG, "n_vectors must not exceed n_values");
+    if (n_vectors && !d_eigenvectors) return secedo::api_fail(SECEDO_E_INVALID_ARG, "d_eigenvectors is null");
+    if ((uint64_t)n * n >= (1ull << 40)) return secedo::api_fail(SECEDO_E_LIMIT, "matrix too large");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return secedo::api_fail(SECEDO_E_NO_DEVICE, "no HIP device is visible: the spectral step has no CPU fallback");
+    if (device_id < 0 || device_id >= n_dev) return secedo::api_fail(SECEDO_E_NO_DEVICE, "device id out of range");
+    SP_TRY(hipSetDevice(device_id));
+    if (tol <= 0.0) tol = 1e-9;
+    if (max_cycles == 0) max_cycles = 60;
+    const double tol_values = std::max(tol, 1e-6);
+
+    Solver sv;
+    int rc = sv.setup(d_sim, n, stream);
+    if (rc) return rc;
+    SP_TRY(row_scale(d_sim, n, sv.s.d(), sv.root.d(), stream));
+    SP_TRY(init_block(n, sv.root.d(), sv.W.d(), stream));
+    std::vector<double> R, R_last;
+    std::vector<char> alive;
+    std::vector<char> basis_alive((size_t)(kCycleBlocks + 1) * BW, 1);
+    auto note_alive = [&](uint32_t blk) { std::copy(alive.begin(), alive.end(), basis_alive.begin() + blk * BW); };
+    if ((rc = sv.orthonormalise(sv.W.d(), sv.block(0), R, alive))) return rc;
+    note_alive(0);
+
+    const uint32_t m = kCycleBlocks * BW;
+    std::vector<double> H((size_t)m * m), theta, U, g;
+    secedo_spectral_info inf;
+    std::memset(&inf, 0, sizeof(inf));
+    std::vector<uint32_t> top(BW);
+    std::vector<double> res(BW, 0.0);
+    for (uint32_t cycle = 0; cycle < max_cycles; ++cycle) {
+        std::fill(H.begin(), H.end(), 0.0);
+        for (uint32_t j = 0; j < kCycleBlocks; ++j) {
+            SP_TRY(apply_operator(d_sim, n, sv.s.d(), sv.block(j), sv.Z.d(), sv.P.d(), sv.W.d(), stream));
+            ++inf.block_products;
+            for (int pass = 0; pass < 2; ++pass) {  // classical Gram-Schmidt, twice
+                if ((rc = sv.gram_host(j + 1, sv.Q.d(), sv.W.d(), g))) return rc;
+                for (uint32_t blk = 0; blk <= j; ++blk)
+                    for (uint32_t a = 0; a < BW; ++a)
+                        for (uint32_t c = 0; c < BW; ++c)
+                            H[(size_t)(blk * BW + a) * m + j * BW + c] += g[((size_t)blk * BW + a) * BW + c];
+                // the coefficients are still in G on the device
+                SP_TRY(block_combine(n, sv.Q.d(), sv.blk_stride, j + 1, sv.G.d(), -1.0, 1.0, sv.W.d(), stream));
+            }
+            if ((rc = sv.orthonormalise(sv.W.d(), sv.block(j + 1), R, alive))) return rc;
+            note_alive(j + 1);
+            if (j + 1 == kCycleBlocks) R_last = R;
+        }
+        // the projection is symmetric: take the computed block upper triangle, mirror it
+        for (uint32_t r = 0; r < m; ++r)
+            for (uint32_t c = 0; c < m; ++c)
+                if (r / BW > c / BW) H[(size_t)r * m + c] = H[(size_t)c * m + r];
+        // a dropped basis column is a zero vector: keep its (zero) Ritz value below the spectrum of T
+        for (uint32_t r = 0; r < m; ++r)
+            if (!basis_alive[r]) H[(size_t)r * m + r] = -1.0;
+        if (!secedo::sym_eig((int)m, H, theta, U))
+            return secedo::api_fail(SECEDO_E_LIMIT, "the projected eigenproblem did not converge");
+        // the largest tau first; residual of a Ritz pair = || R_last u_last || (T V_j = sum_blk V_blk H_blk,j
+        // + V_{j+1} R_j, so T y - theta y = V_6 R_5 u_last for y = V u)
+        for (uint32_t k = 0; k < BW; ++k) top[k] = m - 1 - k;
+        for (uint32_t k = 0; k < BW; ++k) {
+            double r2 = 0.0;
+            for (uint32_t a = 0; a < BW; ++a) {
+                double v = 0.0;
+                for (uint32_t c = 0; c < BW; ++c)
+                    v += R_last[(size_t)a * BW + c] * U[(size_t)((kCycleBlocks - 1) * BW + c) * m + top[k]];
+                r2 += v * v;
+            }
+            res[k] = 2.0 * std::sqrt(r2);  // in units of L = 2 (I - T)
+        }
+        inf.cycles = cycle + 1;
+        inf.max_residual_vectors = 0.0;
+        inf.max_residual_values = 0.0;
+        for (uint32_t k = 0; k < n_values; ++k) {
+            if (k < n_vectors) inf.max_residual_vectors = std::max(inf.max_residual_vectors, res[k]);
+            inf.max_residual_values = std::max(inf.max_residual_values, res[k]);
+        }
+        inf.converged = (inf.max_residual_vectors <= tol && inf.max_residual_values <= tol_values) ? 1u : 0u;
+        if (std::getenv("SECEDO_SPECTRAL_TRACE")) {  // diagnostics: residuals of the wanted pairs per cycle
+            std::fprintf(stderr, "[spectral] cycle %u:", cycle);
+            for (uint32_t k = 0; k < n_values; ++k) std::fprintf(stderr, " %.1e", res[k]);
+            std::fprintf(stderr, "\n");
+        }
+        // Ritz vectors of the 32 best pairs: Y = V U[:, top]
+        std::vector<double> coeff((size_t)kCycleBlocks * BW * BW);
+        for (uint32_t blk = 0; blk < kCycleBlocks; ++blk)
+            for (uint32_t a = 0; a < BW; ++a)
+                for (uint32_t k = 0; k < BW; ++k)
+                    coeff[((size_t)blk * BW + a) * BW + k] = U[(size_t)(blk * BW + a) * m + top[k]];
+        if ((rc = sv.upload_small(coeff))) return rc;
+        SP_TRY(block_combine(n, sv.Q.d(), sv.blk_stride, kCycleBlocks, sv.M.d(), 1.0, 0.0, sv.W.d(), stream));
+        if (inf.converged || cycle + 1 == max_cycles) {
+            for (uint32_t k = 0; k < n_values; ++k) eigenvalues[k] = 2.0 * (1.0 - theta[top[k]]);
+            SP_TRY(write_vectors(n, sv.W.d(), n_vectors, d_eigenvectors, stream));
+            SP_TRY(hipStreamSynchronize(stream));
+            break;
+        }
+        if ((rc = sv.orthonormalise(sv.W.d(), sv.block(0), R, alive))) return rc;
+        note_alive(0);
+    }
+    if (info) *info = inf;
+    return SECEDO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int secedo_laplacian_device(const double *d_similarity, uint32_t n, double *d_out, void *stream) {
+    if (!d_similarity || !d_out) return secedo::api_fail(SECEDO_E_INVALID_ARG, "null argument");
+    if (n == 0) return SECEDO_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Buf s, root;
+    SP_TRY(s.alloc((size_t)n * 8));
+    SP_TRY(root.alloc((size_t)n * 8));
+    SP_TRY(secedo::spectral::row_scale(d_similarity, n, s.d(), root.d(), st));
+    SP_TRY(secedo::spectral::laplacian(d_similarity, s.d(), n, d_out, st));
+    SP_TRY(hipStreamSynchronize(st));  // the scratch is freed on return
+    return SECEDO_OK;
+}
+
+int secedo_spectral_eigs_device(int device_id, const double *d_similarity, uint32_t n, uint32_t n_values,
+                                uint32_t n_vectors, double tol, uint32_t max_cycles, double *eigenvalues,
+                                double *d_eigenvectors, secedo_spectral_info *info, void *stream) {
+    return solve(device_id, d_similarity, n, n_values, n_vectors, tol, max_cycles, eigenvalues, d_eigenvectors, info,
+                 static_cast<hipStream_t>(stream));
+}
+
+int secedo_spectral_eigs(int device_id, const double *similarity, uint32_t n, uint32_t n_values,
+                         uint32_t n_vectors, double tol, uint32_t max_cycles, double *eigenvalues,
+                         double *eigenvectors, secedo_spectral_info *info) {
+    if (!similarity) return secedo::api_fail(SECEDO_E_INVALID_ARG, "similarity is null");
+    if (n_vectors && !eigenvectors) return secedo::api_fail(SECEDO_E_INVALID_ARG, "eigenvectors is null");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return secedo::api_fail(SECEDO_E_NO_DEVICE, "no HIP device is visible: the spectral step has no CPU fallback");
+    if (device_id < 0 || device_id >= n_dev) return secedo::api_fail(SECEDO_E_NO_DEVICE, "device id out of range");
+    SP_TRY(hipSetDevice(device_id));
+    Buf a, v;
+    SP_TRY(a.alloc((size_t)n * n * 8));
+    SP_TRY(v.alloc((size_t)n * std::max<uint32_t>(n_vectors, 1) * 8));
+    SP_TRY(hipMemcpy(a.p, similarity, (size_t)n * n * 8, hipMemcpyHostToDevice));
+    const int rc = solve(device_id, a.d(), n, n_values, n_vectors, tol, max_cycles, eigenvalues, v.d(), info, nullptr);
+    if (rc) return rc;
+    if (n_vectors) SP_TRY(hipMemcpy(eigenvectors, v.p, (size_t)n * n_vectors * 8, hipMemcpyDeviceToHost));
+    return SECEDO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,306 @@
+// spectral_kernels.hip -- gfx950 kernels of the spectral step.
+//
+//   row_scale        row sums of the similarity matrix -> D^-1/2           (HBM-bound, N^2 read)
+//   laplacian        the dense normalised Laplacian, for callers that want the reference's
+//                    laplacian() itself (spectral_clustering.cpp:33-52)
+//   apply_operator   Y = (X + D^-1/2 A D^-1/2 X) / 2 for a block of 32 vectors: the matrix is read
+//                    ONCE for 32 vectors. This is a tall-skinny fp64 GEMM, so it runs on the matrix
+//                    cores (v_mfma_f64_16x16x4_f64); it is bound by the N^2 * 8 bytes of A.
+//   gram, block_combine, write_vectors   N x 32 bookkeeping of the block Krylov iteration
+//
+// The product uses the symmetry of A: Y^T = Z^T A, so the B operand of the MFMA (4 k x 16 columns)
+// is 4 rows x 128 contiguous bytes of the row-major matrix -- coalesced without a transpose.
+#include "spectral_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+namespace secedo {
+namespace spectral {
+
+namespace {
+
+constexpr int BW = (int)kBlockWidth;
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_row_scale(const double *A, uint32_t n, double *s, double *root) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t row = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (row >= n) return;
+    const double *a = A + (size_t)row * n;
+    double sum = 0.0;
+    for (uint32_t j = lane; j < n; j += 64u) sum += a[j];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if (lane == 0) {
+        s[row] = sum == 0.0 ? 0.0 : 1.0 / sqrt(sum);
+        root[row] = sum > 0.0 ? sqrt(sum) : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_laplacian(const double *A, const double *s, uint32_t n, double *out) {
+    const size_t total = (size_t)n * n;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const uint32_t r = (uint32_t)(idx / n), c = (uint32_t)(idx % n);
+        out[idx] = (r == c ? 1.0 : 0.0) - s[r] * s[c] * A[idx];
+    }
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_init_block(uint32_t n, const double *root, double *X) {
+    const size_t total = (size_t)n * BW;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const uint32_t j = (uint32_t)(idx / BW), c = (uint32_t)(idx % BW);
+        // 53 random bits -> (-1, 1)
+        const double u = (double)(mix64(idx) >> 11) * (1.0 / 9007199254740992.0);
+        X[idx] = c == 0 ? root[j] : 2.0 * u - 1.0;
+    }
+}
+
+// Z[j][c] = s[j] * X[j][c]; rows n .. pad16(n) are zero
+__global__ __launch_bounds__(256) void k_scale_rows(uint32_t n, uint32_t n_pad, const double *s, const double *X,
+                                                   double *Z) {
+    const size_t total = (size_t)n_pad * BW;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const uint32_t j = (uint32_t)(idx / BW);
+        Z[idx] = j < n ? s[j] * X[idx] : 0.0;
+    }
+}
+
+// P[seg][i][c] = sum over the segment's rows j of Z[j][c] * A[j][i]. One wave owns 16 columns i and
+// both 16-wide halves of c: per step of 4 rows, one 8-byte load of A per lane feeds two MFMAs.
+__global__ __launch_bounds__(256) void k_product_partial(const double *A, uint32_t n, uint32_t n_pad4,
+                                                        const double *Z, uint32_t seg_rows, uint32_t n_pad16,
+                                                        double *P) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t i0 = (blockIdx.x * 4u + wave) * 16u;
+    if (i0 >= n_pad16) return;
+    const uint32_t col = lane & 15u, kq = lane >> 4;
+    const uint32_t ic = min(i0 + col, n - 1u);  // columns past n are computed from column n-1 and never read
+    // segments are multiples of 16 rows, Z has pad16(n) rows: four steps of 4 rows per trip, the 12
+    // loads of a trip in flight together
+    const uint32_t j_begin = blockIdx.y * seg_rows, j_end = min(n_pad4, j_begin + seg_rows);
+    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (uint32_t j0 = j_begin; j0 < j_end; j0 += 16u) {
+        double a[4], z0[4], z1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t jk = j0 + 4u * u + kq;
+            a[u] = A[(size_t)min(jk, n - 1u) * n + ic];  // rows past n meet zero rows of Z
+            z0[u] = Z[(size_t)jk * BW + col];
+            z1[u] = Z[(size_t)jk * BW + 16u + col];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(z0[u], a[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(z1[u], a[u], acc1, 0, 0, 0);
+        }
+    }
+    // C/D layout of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg
+    double *p = P + ((size_t)blockIdx.y * n_pad16 + i0 + col) * BW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        p[kq + 4u * r] = acc0[r];
+        p[16u + kq + 4u * r] = acc1[r];
+    }
+}
+
+// Y[i][c] = (X[i][c] + s[i] * sum_seg P[seg][i][c]) / 2, segments added in order
+__global__ __launch_bounds__(256) void k_product_finish(uint32_t n, uint32_t n_seg, uint32_t n_pad16,
+                                                       const double *P, const double *s, const double *X,
+                                                       double *Y) {
+    const size_t total = (size_t)n * BW;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const uint32_t i = (uint32_t)(idx / BW);
+        double sum = 0.0;
+        for (uint32_t g = 0; g < n_seg; ++g) sum += P[(size_t)g * n_pad16 * BW + idx];
+        Y[idx] = 0.5 * (X[idx] + s[i] * sum);
+    }
+}
+
+// Gp[chunk][blk][a][c] = sum over the chunk's rows j of Q[blk][j][a] * W[j][c]
+__global__ __launch_bounds__(256) void k_gram_partial(uint32_t n, const double *Q, size_t blk_stride,
+                                                     const double *W, uint32_t nblk, double *Gp) {
+    __shared__ double Qs[kGramChunk][BW];
+    __shared__ double Ws[kGramChunk][BW];
+    const uint32_t chunk = blockIdx.x, blk = blockIdx.y;
+    const uint32_t j0 = chunk * kGramChunk, rows = min(kGramChunk, n - j0);
+    const double *q = Q + blk * blk_stride + (size_t)j0 * BW;
+    const double *w = W + (size_t)j0 * BW;
+    for (uint32_t i = threadIdx.x; i < rows * BW; i += 256u) {
+        (&Qs[0][0])[i] = q[i];
+        (&Ws[0][0])[i] = w[i];
+    }
+    __syncthreads();
+    const uint32_t a = threadIdx.x >> 3, c0 = (threadIdx.x & 7u) * 4u;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (uint32_t j = 0; j < rows; ++j) {
+        const double qa = Qs[j][a];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += qa * Ws[j][c0 + u];
+    }
+    double *out = Gp + ((size_t)chunk * nblk + blk) * BW * BW + a * BW + c0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) out[u] = acc[u];
+}
+
+// G[blk] = sum over chunks of Gp[chunk][blk], chunks added in order (deterministic). One thread per
+// element, four workgroups per block; the loads of eight chunks are in flight together.
+__global__ __launch_bounds__(256) void k_gram_reduce(uint32_t n_chunks, uint32_t nblk, const double *Gp, double *G) {
+    const uint32_t blk = blockIdx.x >> 2, e = (blockIdx.x & 3u) * 256u + threadIdx.x;
+    const size_t stride = (size_t)nblk * BW * BW;
+    const double *p = Gp + (size_t)blk * BW * BW + e;
+    double sum = 0.0;
+    uint32_t ch = 0;
+    for (; ch + 8 <= n_chunks; ch += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(ch + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; ch < n_chunks; ++ch) sum += p[(size_t)ch * stride];
+    G[(size_t)blk * BW * BW + e] = sum;
+}
+
+// out[j][c] = beta * out[j][c] + alpha * sum_blk sum_a Q[blk][j][a] * M[blk][a][c]
+// 16 rows per workgroup (enough workgroups to cover the chip at N = 4096), 2 columns per thread
+__global__ __launch_bounds__(256) void k_block_combine(uint32_t n, const double *Q, size_t blk_stride, uint32_t nblk,
+                                                      const double *M, double alpha, double beta, double *out) {
+    constexpr uint32_t ROWS = 16;
+    __shared__ double Ms[BW][BW];
+    __shared__ double Qs[ROWS][BW + 1];
+    const uint32_t j0 = blockIdx.x * ROWS, rows = min(ROWS, n - j0);
+    const uint32_t jr = threadIdx.x >> 4, c0 = (threadIdx.x & 15u) * 2u;
+    double acc0 = 0.0, acc1 = 0.0;
+    for (uint32_t blk = 0; blk < nblk; ++blk) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < BW * BW; i += 256u) (&Ms[0][0])[i] = M[(size_t)blk * BW * BW + i];
+        const double *q = Q + blk * blk_stride + (size_t)j0 * BW;
+        for (uint32_t i = threadIdx.x; i < rows * BW; i += 256u) Qs[i / BW][i % BW] = q[i];
+        __syncthreads();
+        if (jr < rows) {
+#pragma unroll 8
+            for (uint32_t a = 0; a < (uint32_t)BW; ++a) {
+                const double qa = Qs[jr][a];
+                acc0 += qa * Ms[a][c0];
+                acc1 += qa * Ms[a][c0 + 1];
+            }
+        }
+    }
+    if (jr < rows) {
+        double *o = out + (size_t)(j0 + jr) * BW + c0;
+        o[0] = (beta == 0.0 ? 0.0 : beta * o[0]) + alpha * acc0;
+        o[1] = (beta == 0.0 ? 0.0 : beta * o[1]) + alpha * acc1;
+    }
+}
+
+// one workgroup per output column
+__global__ __launch_bounds__(256) void k_write_vectors(uint32_t n, const double *Y, double *out) {
+    __shared__ double s_norm[256], s_best[256];
+    __shared__ uint32_t s_idx[256];
+    const uint32_t c = blockIdx.x;
+    double norm2 = 0.0, best = -1.0;
+    uint32_t best_i = 0;
+    for (uint32_t j = threadIdx.x; j < n; j += 256u) {
+        const double v = Y[(size_t)j * BW + c];
+        norm2 += v * v;
+        if (fabs(v) > best) {  // strided ascending: the first hit of a thread is its lowest index
+            best = fabs(v);
+            best_i = j;
+        }
+    }
+    s_norm[threadIdx.x] = norm2;
+    s_best[threadIdx.x] = best;
+    s_idx[threadIdx.x] = best_i;
+    __syncthreads();
+    for (uint32_t half = 128; half > 0; half >>= 1) {
+        if (threadIdx.x < half) {
+            s_norm[threadIdx.x] += s_norm[threadIdx.x + half];
+            const double ob = s_best[threadIdx.x + half];
+            const uint32_t oi = s_idx[threadIdx.x + half];
+            if (ob > s_best[threadIdx.x] || (ob == s_best[threadIdx.x] && oi < s_idx[threadIdx.x])) {
+                s_best[threadIdx.x] = ob;
+                s_idx[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const double norm = sqrt(s_norm[0]);
+    double scale = norm > 0.0 ? 1.0 / norm : 0.0;
+    if (Y[(size_t)s_idx[0] * BW + c] < 0.0) scale = -scale;
+    for (uint32_t j = threadIdx.x; j < n; j += 256u) out[(size_t)c * n + j] = scale * Y[(size_t)j * BW + c];
+}
+
+inline uint32_t grid_for(size_t total) {
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 256 * 16));
+}
+
+}  // namespace
+
+hipError_t row_scale(const double *A, uint32_t n, double *s, double *root, hipStream_t stream) {
+    hipLaunchKernelGGL(k_row_scale, dim3((n + 3) / 4), dim3(256), 0, stream, A, n, s, root);
+    return hipGetLastError();
+}
+
+hipError_t laplacian(const double *A, const double *s, uint32_t n, double *out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_laplacian, dim3(grid_for((size_t)n * n)), dim3(256), 0, stream, A, s, n, out);
+    return hipGetLastError();
+}
+
+hipError_t init_block(uint32_t n, const double *root, double *X, hipStream_t stream) {
+    hipLaunchKernelGGL(k_init_block, dim3(grid_for((size_t)n * BW)), dim3(256), 0, stream, n, root, X);
+    return hipGetLastError();
+}
+
+uint32_t product_segments(uint32_t n) {
+    // enough waves to fill 256 CUs: a workgroup column covers 64 matrix columns
+    const uint32_t cols = (pad16(n) + 63u) / 64u;
+    const uint32_t want = (2048u + cols - 1u) / cols;
+    const uint32_t most = std::max(1u, pad16(n) / 64u);  // at least 64 rows per segment
+    return std::max(1u, std::min({want, 64u, most}));
+}
+
+hipError_t apply_operator(const double *A, uint32_t n, const double *s, const double *X, double *Z, double *P,
+                          double *Y, hipStream_t stream) {
+    const uint32_t n4 = pad16(n), n16 = pad16(n), n_seg = product_segments(n);  // Z is padded to 16 rows too
+    const uint32_t seg_rows = ((n4 + n_seg - 1u) / n_seg + 15u) / 16u * 16u;
+    hipLaunchKernelGGL(k_scale_rows, dim3(grid_for((size_t)n4 * BW)), dim3(256), 0, stream, n, n4, s, X, Z);
+    hipLaunchKernelGGL(k_product_partial, dim3((n16 + 63u) / 64u, n_seg), dim3(256), 0, stream, A, n, n4, Z, seg_rows,
+                       n16, P);
+    hipLaunchKernelGGL(k_product_finish, dim3(grid_for((size_t)n * BW)), dim3(256), 0, stream, n, n_seg, n16, P, s, X,
+                       Y);
+    return hipGetLastError();
+}
+
+uint32_t gram_chunks(uint32_t n) { return (n + kGramChunk - 1u) / kGramChunk; }
+
+hipError_t gram(uint32_t n, const double *Q, size_t blk_stride, uint32_t nblk, const double *W, double *Gp,
+                double *G, hipStream_t stream) {
+    const uint32_t chunks = gram_chunks(n);
+    hipLaunchKernelGGL(k_gram_partial, dim3(chunks, nblk), dim3(256), 0, stream, n, Q, blk_stride, W, nblk, Gp);
+    hipLaunchKernelGGL(k_gram_reduce, dim3(nblk * 4u), dim3(256), 0, stream, chunks, nblk, Gp, G);
+    return hipGetLastError();
+}
+
+hipError_t block_combine(uint32_t n, const double *Q, size_t blk_stride, uint32_t nblk, const double *M,
+                         double alpha, double beta, double *out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_block_combine, dim3((n + 15u) / 16u), dim3(256), 0, stream, n, Q, blk_stride, nblk, M, alpha,
+                       beta, out);
+    return hipGetLastError();
+}
+
+hipError_t write_vectors(uint32_t n, const double *Y, uint32_t k, double *out, hipStream_t stream) {
+    if (k == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_write_vectors, dim3(k), dim3(256), 0, stream, n, Y, out);
+    return hipGetLastError();
+}
+
+}  // namespace spectral
+}  // namespace secedo

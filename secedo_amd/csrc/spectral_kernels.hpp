@@ -1,0 +1,51 @@
+// spectral_kernels.hpp -- launch wrappers of spectral_kernels.hip (gfx950). See spectral_api.cpp for
+// the iteration they serve. Block vectors are row-major n x 32 doubles ("32 interleaved vectors").
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace secedo {
+namespace spectral {
+
+constexpr uint32_t kBlockWidth = 32;  // vectors per block: two 16-wide MFMA tiles
+constexpr uint32_t kGramChunk = 128;  // rows per workgroup of the Gram kernel
+
+// s[i] = 1 / sqrt(sum_j A[i][j]) (0 when the sum is 0; reference spectral_clustering.cpp:34-43),
+// root[i] = sqrt(sum_j A[i][j])
+hipError_t row_scale(const double *A, uint32_t n, double *s, double *root, hipStream_t stream);
+
+// out = I - diag(s) A diag(s)   (spectral_clustering.cpp:44-50)
+hipError_t laplacian(const double *A, const double *s, uint32_t n, double *out, hipStream_t stream);
+
+// X[:, 0] = root (the known eigenvector of eigenvalue 0), the other columns a fixed pseudo-random fill
+hipError_t init_block(uint32_t n, const double *root, double *X, hipStream_t stream);
+
+// number of row segments the product is split into, and the padded row count of the partials
+uint32_t product_segments(uint32_t n);
+inline uint32_t pad16(uint32_t n) { return (n + 15u) / 16u * 16u; }
+inline uint32_t pad4(uint32_t n) { return (n + 3u) / 4u * 4u; }
+
+// Y = T X with T = (I + diag(s) A diag(s)) / 2, A symmetric; Z (pad16(n) x 32) and
+// P (segments x pad16(n) x 32) are scratch
+hipError_t apply_operator(const double *A, uint32_t n, const double *s, const double *X, double *Z, double *P,
+                          double *Y, hipStream_t stream);
+
+// G[blk] (32 x 32) = Q[blk]^T W for blk < nblk; Q blocks blk_stride doubles apart; Gp scratch of
+// gram_chunks(n) * nblk * 1024 doubles
+uint32_t gram_chunks(uint32_t n);
+hipError_t gram(uint32_t n, const double *Q, size_t blk_stride, uint32_t nblk, const double *W, double *Gp,
+                double *G, hipStream_t stream);
+
+// out = beta * out + alpha * sum_blk Q[blk] M[blk]   (M[blk] 32 x 32 row-major); out must not alias Q
+hipError_t block_combine(uint32_t n, const double *Q, size_t blk_stride, uint32_t nblk, const double *M,
+                         double alpha, double beta, double *out, hipStream_t stream);
+
+// out (column-major n x k) = the first k columns of Y, each scaled to unit norm and signed so that
+// its component of largest magnitude (lowest index on ties) is positive
+hipError_t write_vectors(uint32_t n, const double *Y, uint32_t k, double *out, hipStream_t stream);
+
+}  // namespace spectral
+}  // namespace secedo
