@@ -63,6 +63,9 @@ def _load_oracle():
         lib.oracle_filter.argtypes = [_u32p, C.c_uint32, _u32p, _u64p, _u32p, _u32p, _u32p, C.c_uint32,
                                       C.c_double, C.c_uint32, _u32p, _u32p, _u64p, _u32p, _u32p,
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        lib.oracle_em.restype = C.c_int
+        lib.oracle_em.argtypes = [_u32p, C.c_uint32, _u64p, _u32p, _u32p, C.c_uint32, C.c_double, _f64p,
+                                  C.c_uint32, C.c_uint32]
         lib.oracle_last_updates.restype = C.c_uint64
         lib.oracle_last_read_pairs.restype = C.c_uint64
         _oracle = lib
@@ -96,6 +99,9 @@ def _load_ref():
         lib.ref_filter.argtypes = [_u32p, C.c_uint32, _u32p, _u64p, _u32p, _u32p, _u32p, C.c_uint32,
                                    C.c_double, C.c_uint32, C.c_uint32, _u32p, _u32p, _u64p, _u32p, _u32p,
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        lib.ref_em.restype = C.c_int
+        lib.ref_em.argtypes = [_u32p, C.c_uint32, _u32p, _u64p, _u32p, _u32p, _u32p, C.c_uint32, C.c_double,
+                               _f64p, C.c_uint32]
         lib.ref_read_pileup_fetch.restype = None
         lib.ref_read_pileup_fetch.argtypes = [_u32p, _u64p, _u32p, _u32p]
         _ref = lib
@@ -251,3 +257,25 @@ def oracle_filter(p, id_to_pos, theta, cell_proportion=4):
 
 def ref_filter(p, id_to_pos, theta, cell_proportion=4, num_threads=2):
     return _run_filter(_load_ref().ref_filter, p, id_to_pos, theta, cell_proportion, extra=(num_threads,))
+
+
+def oracle_em(p, id_to_pos, theta, prob_cluster_b, max_iterations=1000):
+    """oracle/em_oracle.c on a FlatPileup -> (refined probabilities, iterations)."""
+    i2p = np.ascontiguousarray(id_to_pos, dtype=np.uint32)
+    prob = np.array(prob_cluster_b, dtype=np.float64)
+    rc = _load_oracle().oracle_em(p.chr_locus_off, len(p.chr_locus_off) - 1, p.locus_entry_off, p.id_base, i2p,
+                                  len(i2p), theta, prob, len(prob), max_iterations)
+    if rc < 0:
+        raise RuntimeError("oracle_em failed: %d" % rc)
+    return prob, rc
+
+
+def ref_em(p, id_to_pos, theta, prob_cluster_b):
+    """The compiled reference's expectation_maximization (expectation_maximization.cpp:125-161)."""
+    i2p = np.ascontiguousarray(id_to_pos, dtype=np.uint32)
+    prob = np.array(prob_cluster_b, dtype=np.float64)
+    rc = _load_ref().ref_em(p.chr_locus_off, len(p.chr_locus_off) - 1, p.locus_pos, p.locus_entry_off, p.read_ids,
+                            p.id_base, i2p, len(i2p), theta, prob, len(prob))
+    if rc != 0:
+        raise RuntimeError("ref_em failed: %d" % rc)
+    return prob

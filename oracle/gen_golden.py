@@ -299,13 +299,61 @@ def laplacian_kat():
     print("laplacian_kat: 3 x 3")
 
 
+def em_cases():
+    """EM refinement (expectation_maximization.cpp): the five inputs of the reference's own
+    tests/test_expectation_maximization.cpp:15-85 and three random pileups (one with a permuted
+    id_to_pos: the centres are weighted by prob[group id], the sums land at id_to_pos[group id]),
+    each with the compiled reference's output."""
+    def three_loci(cells_bases):
+        ents = [(1000 + i, c, b) for i, (c, b) in enumerate(cells_bases)]
+        return from_rows([[(1234, ents), (1235, ents), (1236, ents)]])  # positions are not used by EM
+
+    cases = {
+        "one_cell": (from_rows([[]]), np.zeros(0, dtype=np.uint32), [1.0]),
+        "two_cells_same": (three_loci([(0, 1), (1, 1)]), np.arange(2, dtype=np.uint32), [0.3, 0.4]),
+        "two_cells_different": (three_loci([(0, 1), (1, 2)]), np.arange(2, dtype=np.uint32), [0.01, 0.02]),
+        "four_cells_22": (three_loci([(0, 1), (1, 1), (2, 2), (3, 2)]), np.arange(4, dtype=np.uint32),
+                          [0.9, 0.02, 0.03, 0.9]),
+        "four_cells_31": (three_loci([(0, 2), (1, 1), (2, 2), (3, 2)]), np.arange(4, dtype=np.uint32),
+                          [0.9, 0.9, 0.03, 0.1]),
+    }
+    rng = np.random.default_rng(77)
+    for name, (n, nchr, L, cov, permute) in {"random_40": (40, 2, 300, 12, False),
+                                             "random_200": (200, 3, 400, 30, False),
+                                             "random_60_permuted": (60, 1, 500, 20, True)}.items():
+        p = random_pileup(int(rng.integers(1 << 30)), n, nchr, L, cov, 400)
+        # two clones: flip the base of the upper half of the cells at every third locus
+        idb = p.id_base.copy()
+        for l in range(0, len(p.locus_pos), 3):
+            b, e = int(p.locus_entry_off[l]), int(p.locus_entry_off[l + 1])
+            upper = (idb[b:e] >> 2) >= n // 2
+            idb[b:e] = np.where(upper, (idb[b:e] & ~np.uint32(3)) | ((idb[b:e] + 1) & 3), idb[b:e])
+        p = FlatPileup(p.chr_locus_off, p.locus_pos, p.locus_entry_off, p.read_ids, idb)
+        i2p = rng.permutation(n).astype(np.uint32) if permute else np.arange(n, dtype=np.uint32)
+        prob = np.clip(np.where(np.arange(n) >= n // 2, 0.7, 0.3) + 0.25 * rng.standard_normal(n), 0.01, 0.99)
+        cases[name] = (p, i2p, prob)
+    out = {}
+    for name, (p, i2p, prob) in cases.items():
+        ref = ob.ref_em(p, i2p, 1e-3, prob)
+        mine, iters = ob.oracle_em(p, i2p, 1e-3, prob)
+        assert np.max(np.abs(ref - mine)) <= 1e-12, (name, np.max(np.abs(ref - mine)))
+        for k, v in dict(chr_locus_off=p.chr_locus_off, locus_pos=p.locus_pos, locus_entry_off=p.locus_entry_off,
+                         read_ids=p.read_ids, id_base=p.id_base, id_to_pos=i2p,
+                         prob_in=np.asarray(prob, dtype=np.float64), prob_out=ref,
+                         iterations=np.int64(iters)).items():
+            out[name + "__" + k] = v
+        print("em %-22s cells %4d entries %6d iterations %d  max|ref - oracle| %.1e" % (
+            name, len(prob), len(p.read_ids), iters, np.max(np.abs(ref - mine)) if len(prob) else 0))
+    np.savez_compressed(os.path.join(GOLDEN, "em_cases.npz"), theta=np.float64(1e-3), **out)
+
+
 def main():
     only = set(sys.argv[1:])
     if not ob.have_ref():
         sys.exit("oracle/_ref/libsecedo_ref.so missing: run `make -C oracle ref` in the container")
     os.makedirs(GOLDEN, exist_ok=True)
     for fn in (semantic_probes, kat_llr_table, reference_pileup_files, divide_clusters_shaped,
-               random_cases, filter_cases, reader_cases, laplacian_kat):
+               random_cases, filter_cases, reader_cases, laplacian_kat, em_cases):
         if not only or fn.__name__ in only:
             fn()
 

@@ -9,6 +9,7 @@
  *   (c) serve as bench.py's cpu_baseline of kind "reference".
  * The flat layout is the one of oracle/simmat_oracle.h.
  */
+#include "expectation_maximization.hpp" // reference: expectation_maximization
 #include "similarity_matrix.hpp"      // reference: computeSimilarityMatrix
 #include "util/is_significant.hpp"    // reference: Filter
 #include "util/pileup_reader.hpp"     // reference: read_pileup, get_grouping
@@ -125,6 +126,37 @@ void ref_read_pileup_fetch(uint32_t *locus_pos, uint64_t *locus_entry_off, uint3
     }
     locus_entry_off[l] = e;
     g_read_result.clear();
+}
+
+// expectation_maximization (expectation_maximization.cpp:125-161) on the flat layout. prob_cluster_b
+// in/out. Returns 0, -3 for an id the reference's u16 packing cannot hold, -4 for an exception
+// (vector::at on a group outside id_to_pos / a position outside the probability vector).
+int ref_em(const uint32_t *chr_locus_off, uint32_t n_chr, const uint32_t *locus_pos,
+           const uint64_t *locus_entry_off, const uint32_t *read_ids, const uint32_t *id_base,
+           const uint32_t *id_to_pos, uint32_t n_groups, double theta, double *prob_cluster_b, uint32_t n_cells) {
+    std::vector<std::vector<PosData>> pos_data(n_chr);
+    for (uint32_t c = 0; c < n_chr; ++c) {
+        for (uint32_t l = chr_locus_off[c]; l < chr_locus_off[c + 1]; ++l) {
+            const uint64_t b = locus_entry_off[l], e = locus_entry_off[l + 1];
+            std::vector<uint32_t> ids(read_ids + b, read_ids + e);
+            std::vector<uint16_t> packed(e - b);
+            for (uint64_t i = b; i < e; ++i) {
+                if (id_base[i] > 0xFFFFu) return -3;
+                packed[i - b] = static_cast<uint16_t>(id_base[i]);
+            }
+            pos_data[c].emplace_back(locus_pos[l], std::move(ids), std::move(packed));
+        }
+    }
+    std::vector<uint32_t> i2p(id_to_pos, id_to_pos + n_groups);
+    std::vector<double> prob(prob_cluster_b, prob_cluster_b + n_cells);
+    try {
+        QuietCout quiet;
+        expectation_maximization(pos_data, i2p, 1, theta, &prob);
+    } catch (...) {
+        return -4;
+    }
+    std::memcpy(prob_cluster_b, prob.data(), n_cells * sizeof(double));
+    return 0;
 }
 
 // Filter::is_significant on base counts (util/is_significant.cpp:78-138).

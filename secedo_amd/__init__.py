@@ -9,3 +9,4 @@ from .similarity_matrix import (InvalidNormalization, NORMALIZATIONS, SecedoErro
 from .filter import Filter, NO_POS, filter_resident  # noqa: F401,E402
 from .pileup_reader import get_grouping, read_pileup  # noqa: F401,E402
 from .spectral import laplacian, smallest_eigenpairs  # noqa: F401,E402
+from .em import expectation_maximization  # noqa: F401,E402

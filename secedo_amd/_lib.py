@@ -49,7 +49,7 @@ class SynthSpec(C.Structure):
     ]
 
 
-# name -> (restype, argtypes): every symbol include/secedo_simmat.h and include/secedo_spectral.h declare
+# name -> (restype, argtypes): every symbol the headers under include/ declare
 SIGNATURES = {
     "secedo_simmat_normalization_from_string": (C.c_int, [C.c_char_p]),
     "secedo_simmat_last_error": (C.c_char_p, []),
@@ -91,6 +91,10 @@ SIGNATURES = {
                                      C.POINTER(PileupInfo), _vp, _vp, _vp, _vp]),
     "secedo_pileup_last_error": (C.c_char_p, []),
     "secedo_synth_generate": (C.c_int, [C.POINTER(SynthSpec), _u64p, _u64p, _vp, _vp, _vp, _vp, _vp]),
+    "secedo_em_refine_device": (C.c_int, [C.c_int, _vp, C.c_uint32, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_double,
+                                          _vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), _vp]),
+    "secedo_em_refine": (C.c_int, [C.c_int, _vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.c_double, _vp, C.c_uint32,
+                                   C.c_uint32, C.POINTER(C.c_uint32)]),
     "secedo_laplacian_device": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
     "secedo_spectral_eigs_device": (C.c_int, [C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
                                               C.c_uint32, _vp, _vp, C.POINTER(SpectralInfo), _vp]),

@@ -24,11 +24,11 @@ def _has_gpu():
 
 def test_library_exports_every_declared_symbol():
     declared = set()
-    for name in ("secedo_simmat.h", "secedo_spectral.h"):
+    for name in ("secedo_simmat.h", "secedo_spectral.h", "secedo_em.h"):
         header = open(os.path.join(ROOT, "include", name)).read()
         header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
         declared |= set(re.findall(r"\b(secedo_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) >= 23
+    assert len(declared) >= 25
     lib = C.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), name
