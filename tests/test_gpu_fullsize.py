@@ -1,0 +1,62 @@
+"""BASELINE.json's full sizes. C2 (1000 cells x 50 K loci, the bench workload) is small enough for the
+oracle (about a second), so it is compared outright. C3 (8000 cells x 100 K loci, 2.96e9 updates) would
+take the oracle minutes: it is checked through what must hold at any size -- exact symmetry and zero
+diagonal, the post-conditions of ADD_MIN, tile ranges composing bit for bit, and the GPU
+packing agreeing with the sequential host emulation of the reference loop in every work counter and
+in every bit of the matrix."""
+import numpy as np
+import pytest
+import torch
+
+import secedo_amd
+from oracle import bindings as ob
+from secedo_amd.synth import CONFIGS, synth_config
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c2_full_size_against_the_oracle():
+    n = CONFIGS["C2"][0]
+    p = synth_config("C2")
+    for norm in ("ADD_MIN", "EXPONENTIATE"):
+        got = secedo_amd.compute_similarity_matrix(p, n, 1000, None, 0.01, 0.5, 0.01, 8, "", norm)
+        ref = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 8, norm)
+        assert gu.normwise_err(got, ref) <= 1e-9
+        assert np.array_equal(got, got.T) and not np.any(np.diag(got))
+    u_ref, pairs_ref = ob.oracle_last_updates(), ob.oracle_last_read_pairs()
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        plan.prepare(p, n, 1000, None, 8)
+        acc = plan.new_acc()
+        plan.accumulate(acc, 0.01, 0.5, 0.01)
+        assert plan.last_counts() == (u_ref, pairs_ref) == (63956330, pairs_ref)
+
+
+def test_c3_full_size_properties():
+    n = CONFIGS["C3"][0]
+    p = synth_config("C3")
+    mats, counts = {}, {}
+    for mode in ("device", "host"):
+        with secedo_amd.SimilarityMatrixPlan(0) as plan:
+            plan.set_packing(mode)
+            plan.prepare(p, n, 1000, None, 8)
+            assert plan.used_device_packing == (mode == "device")
+            acc = plan.new_acc()
+            plan.accumulate(acc, 0.01, 0.5, 0.01)
+            torch.cuda.synchronize()
+            counts[mode] = plan.last_counts() + (plan.num_entries, plan.num_reads)
+            mats[mode] = plan.finalize(acc, "ADD_MIN").clone()
+            if mode == "device":
+                # the same accumulator from three tile ranges, as three ranks would fill it
+                parts = plan.new_acc()
+                t = plan.num_tiles
+                for lo, hi in ((0, t // 3), (t // 3, t // 2), (t // 2, t)):
+                    plan.accumulate(parts, 0.01, 0.5, 0.01, lo, hi)
+                assert torch.equal(parts, acc)
+    assert counts["device"] == counts["host"]
+    assert counts["device"][0] == 2955670215  # the updates the bench line reports for C3
+    assert torch.equal(mats["device"], mats["host"])
+    m = mats["device"]
+    assert torch.equal(m, m.T) and not torch.any(torch.diagonal(m))
+    off_diag_min = (m + torch.diag(torch.full((n,), float("inf"), device=m.device, dtype=m.dtype))).min()
+    assert float(m.min()) == 0.0 and float(off_diag_min) == 0.0  # ADD_MIN: all >= 0, the best pair at 0
