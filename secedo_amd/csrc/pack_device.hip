@@ -55,6 +55,8 @@ struct Scalars {
     uint32_t num_ranges;
     uint32_t max_read_id;
     uint32_t regroup;     // a group too long for the in-group ranking: redo with the radix sorts
+    uint32_t long_reads;  // some id's entries span >= max_fragment_length: flushes may split it (k_split_update)
+    uint32_t split_changed;
     uint32_t pad;
     unsigned long long id_space;  // sum over chromosomes of (largest - smallest read id + 1)
     unsigned long long multi_entries;
@@ -69,6 +71,7 @@ struct Scalars {
 // stable sort gives. A group longer than kRankScanLimit raises Scalars::regroup and the caller
 // falls back to the radix sorts.
 constexpr uint32_t kRankScanLimit = 8192;
+constexpr int kMaxSplitRounds = 32;  // rounds of k_split_update before the host emulation takes over
 // the counting scheme for read ids needs a table over the id space: used while max id < factor * entries
 constexpr uint32_t kIdSpaceFactor = 4;
 
@@ -251,8 +254,9 @@ __global__ void k_check_positions(Raw in, Scalars *sc) {
 struct HeadKeepOp {
     const unsigned long long *skey;
     const uint32_t *keep;
+    const uint32_t *split;  // 1 where a flush re-opens the id as a new read (k_split_update)
     __device__ __forceinline__ unsigned long long operator()(uint32_t s) const {
-        const unsigned long long head = (s == 0 || skey[s] != skey[s - 1]) ? 1ull : 0ull;
+        const unsigned long long head = (s == 0 || skey[s] != skey[s - 1] || split[s]) ? 1ull : 0ull;
         return head | ((unsigned long long)keep[s] << 32);
     }
 };
@@ -262,12 +266,13 @@ __device__ __forceinline__ uint32_t incl_kept(unsigned long long v) { return (ui
 // duplicate-position rule (:387-395) per (read, locus) group of the sorted order, and the mark of
 // every read's first entry (in pileup order) for the appearance rank
 __global__ void k_dup_mark(Raw in, const unsigned long long *skey, const uint32_t *sval,
-                           const uint32_t *entry_locus, uint32_t n, uint32_t *keep, uint32_t *mark) {
+                           const uint32_t *entry_locus, const uint32_t *split, uint32_t n, uint32_t *keep,
+                           uint32_t *mark) {
     for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
         const uint32_t e = sval[s];
         const uint32_t l = entry_locus[e];
-        const bool same_read = s > 0 && skey[s] == skey[s - 1];
-        mark[e] = same_read ? 0u : 1u;
+        const bool same_read = s > 0 && skey[s] == skey[s - 1];  // same id: a split starts at a new locus
+        mark[e] = (same_read && !split[s]) ? 0u : 1u;
         if (s == 0) mark[n] = 0u;
         if (same_read && entry_locus[sval[s - 1]] == l) continue;  // not a group head
         uint32_t stored = s;  // position of the stored entry of this (read, locus)
@@ -319,8 +324,9 @@ __global__ __launch_bounds__(TPB) void k_read_info(Raw in, const unsigned long l
         const uint32_t e0 = sval[s0], e1 = sval[s1 - 1];
         const uint32_t p0 = in.locus_pos[entry_locus[e0]], p1 = in.locus_pos[entry_locus[e1]];
         // a read whose entries reach start + mfl can be flushed before its last entry arrives and is
-        // then re-opened as a new read (:368-371, :379-382): that schedule is emulated on the host
-        if (p1 - p0 >= mfl || (unsigned long long)p1 + mfl > 0xFFFFFFFFull) sc->need_host = 1;
+        // then re-opened as a new read (:368-371, :379-382): k_split_update finds where
+        if (p1 - p0 >= mfl) sc->long_reads = 1;
+        if ((unsigned long long)p1 + mfl > 0xFFFFFFFFull) sc->need_host = 1;
         const uint32_t rk = arank[e0];
         run_rank[r] = rk;
         starts_by_rank[rk] = p0;
@@ -355,29 +361,87 @@ __global__ void k_completed(Raw in, const uint32_t *starts_by_rank, const uint32
 
 // flush chain (:356-373): flushed = c(l) whenever c(l) - flushed >= 4 * num_threads. One workgroup
 // per chromosome; the chain is sequential, so lane 0 walks LDS tiles of the counts.
+// The loci at which a flush happens are listed per chromosome (flush_loci[l0 ..), flush_count[c]).
 __global__ __launch_bounds__(TPB) void k_flush_chain(Raw in, const uint32_t *cnt, uint32_t threshold,
-                                                    uint32_t *flushed_out) {
+                                                    uint32_t *flushed_out, uint32_t *flush_loci,
+                                                    uint32_t *flush_count) {
     __shared__ uint32_t buf[2048];
-    __shared__ uint32_t s_flushed;
+    __shared__ uint32_t s_flushed, s_listed;
     const uint32_t c = blockIdx.x;
     const uint32_t l0 = in.chr_locus_off[c], l1 = in.chr_locus_off[c + 1];
-    if (threadIdx.x == 0) s_flushed = 0;
+    if (threadIdx.x == 0) {
+        s_flushed = 0;
+        s_listed = 0;
+    }
     for (uint32_t base = l0; base < l1; base += 2048) {
         const uint32_t n = min(2048u, l1 - base);
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += TPB) buf[i] = cnt[base + i];
         __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t f = s_flushed;
+            uint32_t f = s_flushed, listed = s_listed;
             for (uint32_t i = 0; i < n; ++i) {
                 const uint32_t v = buf[i];
-                if (v - f >= threshold) f = v;  // v >= f: the counts never decrease
+                if (v - f >= threshold) {  // v >= f: the counts never decrease
+                    f = v;
+                    flush_loci[l0 + listed++] = base + i;
+                }
             }
             s_flushed = f;
+            s_listed = listed;
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) flushed_out[c] = s_flushed;
+    if (threadIdx.x == 0) {
+        flushed_out[c] = s_flushed;
+        flush_count[c] = s_listed;
+    }
+}
+
+// Where do flushes cut the reads whose entries span >= max_fragment_length? A flush at locus f (before
+// its entries are added, :356-373) erases every live read with start + mfl <= position(f); an entry
+// of an erased id opens a new read that starts there (:379-382). One thread per id walks the id's
+// entries (a handful) against the chromosome's flush loci. The cuts change the read starts, hence the
+// completed counts, hence possibly later flushes: the caller iterates until nothing changes.
+__global__ void k_split_update(Raw in, const unsigned long long *skey, const uint32_t *sval,
+                               const uint32_t *entry_locus, uint32_t mfl, const uint32_t *flush_loci,
+                               const uint32_t *flush_count, uint32_t *split, Scalars *sc) {
+    const uint32_t n = in.n_entries;
+    for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
+        if (s > 0 && skey[s] == skey[s - 1]) continue;  // not the first entry of an id
+        uint32_t end = s + 1;
+        while (end < n && skey[end] == skey[s]) ++end;
+        if (end == s + 1) continue;
+        const uint32_t l_first = entry_locus[sval[s]];
+        const uint32_t p_first = in.locus_pos[l_first], p_last = in.locus_pos[entry_locus[sval[end - 1]]];
+        if (p_last - p_first < mfl) continue;  // never in a flushed prefix before its last entry
+        const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l_first);
+        const uint32_t *fl = flush_loci + in.chr_locus_off[c];
+        const uint32_t n_fl = flush_count[c];
+        uint32_t seg_start = p_first, l_prev = l_first;
+        for (uint32_t t = s + 1; t < end; ++t) {
+            const uint32_t l_t = entry_locus[sval[t]];
+            uint32_t cut = 0;
+            if (l_t != l_prev) {
+                // the first flush locus after l_prev whose position has reached seg_start + mfl
+                uint32_t lo = 0, hi = n_fl;
+                const unsigned long long reach = (unsigned long long)seg_start + mfl;
+                while (lo < hi) {
+                    const uint32_t mid = lo + (hi - lo) / 2;
+                    if (fl[mid] <= l_prev || in.locus_pos[fl[mid]] < reach) lo = mid + 1; else hi = mid;
+                }
+                if (lo < n_fl && fl[lo] <= l_t) {
+                    cut = 1;
+                    seg_start = in.locus_pos[l_t];
+                }
+            }
+            if (split[t] != cut) {
+                split[t] = cut;
+                sc->split_changed = 1;
+            }
+            l_prev = l_t;
+        }
+    }
 }
 
 // The binning key: cell block | locus (lbits bits) | cell in block (7 bits) -- bit fields, so that
@@ -788,8 +852,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
 
     // ---- buffers (sized up front: a re-allocation in mid-pipeline would synchronise) -----------
     // MISC: Scalars | id_max[C] | id_negmin[C] | id_base[C+1] | rbeg[C+1] | flushed[C] | cnt[L] |
-    //       locus_chr[L] | locus_rel[L]
-    HIP_OK(S[MISC].ensure(sizeof(Scalars) + sizeof(uint32_t) * ((size_t)5 * C + 4 + (size_t)3 * L) + 64));
+    //       locus_chr[L] | locus_rel[L] | flush_loci[L] | flush_count[C]
+    HIP_OK(S[MISC].ensure(sizeof(Scalars) + sizeof(uint32_t) * ((size_t)6 * C + 4 + (size_t)4 * L) + 64));
     Scalars *sc = S[MISC].as<Scalars>();
     uint32_t *id_max = reinterpret_cast<uint32_t *>(sc + 1);
     uint32_t *id_negmin = id_max + C;
@@ -798,6 +862,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *flushed = rbeg + C + 1;
     uint32_t *cnt = flushed + C;
     uint32_t *locus_chr = cnt + L, *locus_rel = locus_chr + L;
+    uint32_t *flush_loci = locus_rel + L, *flush_count = flush_loci + L;
     // KEY_A: sort keys in, later mark[E+1] | arank[E+1], later the per-(block, locus) counts
     HIP_OK(S[KEY_A].ensure(std::max<size_t>({(size_t)E * 8, ((size_t)2 * E + 4) * 4, (n_off_max + 1) * 4})));
     // KEY_B: sorted keys, later (counting path) the kept entries grouped by (block, locus)
@@ -823,7 +888,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         {
             hipcub::CountingInputIterator<uint32_t> positions(0u);
             hipcub::TransformInputIterator<unsigned long long, HeadKeepOp, hipcub::CountingInputIterator<uint32_t>>
-                    flags(positions, HeadKeepOp{key_b, val_a});
+                    flags(positions, HeadKeepOp{key_b, val_a, val_a});
             HIP_OK(hipcub::DeviceScan::InclusiveSum(nullptr, need, flags, key_a, (int)E, stream));
             most = std::max(most, need);
         }
@@ -883,16 +948,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *arank = mark + (E + 1);
     uint32_t *run_start = S[RUNS].as<uint32_t>();
     uint32_t *run_rank = run_start + E + 1, *starts_by_rank = run_rank + E, *entry_cell_buf = starts_by_rank + E;
-    hipLaunchKernelGGL(k_dup_mark, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sval, eloc, E, keep, mark);
-    {
-        hipcub::CountingInputIterator<uint32_t> positions(0u);
-        hipcub::TransformInputIterator<unsigned long long, HeadKeepOp, hipcub::CountingInputIterator<uint32_t>> flags(
-                positions, HeadKeepOp{skey, keep});
-        cub_cap = S[CUB].bytes;
-        HIP_OK(hipcub::DeviceScan::InclusiveSum(cub_tmp, cub_cap, flags, incl, (int)E, stream));
-    }
-    cub_cap = S[CUB].bytes;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, mark, arank, (int)E + 1, stream));
+    uint32_t *split = S[TMP].as<uint32_t>();  // free until k_keys2 writes the read index per kept entry there
+    HIP_OK(hipMemsetAsync(split, 0, (size_t)E * 4, stream));
     HIP_OK(pk.read_off.ensure(((size_t)E + 1) * 4));
     HIP_OK(pk.read_locus.ensure((size_t)E * 4));
     HIP_OK(pk.read_base.ensure(E));
@@ -904,23 +961,42 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     HIP_OK(pk.blk_off.ensure((n_off_max + 1) * 4));
     uint32_t *read_off = pk.read_off.as<uint32_t>(), *read_locus = pk.read_locus.as<uint32_t>();
     uint8_t *read_base = pk.read_base.as<uint8_t>();
-    hipLaunchKernelGGL(k_runs_csr, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, incl, sval, eloc, E, run_start,
-                       read_locus, read_base);
-    hipLaunchKernelGGL(k_read_info, dim3(std::min<uint32_t>(blocks_for(E), 2048)), dim3(TPB), 0, stream, raw, incl,
-                       run_start, sval, eloc, arank, mfl, run_rank, starts_by_rank, rbeg, read_off, sc);
-
-    // The flush chain is sequential (one lane per chromosome) and only the final gather needs its
-    // result: it runs on a side stream, next to the grouping of the kept entries.
     if (!pk.side) {
         HIP_OK(hipStreamCreateWithFlags(&pk.side, hipStreamNonBlocking));
         HIP_OK(hipEventCreateWithFlags(&pk.ev_fork, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&pk.ev_join, hipEventDisableTiming));
     }
-    HIP_OK(hipEventRecord(pk.ev_fork, stream));
-    HIP_OK(hipStreamWaitEvent(pk.side, pk.ev_fork, 0));
-    hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, pk.side, raw, starts_by_rank, rbeg, mfl, cnt);
-    hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, pk.side, raw, cnt, 4u * num_threads, flushed);
-    HIP_OK(hipEventRecord(pk.ev_join, pk.side));
+    // reads from the current `split` flags, then completed counts and the flush chain. The chain is
+    // sequential (one lane per chromosome) and only the final gather needs its result: it runs on a
+    // side stream, next to the grouping of the kept entries.
+    auto build_reads = [&]() -> std::string {
+        hipLaunchKernelGGL(k_dup_mark, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sval, eloc, split, E, keep,
+                           mark);
+        {
+            hipcub::CountingInputIterator<uint32_t> positions(0u);
+            hipcub::TransformInputIterator<unsigned long long, HeadKeepOp, hipcub::CountingInputIterator<uint32_t>>
+                    flags(positions, HeadKeepOp{skey, keep, split});
+            cub_cap = S[CUB].bytes;
+            HIP_OK(hipcub::DeviceScan::InclusiveSum(cub_tmp, cub_cap, flags, incl, (int)E, stream));
+        }
+        cub_cap = S[CUB].bytes;
+        HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, mark, arank, (int)E + 1, stream));
+        hipLaunchKernelGGL(k_runs_csr, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, incl, sval, eloc, E, run_start,
+                           read_locus, read_base);
+        hipLaunchKernelGGL(k_read_info, dim3(std::min<uint32_t>(blocks_for(E), 2048)), dim3(TPB), 0, stream, raw, incl,
+                           run_start, sval, eloc, arank, mfl, run_rank, starts_by_rank, rbeg, read_off, sc);
+        HIP_OK(hipEventRecord(pk.ev_fork, stream));
+        HIP_OK(hipStreamWaitEvent(pk.side, pk.ev_fork, 0));
+        hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, pk.side, raw, starts_by_rank, rbeg, mfl, cnt);
+        hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, pk.side, raw, cnt, 4u * num_threads, flushed,
+                           flush_loci, flush_count);
+        HIP_OK(hipEventRecord(pk.ev_join, pk.side));
+        return std::string();
+    };
+    {
+        const std::string err = build_reads();
+        if (!err.empty()) return err;
+    }
     struct SideJoin {  // every way out of this function leaves the side stream idle
         hipStream_t side;
         bool joined = false;
@@ -939,6 +1015,34 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     if (hsc.need_host) {
         *need_host = true;
         return std::string();
+    }
+    if (hsc.long_reads) {
+        // Some id's entries span >= max_fragment_length: a flush may erase it before its last entry and
+        // the id re-opens as a new read. Cut at the flush loci, rebuild, repeat until the cuts are stable
+        // (they move forward with the flushes they cause: a few rounds).
+        bool stable = false;
+        for (int round = 0; round < kMaxSplitRounds && !stable; ++round) {
+            HIP_OK(hipStreamWaitEvent(stream, pk.ev_join, 0));  // the chain of the previous build
+            HIP_OK(hipMemsetAsync(&sc->split_changed, 0, 4, stream));
+            hipLaunchKernelGGL(k_split_update, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sval, eloc, mfl,
+                               flush_loci, flush_count, split, sc);
+            HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+            if (!hsc.split_changed) {
+                stable = true;
+                break;
+            }
+            HIP_OK(hipMemsetAsync(&sc->multi_entries, 0, 8, stream));  // k_read_info adds to it
+            const std::string err = build_reads();
+            if (!err.empty()) return err;
+            HIP_OK(hipMemcpyAsync(&totals, incl + (E - 1), 8, hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+        }
+        if (!stable) {
+            *need_host = true;  // did not settle: the exact sequential emulation decides
+            return std::string();
+        }
     }
     const uint32_t R = (uint32_t)totals, n_kept = (uint32_t)(totals >> 32);
     const size_t nk = std::max<uint32_t>(n_kept, 1);

@@ -1,9 +1,10 @@
 // pack_device.hpp -- device-side read assembly, flush schedule and tile packing (gfx950).
 //
 // Same result as pack_host.cpp (see its header for the reference semantics) but computed on the
-// GPU from the raw flat pileup resident in HBM, for the common case in which no read outlives
-// max_fragment_length (no read is split at a flush). When that precondition does not hold, or a
-// size limit of this path is exceeded, `need_host` is set and the caller packs on the host.
+// GPU from the raw flat pileup resident in HBM. Reads that outlive max_fragment_length are cut where
+// a flush erases them (the cuts and the flush chain are iterated to their fixed point). When a size
+// limit of this path is exceeded (positions within max_fragment_length of 2^32, 2^31 entries, an
+// empty pileup) or that iteration does not settle, `need_host` is set and the caller packs on the host.
 #pragma once
 
 #include "pack_host.hpp"
@@ -60,8 +61,8 @@ struct DevicePacked {
 };
 
 // Returns "" on success. On success with *need_host == true nothing usable was produced and the
-// caller must fall back to pack_pileup() on the host (reads longer than max_fragment_length, or
-// more than 2^31 entries). Synchronises `stream` a few times (scalar read-backs).
+// caller must fall back to pack_pileup() on the host. Synchronises `stream` a few times (scalar
+// read-backs).
 std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells,
                                uint32_t max_fragment_length, uint32_t num_threads,
                                uint32_t block_cells, StageGeometry (*geometry)(uint32_t),

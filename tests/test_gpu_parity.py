@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import secedo_amd
+from secedo_amd.pileup import FlatPileup
 from oracle import bindings as ob
 from tests import golden_util as gu
 from tests.pileup_gen import from_rows, random_pileup
@@ -159,6 +160,12 @@ PACK_CASES = [
     (53, 150, 1, 1500, 25, 2500, 1000, 8, 128),
     (54, 16, 1, 300, 6, 9, 1000, 2, 0),       # long reads: window overflow, > 16 loci per read
     (55, 300, 24, 60, 40, 1500, 1000, 3, 0),  # many short chromosomes: tails dominate
+    # fragments (up to 600 long) outlive max_fragment_length: flushes cut reads, the cuts move the
+    # later flushes (k_split_update iterates)
+    (56, 120, 2, 600, 20, 200, 150, 2, 0),
+    (57, 60, 1, 800, 30, 100, 80, 1, 64),
+    (58, 100, 3, 500, 25, 250, 300, 4, 0),
+    (59, 40, 1, 400, 12, 60, 40, 8, 0),
 ]
 
 
@@ -191,13 +198,16 @@ def test_device_packing_equals_host_packing(seed, n, nchr, L, cov, gap, mfl, T, 
     assert accs[0][0] == accs[1][0] and torch.equal(accs[0][1], accs[1][1])
 
 
-def test_resident_pileup_and_fallback_to_host():
-    """prepare_resident: raw pileup in HBM -> matrix without touching host data; a read longer than
-    max_fragment_length makes the automatic mode fall back to the exact host emulation."""
+def test_resident_pileup_split_reads_and_fallback_to_host():
+    """prepare_resident: raw pileup in HBM -> matrix without touching host data, also when reads
+    outlive max_fragment_length and are cut by flushes (the reference re-opens a flushed id as a new
+    read, similarity_matrix.cpp:368-371, :379-382). What the device path does not cover (positions
+    within max_fragment_length of 2^32) makes the automatic mode fall back to the host emulation."""
     n = 120
     p = random_pileup(61, n, 2, 600, 20, 300)
     ref = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 4, "ADD_MIN")
     ref_split = ob.oracle_compute(p, n, 150, None, 0.01, 0.5, 0.01, 4, "ADD_MIN")
+    assert gu.normwise_err(ref, ref_split) > 1e-3  # the split schedule matters on this input
     with secedo_amd.SimilarityMatrixPlan(0) as plan:
         res = plan.upload(p, None, n)
         plan.prepare_resident(res, n, 1000, 4)
@@ -205,14 +215,26 @@ def test_resident_pileup_and_fallback_to_host():
         acc = plan.new_acc()
         plan.accumulate(acc, 0.01, 0.5, 0.01)
         assert gu.normwise_err(plan.finalize(acc, "ADD_MIN").cpu().numpy(), ref) <= TOL
+        plan.set_packing("device")
         plan.prepare_resident(res, n, 150, 4)  # fragments are up to 600 long: reads get split
-        assert not plan.used_device_packing
+        assert plan.used_device_packing
         acc = plan.new_acc()
         plan.accumulate(acc, 0.01, 0.5, 0.01)
         assert gu.normwise_err(plan.finalize(acc, "ADD_MIN").cpu().numpy(), ref_split) <= TOL
+    # positions close to 2^32: start + max_fragment_length does not fit the device path's 32 bits
+    far = FlatPileup(p.chr_locus_off, (p.locus_pos.astype(np.uint64) + (2**32 - 1 - int(p.locus_pos.max()))).astype(
+        np.uint32), p.locus_entry_off, p.read_ids, p.id_base)
+    ref_far = ob.oracle_compute(far, n, 1000, None, 0.01, 0.5, 0.01, 4, "ADD_MIN")
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        res = plan.upload(far, None, n)
+        plan.prepare_resident(res, n, 1000, 4)
+        assert not plan.used_device_packing
+        acc = plan.new_acc()
+        plan.accumulate(acc, 0.01, 0.5, 0.01)
+        assert gu.normwise_err(plan.finalize(acc, "ADD_MIN").cpu().numpy(), ref_far) <= TOL
         plan.set_packing("device")
         with pytest.raises(secedo_amd.SecedoError):
-            plan.prepare_resident(res, n, 150, 4)
+            plan.prepare_resident(res, n, 1000, 4)
 
 
 def test_more_than_16383_cells_u32_ids():
