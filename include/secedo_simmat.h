@@ -139,6 +139,12 @@ int secedo_simmat_accumulate(secedo_simmat_t *handle, double mutation_rate, doub
                              int64_t *d_acc, void *stream);
 int secedo_simmat_finalize(secedo_simmat_t *handle, int normalization, const int64_t *d_acc,
                            double *d_out, void *stream);
+/* finalize for a row block only: d_out_rows[(row_end - row_begin) * num_cells] receives rows
+ * [row_begin, row_end) of the normalised matrix (the maximum that ADD_MIN / SCALE_MAX_1 need is still
+ * taken over the whole accumulator). For ranks that keep the matrix sharded by rows (BASELINE config
+ * 5) and hand their block to secedo_spectral_eigs_rows_device (secedo_spectral.h). */
+int secedo_simmat_finalize_rows(secedo_simmat_t *handle, int normalization, const int64_t *d_acc,
+                                uint32_t row_begin, uint32_t row_end, double *d_out_rows, void *stream);
 /* Same as finalize with SECEDO_NORM_*, but writes the un-normalised D = logP_diff - logP_same
  * (similarity_matrix.cpp:428), mirrored to both triangles, zero diagonal. For parity checks. */
 int secedo_simmat_finalize_raw(secedo_simmat_t *handle, const int64_t *d_acc, double *d_out,

@@ -55,6 +55,22 @@ int secedo_spectral_eigs_device(int device_id, const double *d_similarity, uint3
                                 uint32_t n_vectors, double tol, uint32_t max_cycles, double *eigenvalues,
                                 double *d_eigenvectors, secedo_spectral_info *info, void *stream);
 
+/* The matrix sharded by rows over several ranks (one process per GPU; BASELINE config 5: the matrix
+ * is never gathered). Every rank passes the rows [row_begin, row_begin + n_rows) it holds
+ * (d_rows[n_rows * n], e.g. from secedo_simmat_finalize_rows; the row blocks of the ranks partition
+ * [0, n), a rank may hold none) and a callback that sums a device buffer of doubles over all ranks in
+ * place, on `stream` (RCCL ncclAllReduce, torch.distributed.all_reduce, ...; 0 on success). Per product
+ * with a block of 32 vectors each rank multiplies its rows and the n x 32 partial results are summed:
+ * 8 N^2 / ranks bytes of matrix per rank against one all-reduce of 256 N bytes. Everything else is
+ * replicated and deterministic, so every rank returns the same eigenvalues and the full eigenvectors.
+ * allreduce == NULL requires the full matrix (row_begin 0, n_rows n). */
+typedef int (*secedo_allreduce_sum_fn)(void *ctx, double *d_buffer, uint64_t count, void *stream);
+int secedo_spectral_eigs_rows_device(int device_id, const double *d_rows, uint32_t row_begin, uint32_t n_rows,
+                                     uint32_t n, uint32_t n_values, uint32_t n_vectors, double tol,
+                                     uint32_t max_cycles, double *eigenvalues, double *d_eigenvectors,
+                                     secedo_spectral_info *info, secedo_allreduce_sum_fn allreduce,
+                                     void *allreduce_ctx, void *stream);
+
 /* Same with host buffers (similarity n*n row-major in, eigenvectors column-major out): what a
  * caller holding a Matd uses. */
 int secedo_spectral_eigs(int device_id, const double *similarity, uint32_t n, uint32_t n_values,

@@ -40,6 +40,10 @@ class SpectralInfo(C.Structure):
                 ("max_residual_values", C.c_double)]
 
 
+# int (*secedo_allreduce_sum_fn)(void *ctx, double *d_buffer, uint64_t count, void *stream)
+ALLREDUCE_SUM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+
 class SynthSpec(C.Structure):
     _fields_ = [
         ("num_cells", C.c_uint32), ("num_loci", C.c_uint32), ("num_chromosomes", C.c_uint32),
@@ -77,6 +81,7 @@ SIGNATURES = {
     "secedo_simmat_accumulate": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_uint32,
                                            C.c_uint32, _vp, _vp]),
     "secedo_simmat_finalize": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "secedo_simmat_finalize_rows": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
     "secedo_simmat_finalize_raw": (C.c_int, [_vp, _vp, _vp, _vp]),
     "secedo_simmat_last_counts": (C.c_int, [_vp, _u64p, _u64p]),
     "secedo_simmat_last_accumulate_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
@@ -98,6 +103,9 @@ SIGNATURES = {
     "secedo_laplacian_device": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
     "secedo_spectral_eigs_device": (C.c_int, [C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
                                               C.c_uint32, _vp, _vp, C.POINTER(SpectralInfo), _vp]),
+    "secedo_spectral_eigs_rows_device": (C.c_int, [C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                   C.c_uint32, C.c_double, C.c_uint32, _vp, _vp,
+                                                   C.POINTER(SpectralInfo), _vp, _vp, _vp]),
     "secedo_spectral_eigs": (C.c_int, [C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32,
                                        _vp, _vp, C.POINTER(SpectralInfo)]),
 }

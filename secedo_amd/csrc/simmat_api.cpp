@@ -538,14 +538,17 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     return SECEDO_OK;
 }
 
-static int finalize_mode(secedo_simmat_t *h, int mode, const int64_t *d_acc, double *d_out, void *stream) {
+static int finalize_mode(secedo_simmat_t *h, int mode, const int64_t *d_acc, uint32_t row_begin, uint32_t row_end,
+                         double *d_out, void *stream) {
     if (!h || !d_acc || !d_out) return fail(SECEDO_E_INVALID_ARG, "null argument");
     if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
     if (!h->have_lut) return fail(SECEDO_E_STATE, "accumulate was not called");
+    if (row_begin > row_end || row_end > h->pk.num_cells) return fail(SECEDO_E_INVALID_ARG, "row range outside the matrix");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(secedo::launch_finalize(d_acc, h->tile_row.as<uint16_t>(), h->tile_col.as<uint16_t>(), h->num_tiles,
                                     h->pk.num_cells, h->pk.block_cells, h->scale_log2, mode,
-                                    h->max_bits.as<unsigned long long>(), d_out, static_cast<hipStream_t>(stream)));
+                                    h->max_bits.as<unsigned long long>(), row_begin, row_end, d_out,
+                                    static_cast<hipStream_t>(stream)));
     return SECEDO_OK;
 }
 
@@ -553,11 +556,18 @@ int secedo_simmat_finalize(secedo_simmat_t *h, int normalization, const int64_t 
                            void *stream) {
     if (normalization < 0 || normalization > 2)
         return fail(SECEDO_E_INVALID_NORMALIZATION, "Invalid normalization: " + std::to_string(normalization));
-    return finalize_mode(h, normalization, d_acc, d_out, stream);
+    return finalize_mode(h, normalization, d_acc, 0, h ? h->pk.num_cells : 0, d_out, stream);
+}
+
+int secedo_simmat_finalize_rows(secedo_simmat_t *h, int normalization, const int64_t *d_acc, uint32_t row_begin,
+                                uint32_t row_end, double *d_out_rows, void *stream) {
+    if (normalization < 0 || normalization > 2)
+        return fail(SECEDO_E_INVALID_NORMALIZATION, "Invalid normalization: " + std::to_string(normalization));
+    return finalize_mode(h, normalization, d_acc, row_begin, row_end, d_out_rows, stream);
 }
 
 int secedo_simmat_finalize_raw(secedo_simmat_t *h, const int64_t *d_acc, double *d_out, void *stream) {
-    return finalize_mode(h, 3, d_acc, d_out, stream);
+    return finalize_mode(h, 3, d_acc, 0, h ? h->pk.num_cells : 0, d_out, stream);
 }
 
 int secedo_simmat_last_counts(secedo_simmat_t *h, uint64_t *updates, uint64_t *read_pairs) {

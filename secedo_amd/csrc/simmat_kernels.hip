@@ -634,9 +634,12 @@ __global__ __launch_bounds__(256) void reduce_max(const long long *acc, const ui
 // read once with coalesced loads, normalised into LDS, and written twice -- as out[i][j] straight,
 // as out[j][i] transposed through LDS -- so both the reads and the writes are full 256-byte rows.
 template <int B>
+// Only rows [row_begin, row_end) are written, to out[(i - row_begin) * n + j]: a rank that keeps a
+// row block of the matrix (BASELINE config 5) passes its range, everyone else [0, n).
 __global__ __launch_bounds__(256) void write_matrix(const long long *acc, const uint16_t *tile_row,
                                                     const uint16_t *tile_col, uint32_t n, double scale, int mode,
-                                                    const unsigned long long *max_bits, double *out) {
+                                                    const unsigned long long *max_bits, uint32_t row_begin,
+                                                    uint32_t row_end, double *out) {
     constexpr uint32_t SB = 32, PER = B / SB;
     __shared__ double V[SB][SB + 1];
     const uint32_t t = blockIdx.x / (PER * PER), sub = blockIdx.x % (PER * PER);
@@ -652,6 +655,8 @@ __global__ __launch_bounds__(256) void write_matrix(const long long *acc, const 
     const long long *tile = acc + (size_t)t * B * B;
     const uint32_t tx = threadIdx.x % SB, ty = threadIdx.x / SB;  // 32 x 8
     const uint32_t i0 = I * B + a * SB, j0 = J * B + b * SB;
+    // rows i0.. (straight) and j0.. (mirror) both outside the range: nothing to do
+    if ((i0 >= row_end || i0 + SB <= row_begin) && (j0 >= row_end || j0 + SB <= row_begin)) return;
 #pragma unroll
     for (uint32_t k = 0; k < SB; k += 8) {
         const uint32_t r = ty + k, c = tx;
@@ -667,14 +672,16 @@ __global__ __launch_bounds__(256) void write_matrix(const long long *acc, const 
         }
         if (i0 + r == j0 + c) w = 0.0;
         V[r][c] = w;
-        if (i0 + r < n && j0 + c < n) out[(size_t)(i0 + r) * n + j0 + c] = w;
+        const uint32_t i = i0 + r;
+        if (i < n && j0 + c < n && i >= row_begin && i < row_end) out[(size_t)(i - row_begin) * n + j0 + c] = w;
     }
     if (diag && a == b) return;  // the sub-block is symmetric in itself
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < SB; k += 8) {
         const uint32_t c = ty + k, r = tx;  // out[j0 + c][i0 + r], r fastest
-        if (i0 + r < n && j0 + c < n) out[(size_t)(j0 + c) * n + i0 + r] = V[r][c];
+        const uint32_t j = j0 + c;
+        if (i0 + r < n && j < n && j >= row_begin && j < row_end) out[(size_t)(j - row_begin) * n + i0 + r] = V[r][c];
     }
 }
 
@@ -732,7 +739,8 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
 
 hipError_t launch_finalize(const int64_t *acc, const uint16_t *tile_row, const uint16_t *tile_col, uint32_t n_tiles,
                            uint32_t n, uint32_t block_cells, int scale_log2, int mode,
-                           unsigned long long *d_max_bits, double *out, hipStream_t stream) {
+                           unsigned long long *d_max_bits, uint32_t row_begin, uint32_t row_end, double *out,
+                           hipStream_t stream) {
     const double scale = ldexp(1.0, -scale_log2);
     const size_t total = (size_t)n_tiles * block_cells * block_cells;
     const uint32_t grid = (uint32_t)std::min<size_t>((total + 255) / 256, 256 * 8);
@@ -751,10 +759,10 @@ hipError_t launch_finalize(const int64_t *acc, const uint16_t *tile_row, const u
     }
     if (block_cells == 128) {
         hipLaunchKernelGGL((write_matrix<128>), dim3(n_tiles * 16), dim3(256), 0, stream, a, tile_row, tile_col, n,
-                           scale, mode, d_max_bits, out);
+                           scale, mode, d_max_bits, row_begin, row_end, out);
     } else {
         hipLaunchKernelGGL((write_matrix<64>), dim3(n_tiles * 4), dim3(256), 0, stream, a, tile_row, tile_col, n,
-                           scale, mode, d_max_bits, out);
+                           scale, mode, d_max_bits, row_begin, row_end, out);
     }
     return hipGetLastError();
 }

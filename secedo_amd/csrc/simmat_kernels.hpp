@@ -79,6 +79,7 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
 // mode 0..2 = SECEDO_NORM_*, 3 = raw D
 hipError_t launch_finalize(const int64_t *acc, const uint16_t *tile_row, const uint16_t *tile_col, uint32_t n_tiles,
                            uint32_t n, uint32_t block_cells, int scale_log2, int mode,
-                           unsigned long long *d_max_bits, double *out, hipStream_t stream);
+                           unsigned long long *d_max_bits, uint32_t row_begin, uint32_t row_end, double *out,
+                           hipStream_t stream);
 
 }  // namespace secedo

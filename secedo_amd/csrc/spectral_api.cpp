@@ -4,7 +4,7 @@
 // spectral_clustering.cpp:33-52, :127-138) without forming L and without the O(N^3) decomposition.
 // The wanted pairs are the LARGEST of T = (I + D^-1/2 A D^-1/2) / 2 (spectrum in [0, 1],
 // lambda_L = 2 (1 - tau)), found by a restarted block Lanczos iteration:
-//   * blocks of 32 vectors: one pass over the N x N matrix serves 32 vectors (apply_operator runs on
+//   * blocks of 32 vectors: one pass over the N x N matrix serves 32 vectors (the block product runs on
 //     the fp64 matrix cores and is bound by the 8 N^2 bytes of A);
 //   * full re-orthogonalisation against the cycle's basis (classical Gram-Schmidt twice) and a
 //     Cholesky QR of each new block, with dependent columns dropped -- so eigenvalue multiplicity
@@ -117,30 +117,65 @@ std::vector<double> matmul32(const std::vector<double> &a, const std::vector<dou
 }
 
 struct Solver {
-    uint32_t n = 0;
+    uint32_t n = 0, row_begin = 0, n_rows = 0;
     hipStream_t stream = nullptr;
-    const double *A = nullptr;
-    Buf s, root, Q, W, Z, P, Gp, G, M;
+    const double *A = nullptr;  // rows [row_begin, row_begin + n_rows) of the matrix
+    secedo_allreduce_sum_fn allreduce = nullptr;
+    void *allreduce_ctx = nullptr;
+    Buf s, root, sums, Q, W, Z, P, Ypart, Gp, G, M;
     size_t blk_stride = 0;
 
-    int setup(const double *d_sim, uint32_t n_, hipStream_t st) {
+    int setup(const double *d_rows, uint32_t row_begin_, uint32_t n_rows_, uint32_t n_, secedo_allreduce_sum_fn fn,
+              void *ctx, hipStream_t st) {
         using namespace secedo::spectral;
         n = n_;
+        row_begin = row_begin_;
+        n_rows = n_rows_;
         stream = st;
-        A = d_sim;
+        A = d_rows;
+        allreduce = fn;
+        allreduce_ctx = ctx;
         blk_stride = (size_t)n * BW;
+        SP_TRY(sums.alloc((size_t)n * 8));
+        SP_TRY(Ypart.alloc(blk_stride * 8));
         SP_TRY(s.alloc((size_t)n * 8));
         SP_TRY(root.alloc((size_t)n * 8));
         SP_TRY(Q.alloc((kCycleBlocks + 1) * blk_stride * 8));
         SP_TRY(W.alloc(blk_stride * 8));
-        SP_TRY(Z.alloc((size_t)pad16(n) * BW * 8));
-        SP_TRY(P.alloc((size_t)product_segments(n) * pad16(n) * BW * 8));
+        SP_TRY(Z.alloc(((size_t)pad16(n) + 16) * BW * 8));
+        SP_TRY(P.alloc((size_t)product_segments(n, n_rows) * pad16(n) * BW * 8));
         SP_TRY(Gp.alloc((size_t)gram_chunks(n) * (kCycleBlocks + 1) * BW * BW * 8));
         SP_TRY(G.alloc((size_t)(kCycleBlocks + 1) * BW * BW * 8));
         SP_TRY(M.alloc((size_t)(kCycleBlocks + 1) * BW * BW * 8));
         return SECEDO_OK;
     }
     double *block(uint32_t b) const { return Q.d() + b * blk_stride; }
+    // sum over the ranks of a device buffer, in place (nothing to do for a rank that holds all rows)
+    int reduce_ranks(double *buf, size_t count) {
+        if (!allreduce) return SECEDO_OK;
+        if (allreduce(allreduce_ctx, buf, count, stream) != 0)
+            return secedo::api_fail(SECEDO_E_STATE, "the all-reduce callback of the spectral step failed");
+        return SECEDO_OK;
+    }
+    // D^-1/2 from the row sums of the whole matrix
+    int scales() {
+        using namespace secedo::spectral;
+        SP_TRY(hipMemsetAsync(sums.p, 0, (size_t)n * 8, stream));
+        SP_TRY(row_sums(A, n, row_begin, n_rows, sums.d(), stream));
+        const int rc = reduce_ranks(sums.d(), n);
+        if (rc) return rc;
+        SP_TRY(scale_from_sums(n, sums.d(), s.d(), root.d(), stream));
+        return SECEDO_OK;
+    }
+    // y = T x
+    int product(const double *x, double *y) {
+        using namespace secedo::spectral;
+        SP_TRY(product_partial(A, n, row_begin, n_rows, s.d(), x, Z.d(), P.d(), Ypart.d(), stream));
+        const int rc = reduce_ranks(Ypart.d(), blk_stride);
+        if (rc) return rc;
+        SP_TRY(product_finish(n, s.d(), x, Ypart.d(), y, stream));
+        return SECEDO_OK;
+    }
     // G[blk] = Q[blk]^T w for blk < nblk, to the host
     int gram_host(uint32_t nblk, const double *basis, const double *w, std::vector<double> &out) {
         SP_TRY(secedo::spectral::gram(n, basis, blk_stride, nblk, w, Gp.d(), G.d(), stream));
@@ -172,11 +207,14 @@ struct Solver {
     }
 };
 
-int solve(int device_id, const double *d_sim, uint32_t n, uint32_t n_values, uint32_t n_vectors, double tol,
-          uint32_t max_cycles, double *eigenvalues, double *d_eigenvectors, secedo_spectral_info *info,
-          hipStream_t stream) {
+int solve(int device_id, const double *d_rows, uint32_t row_begin, uint32_t n_rows, uint32_t n, uint32_t n_values,
+          uint32_t n_vectors, double tol, uint32_t max_cycles, double *eigenvalues, double *d_eigenvectors,
+          secedo_spectral_info *info, secedo_allreduce_sum_fn allreduce, void *allreduce_ctx, hipStream_t stream) {
     using namespace secedo::spectral;
-    if (!d_sim || !eigenvalues) return secedo::api_fail(SECEDO_E_INVALID_ARG, "null argument");
+    if ((!d_rows && n_rows) || !eigenvalues) return secedo::api_fail(SECEDO_E_INVALID_ARG, "null argument");
+    if ((uint64_t)row_begin + n_rows > n) return secedo::api_fail(SECEDO_E_INVALID_ARG, "row block outside the matrix");
+    if (!allreduce && n_rows != n)
+        return secedo::api_fail(SECEDO_E_INVALID_ARG, "a row block needs the all-reduce callback of the other ranks");
     if (n == 0) return secedo::api_fail(SECEDO_E_INVALID_ARG, "the similarity matrix is empty");
     if (n_values == 0 || n_values > std::min<uint32_t>(n, SECEDO_SPECTRAL_MAX_VALUES))
         return secedo::api_fail(SECEDO_E_INVALID_ARG, "n_values must be in [1, min(n, 32)]");
@@ -193,9 +231,9 @@ int solve(int device_id, const double *d_sim, uint32_t n, uint32_t n_values, uin
     const double tol_values = std::max(tol, 1e-6);
 
     Solver sv;
-    int rc = sv.setup(d_sim, n, stream);
+    int rc = sv.setup(d_rows, row_begin, n_rows, n, allreduce, allreduce_ctx, stream);
     if (rc) return rc;
-    SP_TRY(row_scale(d_sim, n, sv.s.d(), sv.root.d(), stream));
+    if ((rc = sv.scales())) return rc;
     SP_TRY(init_block(n, sv.root.d(), sv.W.d(), stream));
     std::vector<double> R, R_last;
     std::vector<char> alive;
@@ -213,7 +251,7 @@ int solve(int device_id, const double *d_sim, uint32_t n, uint32_t n_values, uin
     for (uint32_t cycle = 0; cycle < max_cycles; ++cycle) {
         std::fill(H.begin(), H.end(), 0.0);
         for (uint32_t j = 0; j < kCycleBlocks; ++j) {
-            SP_TRY(apply_operator(d_sim, n, sv.s.d(), sv.block(j), sv.Z.d(), sv.P.d(), sv.W.d(), stream));
+            if ((rc = sv.product(sv.block(j), sv.W.d()))) return rc;
             ++inf.block_products;
             for (int pass = 0; pass < 2; ++pass) {  // classical Gram-Schmidt, twice
                 if ((rc = sv.gram_host(j + 1, sv.Q.d(), sv.W.d(), g))) return rc;
@@ -292,10 +330,12 @@ int secedo_laplacian_device(const double *d_similarity, uint32_t n, double *d_ou
     if (!d_similarity || !d_out) return secedo::api_fail(SECEDO_E_INVALID_ARG, "null argument");
     if (n == 0) return SECEDO_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    Buf s, root;
+    Buf s, root, sums;
     SP_TRY(s.alloc((size_t)n * 8));
     SP_TRY(root.alloc((size_t)n * 8));
-    SP_TRY(secedo::spectral::row_scale(d_similarity, n, s.d(), root.d(), st));
+    SP_TRY(sums.alloc((size_t)n * 8));
+    SP_TRY(secedo::spectral::row_sums(d_similarity, n, 0, n, sums.d(), st));
+    SP_TRY(secedo::spectral::scale_from_sums(n, sums.d(), s.d(), root.d(), st));
     SP_TRY(secedo::spectral::laplacian(d_similarity, s.d(), n, d_out, st));
     SP_TRY(hipStreamSynchronize(st));  // the scratch is freed on return
     return SECEDO_OK;
@@ -304,8 +344,17 @@ int secedo_laplacian_device(const double *d_similarity, uint32_t n, double *d_ou
 int secedo_spectral_eigs_device(int device_id, const double *d_similarity, uint32_t n, uint32_t n_values,
                                 uint32_t n_vectors, double tol, uint32_t max_cycles, double *eigenvalues,
                                 double *d_eigenvectors, secedo_spectral_info *info, void *stream) {
-    return solve(device_id, d_similarity, n, n_values, n_vectors, tol, max_cycles, eigenvalues, d_eigenvectors, info,
-                 static_cast<hipStream_t>(stream));
+    return solve(device_id, d_similarity, 0, n, n, n_values, n_vectors, tol, max_cycles, eigenvalues, d_eigenvectors,
+                 info, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int secedo_spectral_eigs_rows_device(int device_id, const double *d_rows, uint32_t row_begin, uint32_t n_rows,
+                                     uint32_t n, uint32_t n_values, uint32_t n_vectors, double tol,
+                                     uint32_t max_cycles, double *eigenvalues, double *d_eigenvectors,
+                                     secedo_spectral_info *info, secedo_allreduce_sum_fn allreduce,
+                                     void *allreduce_ctx, void *stream) {
+    return solve(device_id, d_rows, row_begin, n_rows, n, n_values, n_vectors, tol, max_cycles, eigenvalues,
+                 d_eigenvectors, info, allreduce, allreduce_ctx, static_cast<hipStream_t>(stream));
 }
 
 int secedo_spectral_eigs(int device_id, const double *similarity, uint32_t n, uint32_t n_values,
@@ -322,7 +371,8 @@ int secedo_spectral_eigs(int device_id, const double *similarity, uint32_t n, ui
     SP_TRY(a.alloc((size_t)n * n * 8));
     SP_TRY(v.alloc((size_t)n * std::max<uint32_t>(n_vectors, 1) * 8));
     SP_TRY(hipMemcpy(a.p, similarity, (size_t)n * n * 8, hipMemcpyHostToDevice));
-    const int rc = solve(device_id, a.d(), n, n_values, n_vectors, tol, max_cycles, eigenvalues, v.d(), info, nullptr);
+    const int rc = solve(device_id, a.d(), 0, n, n, n_values, n_vectors, tol, max_cycles, eigenvalues, v.d(), info,
+                         nullptr, nullptr, nullptr);
     if (rc) return rc;
     if (n_vectors) SP_TRY(hipMemcpy(eigenvectors, v.p, (size_t)n * n_vectors * 8, hipMemcpyDeviceToHost));
     return SECEDO_OK;

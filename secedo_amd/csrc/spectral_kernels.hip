@@ -1,9 +1,9 @@
 // spectral_kernels.hip -- gfx950 kernels of the spectral step.
 //
-//   row_scale        row sums of the similarity matrix -> D^-1/2           (HBM-bound, N^2 read)
+//   row_sums         row sums of the similarity matrix -> D^-1/2           (HBM-bound, N^2 read)
 //   laplacian        the dense normalised Laplacian, for callers that want the reference's
 //                    laplacian() itself (spectral_clustering.cpp:33-52)
-//   apply_operator   Y = (X + D^-1/2 A D^-1/2 X) / 2 for a block of 32 vectors: the matrix is read
+//   product_*        Y = (X + D^-1/2 A D^-1/2 X) / 2 for a block of 32 vectors: the matrix is read
 //                    ONCE for 32 vectors. This is a tall-skinny fp64 GEMM, so it runs on the matrix
 //                    cores (v_mfma_f64_16x16x4_f64); it is bound by the N^2 * 8 bytes of A.
 //   gram, block_combine, write_vectors   N x 32 bookkeeping of the block Krylov iteration
@@ -24,18 +24,25 @@ namespace {
 constexpr int BW = (int)kBlockWidth;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_row_scale(const double *A, uint32_t n, double *s, double *root) {
+// sums[row_begin + r] = sum_j A_rows[r][j] for the local rows (one wave per row)
+__global__ __launch_bounds__(256) void k_row_sums(const double *A_rows, uint32_t n, uint32_t row_begin,
+                                                 uint32_t n_rows, double *sums) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t row = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    if (row >= n) return;
-    const double *a = A + (size_t)row * n;
+    if (row >= n_rows) return;
+    const double *a = A_rows + (size_t)row * n;
     double sum = 0.0;
     for (uint32_t j = lane; j < n; j += 64u) sum += a[j];
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
-    if (lane == 0) {
-        s[row] = sum == 0.0 ? 0.0 : 1.0 / sqrt(sum);
-        root[row] = sum > 0.0 ? sqrt(sum) : 0.0;
-    }
+    if (lane == 0) sums[row_begin + row] = sum;
+}
+
+__global__ __launch_bounds__(256) void k_scale_from_sums(uint32_t n, const double *sums, double *s, double *root) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double sum = sums[i];
+    s[i] = sum == 0.0 ? 0.0 : 1.0 / sqrt(sum);  // spectral_clustering.cpp:40-41
+    root[i] = sum > 0.0 ? sqrt(sum) : 0.0;
 }
 
 __global__ __launch_bounds__(256) void k_laplacian(const double *A, const double *s, uint32_t n, double *out) {
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256) void k_init_block(uint32_t n, const double *ro
     }
 }
 
-// Z[j][c] = s[j] * X[j][c]; rows n .. pad16(n) are zero
+// Z[j][c] = s[j] * X[j][c]; rows from n on (padding + 16 rows of slack) are zero
 __global__ __launch_bounds__(256) void k_scale_rows(uint32_t n, uint32_t n_pad, const double *s, const double *X,
                                                    double *Z) {
     const size_t total = (size_t)n_pad * BW;
@@ -73,28 +80,31 @@ __global__ __launch_bounds__(256) void k_scale_rows(uint32_t n, uint32_t n_pad, 
     }
 }
 
-// P[seg][i][c] = sum over the segment's rows j of Z[j][c] * A[j][i]. One wave owns 16 columns i and
-// both 16-wide halves of c: per step of 4 rows, one 8-byte load of A per lane feeds two MFMAs.
-__global__ __launch_bounds__(256) void k_product_partial(const double *A, uint32_t n, uint32_t n_pad4,
-                                                        const double *Z, uint32_t seg_rows, uint32_t n_pad16,
-                                                        double *P) {
+// P[seg][i][c] = sum over the segment's rows j of Z[j][c] * A[j][i], for the rows this rank holds
+// (A_rows = rows [row_begin, row_begin + n_rows) of the matrix). One wave owns 16 columns i and both
+// 16-wide halves of c: per step of 4 rows, one 8-byte load of A per lane feeds two MFMAs.
+__global__ __launch_bounds__(256) void k_product_partial(const double *A_rows, uint32_t n, uint32_t row_begin,
+                                                        uint32_t n_rows, const double *Z, uint32_t seg_rows,
+                                                        uint32_t n_pad16, double *P) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t i0 = (blockIdx.x * 4u + wave) * 16u;
     if (i0 >= n_pad16) return;
     const uint32_t col = lane & 15u, kq = lane >> 4;
     const uint32_t ic = min(i0 + col, n - 1u);  // columns past n are computed from column n-1 and never read
-    // segments are multiples of 16 rows, Z has pad16(n) rows: four steps of 4 rows per trip, the 12
-    // loads of a trip in flight together
-    const uint32_t j_begin = blockIdx.y * seg_rows, j_end = min(n_pad4, j_begin + seg_rows);
+    // segments are multiples of 16 local rows: four steps of 4 rows per trip, the 12 loads of a trip in
+    // flight together; local rows past n_rows contribute a zero A
+    const uint32_t rows_pad = (n_rows + 15u) / 16u * 16u;
+    const uint32_t j_begin = blockIdx.y * seg_rows, j_end = min(rows_pad, j_begin + seg_rows);
     double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     for (uint32_t j0 = j_begin; j0 < j_end; j0 += 16u) {
         double a[4], z0[4], z1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint32_t jk = j0 + 4u * u + kq;
-            a[u] = A[(size_t)min(jk, n - 1u) * n + ic];  // rows past n meet zero rows of Z
-            z0[u] = Z[(size_t)jk * BW + col];
-            z1[u] = Z[(size_t)jk * BW + 16u + col];
+            const uint32_t jl = j0 + 4u * u + kq;
+            const double av = A_rows[(size_t)min(jl, n_rows - 1u) * n + ic];
+            a[u] = jl < n_rows ? av : 0.0;
+            z0[u] = Z[(size_t)(row_begin + jl) * BW + col];  // Z has 16 zero rows of slack past pad16(n)
+            z1[u] = Z[(size_t)(row_begin + jl) * BW + 16u + col];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -111,17 +121,23 @@ __global__ __launch_bounds__(256) void k_product_partial(const double *A, uint32
     }
 }
 
-// Y[i][c] = (X[i][c] + s[i] * sum_seg P[seg][i][c]) / 2, segments added in order
-__global__ __launch_bounds__(256) void k_product_finish(uint32_t n, uint32_t n_seg, uint32_t n_pad16,
-                                                       const double *P, const double *s, const double *X,
-                                                       double *Y) {
+// Ypart[i][c] = sum_seg P[seg][i][c], segments added in order
+__global__ __launch_bounds__(256) void k_product_reduce(uint32_t n, uint32_t n_seg, uint32_t n_pad16, const double *P,
+                                                       double *Ypart) {
     const size_t total = (size_t)n * BW;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const uint32_t i = (uint32_t)(idx / BW);
         double sum = 0.0;
         for (uint32_t g = 0; g < n_seg; ++g) sum += P[(size_t)g * n_pad16 * BW + idx];
-        Y[idx] = 0.5 * (X[idx] + s[i] * sum);
+        Ypart[idx] = sum;
     }
+}
+
+// Y[i][c] = (X[i][c] + s[i] * Ysum[i][c]) / 2
+__global__ __launch_bounds__(256) void k_product_finish(uint32_t n, const double *Ysum, const double *s,
+                                                       const double *X, double *Y) {
+    const size_t total = (size_t)n * BW;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256)
+        Y[idx] = 0.5 * (X[idx] + s[idx / BW] * Ysum[idx]);
 }
 
 // Gp[chunk][blk][a][c] = sum over the chunk's rows j of Q[blk][j][a] * W[j][c]
@@ -244,8 +260,15 @@ inline uint32_t grid_for(size_t total) {
 
 }  // namespace
 
-hipError_t row_scale(const double *A, uint32_t n, double *s, double *root, hipStream_t stream) {
-    hipLaunchKernelGGL(k_row_scale, dim3((n + 3) / 4), dim3(256), 0, stream, A, n, s, root);
+hipError_t row_sums(const double *A_rows, uint32_t n, uint32_t row_begin, uint32_t n_rows, double *sums,
+                    hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_row_sums, dim3((n_rows + 3) / 4), dim3(256), 0, stream, A_rows, n, row_begin, n_rows, sums);
+    return hipGetLastError();
+}
+
+hipError_t scale_from_sums(uint32_t n, const double *sums, double *s, double *root, hipStream_t stream) {
+    hipLaunchKernelGGL(k_scale_from_sums, dim3((n + 255) / 256), dim3(256), 0, stream, n, sums, s, root);
     return hipGetLastError();
 }
 
@@ -259,23 +282,30 @@ hipError_t init_block(uint32_t n, const double *root, double *X, hipStream_t str
     return hipGetLastError();
 }
 
-uint32_t product_segments(uint32_t n) {
+uint32_t product_segments(uint32_t n, uint32_t n_rows) {
     // enough waves to fill 256 CUs: a workgroup column covers 64 matrix columns
     const uint32_t cols = (pad16(n) + 63u) / 64u;
     const uint32_t want = (2048u + cols - 1u) / cols;
-    const uint32_t most = std::max(1u, pad16(n) / 64u);  // at least 64 rows per segment
+    const uint32_t most = std::max(1u, pad16(n_rows) / 64u);  // at least 64 rows per segment
     return std::max(1u, std::min({want, 64u, most}));
 }
 
-hipError_t apply_operator(const double *A, uint32_t n, const double *s, const double *X, double *Z, double *P,
-                          double *Y, hipStream_t stream) {
-    const uint32_t n4 = pad16(n), n16 = pad16(n), n_seg = product_segments(n);  // Z is padded to 16 rows too
-    const uint32_t seg_rows = ((n4 + n_seg - 1u) / n_seg + 15u) / 16u * 16u;
-    hipLaunchKernelGGL(k_scale_rows, dim3(grid_for((size_t)n4 * BW)), dim3(256), 0, stream, n, n4, s, X, Z);
-    hipLaunchKernelGGL(k_product_partial, dim3((n16 + 63u) / 64u, n_seg), dim3(256), 0, stream, A, n, n4, Z, seg_rows,
-                       n16, P);
-    hipLaunchKernelGGL(k_product_finish, dim3(grid_for((size_t)n * BW)), dim3(256), 0, stream, n, n_seg, n16, P, s, X,
-                       Y);
+hipError_t product_partial(const double *A_rows, uint32_t n, uint32_t row_begin, uint32_t n_rows, const double *s,
+                           const double *X, double *Z, double *P, double *Ypart, hipStream_t stream) {
+    const uint32_t nz = pad16(n) + 16u, n16 = pad16(n), n_seg = product_segments(n, n_rows);
+    const uint32_t seg_rows = ((pad16(n_rows) + n_seg - 1u) / n_seg + 15u) / 16u * 16u;
+    hipLaunchKernelGGL(k_scale_rows, dim3(grid_for((size_t)nz * BW)), dim3(256), 0, stream, n, nz, s, X, Z);
+    if (n_rows)
+        hipLaunchKernelGGL(k_product_partial, dim3((n16 + 63u) / 64u, n_seg), dim3(256), 0, stream, A_rows, n, row_begin,
+                           n_rows, Z, seg_rows, n16, P);
+    hipLaunchKernelGGL(k_product_reduce, dim3(grid_for((size_t)n * BW)), dim3(256), 0, stream, n, n_rows ? n_seg : 0u,
+                       n16, P, Ypart);
+    return hipGetLastError();
+}
+
+hipError_t product_finish(uint32_t n, const double *s, const double *X, const double *Ysum, double *Y,
+                          hipStream_t stream) {
+    hipLaunchKernelGGL(k_product_finish, dim3(grid_for((size_t)n * BW)), dim3(256), 0, stream, n, Ysum, s, X, Y);
     return hipGetLastError();
 }
 

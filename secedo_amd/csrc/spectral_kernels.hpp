@@ -13,9 +13,11 @@ namespace spectral {
 constexpr uint32_t kBlockWidth = 32;  // vectors per block: two 16-wide MFMA tiles
 constexpr uint32_t kGramChunk = 128;  // rows per workgroup of the Gram kernel
 
-// s[i] = 1 / sqrt(sum_j A[i][j]) (0 when the sum is 0; reference spectral_clustering.cpp:34-43),
-// root[i] = sqrt(sum_j A[i][j])
-hipError_t row_scale(const double *A, uint32_t n, double *s, double *root, hipStream_t stream);
+// sums[row_begin + r] = sum_j A_rows[r][j] for the n_rows local rows (the rest of sums is left alone)
+hipError_t row_sums(const double *A_rows, uint32_t n, uint32_t row_begin, uint32_t n_rows, double *sums,
+                    hipStream_t stream);
+// s[i] = 1 / sqrt(sums[i]) (0 when the sum is 0; reference spectral_clustering.cpp:34-43), root[i] = sqrt(sums[i])
+hipError_t scale_from_sums(uint32_t n, const double *sums, double *s, double *root, hipStream_t stream);
 
 // out = I - diag(s) A diag(s)   (spectral_clustering.cpp:44-50)
 hipError_t laplacian(const double *A, const double *s, uint32_t n, double *out, hipStream_t stream);
@@ -23,15 +25,19 @@ hipError_t laplacian(const double *A, const double *s, uint32_t n, double *out, 
 // X[:, 0] = root (the known eigenvector of eigenvalue 0), the other columns a fixed pseudo-random fill
 hipError_t init_block(uint32_t n, const double *root, double *X, hipStream_t stream);
 
-// number of row segments the product is split into, and the padded row count of the partials
-uint32_t product_segments(uint32_t n);
+// number of row segments the product over n_rows local rows is split into; padded row counts
+uint32_t product_segments(uint32_t n, uint32_t n_rows);
 inline uint32_t pad16(uint32_t n) { return (n + 15u) / 16u * 16u; }
-inline uint32_t pad4(uint32_t n) { return (n + 3u) / 4u * 4u; }
 
-// Y = T X with T = (I + diag(s) A diag(s)) / 2, A symmetric; Z (pad16(n) x 32) and
-// P (segments x pad16(n) x 32) are scratch
-hipError_t apply_operator(const double *A, uint32_t n, const double *s, const double *X, double *Z, double *P,
-                          double *Y, hipStream_t stream);
+// T = (I + diag(s) A diag(s)) / 2 applied to a block X in two halves, so that ranks holding row blocks
+// of the symmetric A can add their parts in between:
+//   product_partial  Ypart = sum over the local rows j of (s[j] X[j]) A[j][:]      (n x 32)
+//   product_finish   Y = (X + s o Ysum) / 2, Ysum = the sum of all ranks' Ypart
+// Z ((pad16(n) + 16) x 32) and P (segments x pad16(n) x 32) are scratch.
+hipError_t product_partial(const double *A_rows, uint32_t n, uint32_t row_begin, uint32_t n_rows, const double *s,
+                           const double *X, double *Z, double *P, double *Ypart, hipStream_t stream);
+hipError_t product_finish(uint32_t n, const double *s, const double *X, const double *Ysum, double *Y,
+                          hipStream_t stream);
 
 // G[blk] (32 x 32) = Q[blk]^T W for blk < nblk; Q blocks blk_stride doubles apart; Gp scratch of
 // gram_chunks(n) * nblk * 1024 doubles

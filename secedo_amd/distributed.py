@@ -47,3 +47,72 @@ def sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate
         else:
             dist.all_gather_into_tensor(acc, mine.clone(), group=group)
     return acc
+
+
+def row_range(num_cells, rank, world):
+    """Rows [lo, hi) of the matrix that `rank` keeps when the matrix stays sharded (contiguous, as even
+    as possible)."""
+    per, extra = divmod(num_cells, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
+
+
+class _DevicePointer:
+    """A device buffer handed to the all-reduce callback, seen through the CUDA array interface."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def sharded_eigenpairs(rows, row_begin, num_cells, n_values=20, n_vectors=7, tol=0.0, max_cycles=0, group=None):
+    """Spectral step on a matrix kept sharded by rows (BASELINE config 5; reference
+    spectral_clustering.cpp:127-138 on the whole matrix): every rank passes the (rows x num_cells)
+    float64 CUDA tensor of its row block (`SimilarityMatrixPlan.finalize_rows`), the n x 32 partial
+    products are summed with `torch.distributed.all_reduce` (RCCL on "nccl"; rehearsal backends such as
+    gloo are staged through the host). Returns (eigenvalues, eigenvectors (num_cells x n_vectors CUDA
+    tensor, the same on every rank), info) like `secedo_amd.smallest_eigenpairs`."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib
+    assert rows.is_cuda and rows.dtype == torch.float64 and rows.is_contiguous()
+    n_rows = rows.shape[0]
+    assert n_rows == 0 or rows.shape[1] == num_cells
+    direct = dist.get_backend(group) == "nccl"
+    failure = []
+
+    def allreduce(_ctx, ptr, count, _stream):
+        try:
+            buf = torch.as_tensor(_DevicePointer(ptr, count), device=rows.device)
+            if direct:
+                dist.all_reduce(buf, group=group)
+            else:
+                host = buf.cpu()
+                dist.all_reduce(host, group=group)
+                buf.copy_(host)
+            return 0
+        except Exception as e:  # an exception must not cross the C frames above
+            failure.append(e)
+            return 1
+
+    hook = _lib.ALLREDUCE_SUM_FN(allreduce)
+    n_values = min(n_values, num_cells, 32)
+    n_vectors = min(n_vectors, n_values)
+    vals = np.empty(n_values, dtype=np.float64)
+    vecs = torch.empty((max(n_vectors, 1), num_cells), dtype=torch.float64, device=rows.device)
+    info = _lib.SpectralInfo()
+    stream = torch.cuda.current_stream(rows.device).cuda_stream
+    rc = _lib.lib().secedo_spectral_eigs_rows_device(
+        rows.device.index or 0, rows.data_ptr() if n_rows else None, row_begin, n_rows, num_cells, n_values,
+        n_vectors, tol, max_cycles, _lib.ptr(vals), vecs.data_ptr(), C.byref(info), hook, None, stream)
+    if failure:
+        raise failure[0]
+    _lib.check(rc)
+    return vals, vecs[:n_vectors].T, {"cycles": info.cycles, "block_products": info.block_products,
+                                      "converged": bool(info.converged),
+                                      "max_residual_vectors": info.max_residual_vectors,
+                                      "max_residual_values": info.max_residual_values}

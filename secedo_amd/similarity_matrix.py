@@ -233,6 +233,19 @@ class SimilarityMatrixPlan:
             self._h, norm, C.c_void_p(acc.data_ptr()), C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
+    def finalize_rows(self, acc, row_begin, row_end, normalization="ADD_MIN", out=None):
+        """Rows [row_begin, row_end) of the normalised matrix as a (rows x num_cells) tensor: the row
+        block a rank keeps when the matrix stays sharded (BASELINE config 5)."""
+        norm = to_enum(normalization)
+        if out is None:
+            out = self._torch.empty((row_end - row_begin, self.num_cells), dtype=self._torch.float64,
+                                    device="cuda:%d" % self.device)
+        assert out.dtype == self._torch.float64 and out.is_contiguous()
+        _lib.check(_lib.lib().secedo_simmat_finalize_rows(
+            self._h, norm, C.c_void_p(acc.data_ptr()), row_begin, row_end, C.c_void_p(out.data_ptr()),
+            self._stream()))
+        return out
+
     def finalize_raw(self, acc, out=None):
         if out is None:
             out = self._torch.empty((self.num_cells, self.num_cells), dtype=self._torch.float64,

@@ -73,3 +73,15 @@ def test_sharded_accumulate_gloo_world2(num_tiles):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=10) == [1, 1]
+
+
+def test_row_ranges_partition_the_matrix():
+    """Row blocks of the matrix kept sharded (BASELINE config 5): contiguous, disjoint, covering, even."""
+    from secedo_amd.distributed import row_range
+    for n in (1, 7, 64, 1000, 32000):
+        for world in (1, 2, 3, 8):
+            edges = [row_range(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1

@@ -40,6 +40,70 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _spectral_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import secedo_amd
+        from secedo_amd import distributed as sd
+        from secedo_amd.synth import synth_config
+
+        n = 64
+        p = synth_config("C1")  # two clones of 32 cells
+        torch.cuda.set_device(0)
+        with secedo_amd.SimilarityMatrixPlan(0) as plan:
+            plan.prepare(p, n, 1000, None, 8)
+            acc = plan.new_acc(pad_tiles_to=world)
+            sd.sharded_accumulate(plan, acc, 0.01, 0.5, 0.01, rank, world)
+            lo, hi = sd.row_range(n, rank, world)  # 3 ranks: 22 + 21 + 21 rows
+            rows = plan.finalize_rows(acc, lo, hi, "ADD_MIN")
+            vals, vecs, info = sd.sharded_eigenpairs(rows, lo, n, 20, 7)
+            assert info["converged"]
+            np.save(os.path.join(out_dir, "vals%d.npy" % rank), vals)
+            np.save(os.path.join(out_dir, "vecs%d.npy" % rank), vecs.cpu().numpy())
+            np.save(os.path.join(out_dir, "rows%d.npy" % rank), rows.cpu().numpy())
+            if rank == 0:
+                full = plan.finalize(acc, "ADD_MIN")
+                np.save(os.path.join(out_dir, "full.npy"), full.cpu().numpy())
+                v1, w1, _ = secedo_amd.smallest_eigenpairs(full, 20, 7)
+                np.save(os.path.join(out_dir, "vals_single.npy"), v1)
+                np.save(os.path.join(out_dir, "vecs_single.npy"), w1.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_matrix_sharded_by_rows_feeds_the_distributed_spectral_step(tmp_path):
+    """BASELINE config 5 in small: three ranks (on the one GPU of the box, gloo rendezvous) keep a row
+    block each of the normalised matrix (finalize_rows), the spectral step multiplies per rank and
+    all-reduces the n x 32 partial products. Every rank must return the same eigenpairs, they must
+    agree with the single-process solve on the gathered matrix, and the row blocks must tile it."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    world = 3
+    procs = [ctx.Process(target=_spectral_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    full = np.load(tmp_path / "full.npy")
+    assert np.array_equal(np.concatenate([np.load(tmp_path / ("rows%d.npy" % r)) for r in range(world)]), full)
+    v_single, w_single = np.load(tmp_path / "vals_single.npy"), np.load(tmp_path / "vecs_single.npy")
+    for r in range(world):
+        vals, vecs = np.load(tmp_path / ("vals%d.npy" % r)), np.load(tmp_path / ("vecs%d.npy" % r))
+        assert np.array_equal(vals, np.load(tmp_path / "vals0.npy")) and np.array_equal(vecs, np.load(tmp_path / "vecs0.npy"))
+        assert np.max(np.abs(vals - v_single)) <= 1e-9
+        # the Fiedler vector splits the two clones on every rank
+        side = vecs[:, 1] >= 0
+        assert np.all(side[:32] == side[0]) and np.all(side[32:] == side[32]) and side[0] != side[32]
+    lap = np.eye(64) - full / np.sqrt(np.outer(full.sum(1), full.sum(1)))
+    vals, vecs = np.load(tmp_path / "vals1.npy"), np.load(tmp_path / "vecs1.npy")
+    assert np.max(np.abs(lap @ vecs - vecs * vals[:7])) <= 2e-8
+
+
 def test_two_ranks_reproduce_single_process_bitwise(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
