@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""bench_em.py [WORKLOAD ...] -- EM refinement on a synthetic pileup resident in HBM: ms per call, iterations,
-bytes of pileup read per second. CPU: oracle/em_oracle.c on the same input (one thread, as the reference)."""
+"""bench_em.py [WORKLOAD ...] -- EM refinement on a synthetic pileup resident in HBM: ms per call and
+iterations. (The CPU figure quoted in DESIGN.md comes from the oracle under tests/, which tools may not import.)"""
 import json
 import sys
 import time
@@ -33,10 +33,4 @@ for name in sys.argv[1:] or ["C2", "C3"]:
         times.append((time.perf_counter() - t0) * 1e3)
     line = {"workload": name, "cells": n, "entries": E, "iterations": iters, "ms": min(times),
             "clones_separated": bool((d_prob[: n // 2] < 0.05).all() and (d_prob[n // 2:] > 0.95).all())}
-    if E <= 3_000_000:
-        from oracle import bindings as ob
-        t0 = time.perf_counter()
-        ref, it = ob.oracle_em(p, np.arange(n, dtype=np.uint32), 1e-3, prob0)
-        line["cpu_port_ms"] = (time.perf_counter() - t0) * 1e3
-        line["max_abs_diff"] = float(np.max(np.abs(ref - d_prob.cpu().numpy())))
     print(json.dumps(line))
