@@ -9,7 +9,8 @@
 //   * full re-orthogonalisation against the cycle's basis (classical Gram-Schmidt twice) and a
 //     Cholesky QR of each new block, with dependent columns dropped -- so eigenvalue multiplicity
 //     up to 32 (disconnected cell graphs) and N < 32 need no special case;
-//   * Rayleigh-Ritz on the (6 x 32)-dimensional projection every cycle, on the host (sym_eig.cpp);
+//   * Rayleigh-Ritz on the (6 x 32)-dimensional projection every cycle, on the host (sym_eig.cpp: all
+//     Ritz values, the 32 Ritz vectors that are kept);
 //     residuals from the last coupling block; restart from the 32 best Ritz vectors.
 // The first start vector is D^1/2 1, the known eigenvector of eigenvalue 0.
 // The cell-cluster eigenvectors converge in the first cycle or two. The rest of the 20 values the
@@ -25,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -248,6 +250,8 @@ int solve(int device_id, const double *d_rows, uint32_t row_begin, uint32_t n_ro
     std::memset(&inf, 0, sizeof(inf));
     std::vector<uint32_t> top(BW);
     std::vector<double> res(BW, 0.0);
+    double rr_seconds = 0.0;
+    const auto t_solve = std::chrono::steady_clock::now();
     for (uint32_t cycle = 0; cycle < max_cycles; ++cycle) {
         std::fill(H.begin(), H.end(), 0.0);
         for (uint32_t j = 0; j < kCycleBlocks; ++j) {
@@ -273,8 +277,10 @@ int solve(int device_id, const double *d_rows, uint32_t row_begin, uint32_t n_ro
         // a dropped basis column is a zero vector: keep its (zero) Ritz value below the spectrum of T
         for (uint32_t r = 0; r < m; ++r)
             if (!basis_alive[r]) H[(size_t)r * m + r] = -1.0;
-        if (!secedo::sym_eig((int)m, H, theta, U))
+        const auto t_rr = std::chrono::steady_clock::now();
+        if (!secedo::sym_eig_top((int)m, H, (int)BW, theta, U))  // U: m x 32, column k = k-th largest
             return secedo::api_fail(SECEDO_E_LIMIT, "the projected eigenproblem did not converge");
+        rr_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rr).count();
         // the largest tau first; residual of a Ritz pair = || R_last u_last || (T V_j = sum_blk V_blk H_blk,j
         // + V_{j+1} R_j, so T y - theta y = V_6 R_5 u_last for y = V u)
         for (uint32_t k = 0; k < BW; ++k) top[k] = m - 1 - k;
@@ -283,7 +289,7 @@ int solve(int device_id, const double *d_rows, uint32_t row_begin, uint32_t n_ro
             for (uint32_t a = 0; a < BW; ++a) {
                 double v = 0.0;
                 for (uint32_t c = 0; c < BW; ++c)
-                    v += R_last[(size_t)a * BW + c] * U[(size_t)((kCycleBlocks - 1) * BW + c) * m + top[k]];
+                    v += R_last[(size_t)a * BW + c] * U[(size_t)((kCycleBlocks - 1) * BW + c) * BW + k];
                 r2 += v * v;
             }
             res[k] = 2.0 * std::sqrt(r2);  // in units of L = 2 (I - T)
@@ -299,14 +305,16 @@ int solve(int device_id, const double *d_rows, uint32_t row_begin, uint32_t n_ro
         if (std::getenv("SECEDO_SPECTRAL_TRACE")) {  // diagnostics: residuals of the wanted pairs per cycle
             std::fprintf(stderr, "[spectral] cycle %u:", cycle);
             for (uint32_t k = 0; k < n_values; ++k) std::fprintf(stderr, " %.1e", res[k]);
-            std::fprintf(stderr, "\n");
+            std::fprintf(stderr, " | %.1f ms so far, %.1f ms of it in the projected eigenproblem\n",
+                         1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_solve).count(),
+                         1e3 * rr_seconds);
         }
         // Ritz vectors of the 32 best pairs: Y = V U[:, top]
         std::vector<double> coeff((size_t)kCycleBlocks * BW * BW);
         for (uint32_t blk = 0; blk < kCycleBlocks; ++blk)
             for (uint32_t a = 0; a < BW; ++a)
                 for (uint32_t k = 0; k < BW; ++k)
-                    coeff[((size_t)blk * BW + a) * BW + k] = U[(size_t)(blk * BW + a) * m + top[k]];
+                    coeff[((size_t)blk * BW + a) * BW + k] = U[(size_t)(blk * BW + a) * BW + k];
         if ((rc = sv.upload_small(coeff))) return rc;
         SP_TRY(block_combine(n, sv.Q.d(), sv.blk_stride, kCycleBlocks, sv.M.d(), 1.0, 0.0, sv.W.d(), stream));
         if (inf.converged || cycle + 1 == max_cycles) {

@@ -10,7 +10,17 @@
 
 namespace secedo {
 
+bool sym_eig(int n, const std::vector<double> &a_in, std::vector<double> &evals, std::vector<double> &evecs);
+
 namespace {
+
+// sqrt(a^2 + b^2); std::hypot guards against overflow at ten times the cost, which only matters far
+// outside the range of a projected operator with norm <= 1
+inline double pythag(double a, double b) {
+    const double m = std::fmax(std::fabs(a), std::fabs(b));
+    if (m > 1e-140 && m < 1e140) return std::sqrt(a * a + b * b);
+    return std::hypot(a, b);
+}
 
 // A (n x n, row-major, symmetric) -> tridiagonal (d, e) with A = Q T Q^T; Q^T overwrites A
 void tridiagonalise(int n, std::vector<double> &a, std::vector<double> &d, std::vector<double> &e) {
@@ -88,14 +98,14 @@ bool ql_implicit(int n, std::vector<double> &d, std::vector<double> &e, std::vec
             if (m == l) break;
             if (++iter > 200) return false;
             double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-            double r = std::hypot(g, 1.0);
+            double r = pythag(g, 1.0);
             g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
             double s = 1.0, c = 1.0, p = 0.0;
             int i = m - 1;
             for (; i >= l; --i) {
                 double f = s * e[i];
                 const double b = c * e[i];
-                r = std::hypot(f, g);
+                r = pythag(f, g);
                 e[i + 1] = r;
                 if (r == 0.0) {
                     d[i + 1] -= p;
@@ -124,6 +134,273 @@ bool ql_implicit(int n, std::vector<double> &d, std::vector<double> &e, std::vec
     }
     return true;
 }
+
+// Householder reduction that keeps the reflectors (column k of `vs` = v_k, unit norm, zero up to row
+// k): Q = H_0 H_1 ... is applied to single vectors afterwards instead of being formed.
+void tridiagonalise_keep(int n, std::vector<double> &a, std::vector<double> &d, std::vector<double> &e,
+                         std::vector<double> &vs, std::vector<char> &used) {
+    std::vector<double> v(n), p(n);
+    vs.assign((size_t)n * n, 0.0);
+    used.assign(n, 0);
+    for (int k = 0; k + 2 < n; ++k) {
+        double norm2 = 0.0;  // column k below the diagonal, from the lower triangle
+        for (int i = k + 1; i < n; ++i) norm2 += a[(size_t)i * n + k] * a[(size_t)i * n + k];
+        const double x0 = a[(size_t)(k + 1) * n + k];
+        if (norm2 - x0 * x0 <= 0.0) continue;
+        const double norm = std::sqrt(norm2);
+        const double alpha = x0 > 0.0 ? -norm : norm;
+        double vnorm2 = 0.0;
+        for (int i = k + 1; i < n; ++i) {
+            v[i] = a[(size_t)i * n + k];
+            if (i == k + 1) v[i] -= alpha;
+            vnorm2 += v[i] * v[i];
+        }
+        if (vnorm2 == 0.0) continue;
+        const double inv = 1.0 / std::sqrt(vnorm2);
+        for (int i = k + 1; i < n; ++i) v[i] *= inv;
+        // only the lower triangle of the trailing block is kept up to date: p = B v from it
+        for (int i = k + 1; i < n; ++i) p[i] = 0.0;
+        for (int i = k + 1; i < n; ++i) {
+            const double *row = &a[(size_t)i * n];
+            const double vi = v[i];
+            double s = row[i] * vi;
+            for (int j = k + 1; j < i; ++j) {
+                s += row[j] * v[j];
+                p[j] += row[j] * vi;
+            }
+            p[i] += s;
+        }
+        double kappa = 0.0;
+        for (int i = k + 1; i < n; ++i) kappa += v[i] * p[i];
+        for (int i = k + 1; i < n; ++i) p[i] -= kappa * v[i];
+        for (int i = k + 1; i < n; ++i) {
+            double *row = &a[(size_t)i * n];
+            const double vi = 2.0 * v[i], pi = 2.0 * p[i];
+            for (int j = k + 1; j <= i; ++j) row[j] -= vi * p[j] + pi * v[j];
+        }
+        a[(size_t)(k + 1) * n + k] = alpha;
+        for (int i = k + 2; i < n; ++i) a[(size_t)i * n + k] = 0.0;
+        for (int i = k + 1; i < n; ++i) vs[(size_t)k * n + i] = v[i];  // reflector k, stored as a row
+        used[k] = 1;
+    }
+    d.assign(n, 0.0);
+    e.assign(n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        d[i] = a[(size_t)i * n + i];
+        if (i + 1 < n) e[i] = a[(size_t)(i + 1) * n + i];
+    }
+}
+
+// eigenvalues of the tridiagonal (d, e) by the implicit QL iteration, no vectors
+bool ql_values(int n, std::vector<double> d, std::vector<double> e, std::vector<double> &out) {
+    for (int l = 0; l < n; ++l) {
+        int iter = 0;
+        while (true) {
+            int m = l;
+            for (; m + 1 < n; ++m) {
+                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
+            }
+            if (m == l) break;
+            if (++iter > 200) return false;
+            double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+            double r = pythag(g, 1.0);
+            g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+            double s = 1.0, c = 1.0, p = 0.0;
+            int i = m - 1;
+            for (; i >= l; --i) {
+                const double f = s * e[i], b = c * e[i];
+                r = pythag(f, g);
+                e[i + 1] = r;
+                if (r == 0.0) {
+                    d[i + 1] -= p;
+                    e[m] = 0.0;
+                    break;
+                }
+                s = f / r;
+                c = g / r;
+                g = d[i + 1] - p;
+                r = (d[i] - g) * s + 2.0 * c * b;
+                p = s * r;
+                d[i + 1] = g + p;
+                g = c * r - b;
+            }
+            if (r == 0.0 && i >= l) continue;
+            d[l] -= p;
+            e[l] = g;
+            e[m] = 0.0;
+        }
+    }
+    out = d;
+    std::sort(out.begin(), out.end());
+    return true;
+}
+
+// One eigenvector of the tridiagonal (d, e) for the eigenvalue approximation lambda by inverse
+// iteration: LU of T - lambda I with partial pivoting (a second super-diagonal appears), a few
+// solves from a fixed pseudo-random start, orthogonalised against `against` (the vectors already
+// found for eigenvalues close to lambda) before each normalisation.
+bool inverse_iteration(int n, const std::vector<double> &d, const std::vector<double> &e, double lambda, double tnorm,
+                       const std::vector<const double *> &against, unsigned seed, double *x) {
+    std::vector<double> u0(n), u1(n, 0.0), u2(n, 0.0), lmul(n, 0.0);
+    std::vector<char> swapped(n, 0);
+    const double tiny = 2.3e-16 * (tnorm > 0.0 ? tnorm : 1.0);
+    // elimination: row i has (u0[i], u1[i], u2[i]) on columns (i, i+1, i+2) after the step
+    double di = d[0] - lambda, ei = n > 1 ? e[0] : 0.0, fi = 0.0;  // current row i
+    for (int i = 0; i + 1 < n; ++i) {
+        const double sub = e[i];                                        // row i+1: (sub, d[i+1]-lambda, e[i+1])
+        const double dn = d[i + 1] - lambda, en = (i + 2 < n) ? e[i + 1] : 0.0;
+        if (std::fabs(sub) > std::fabs(di)) {  // swap rows i and i+1
+            swapped[i] = 1;
+            lmul[i] = di / sub;
+            u0[i] = sub;
+            u1[i] = dn;
+            u2[i] = en;
+            const double ndi = ei - lmul[i] * dn, nei = fi - lmul[i] * en;
+            di = ndi;
+            ei = nei;
+            fi = 0.0;
+        } else {
+            const double piv = std::fabs(di) < tiny ? (di < 0 ? -tiny : tiny) : di;
+            lmul[i] = sub / piv;
+            u0[i] = piv;
+            u1[i] = ei;
+            u2[i] = fi;
+            di = dn - lmul[i] * ei;
+            ei = en - lmul[i] * fi;
+            fi = 0.0;
+        }
+    }
+    u0[n - 1] = std::fabs(di) < tiny ? (di < 0 ? -tiny : tiny) : di;
+    unsigned long long state = 0x9E3779B97F4A7C15ull * (seed + 1);
+    for (int i = 0; i < n; ++i) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        x[i] = 0.5 + (double)(state >> 11) * (1.0 / 9007199254740992.0);  // (0.5, 1.5): no accidental zero start
+    }
+    std::vector<double> y(n);
+    for (int it = 0; it < 6; ++it) {
+        // forward: apply the row operations to x
+        for (int i = 0; i < n; ++i) y[i] = x[i];
+        for (int i = 0; i + 1 < n; ++i) {
+            if (swapped[i]) std::swap(y[i], y[i + 1]);
+            y[i + 1] -= lmul[i] * y[i];
+        }
+        // back substitution with the upper triangle (three diagonals)
+        for (int i = n - 1; i >= 0; --i) {
+            double v = y[i];
+            if (i + 1 < n) v -= u1[i] * y[i + 1];
+            if (i + 2 < n) v -= u2[i] * y[i + 2];
+            y[i] = v / u0[i];
+        }
+        for (const double *q : against) {
+            double dot = 0.0;
+            for (int i = 0; i < n; ++i) dot += q[i] * y[i];
+            for (int i = 0; i < n; ++i) y[i] -= dot * q[i];
+        }
+        double norm = 0.0;
+        for (int i = 0; i < n; ++i) norm += y[i] * y[i];
+        norm = std::sqrt(norm);
+        if (!(norm > 0.0) || !std::isfinite(norm)) return false;
+        for (int i = 0; i < n; ++i) x[i] = y[i] / norm;
+        // converged when T x - lambda x is at rounding level
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double r = (d[i] - lambda) * x[i];
+            if (i > 0) r += e[i - 1] * x[i - 1];
+            if (i + 1 < n) r += e[i] * x[i + 1];
+            res = std::max(res, std::fabs(r));
+        }
+        if (it >= 1 && res <= 64.0 * tiny) return true;
+    }
+    return false;
+}
+
+}  // namespace
+
+bool sym_eig_top(int n, const std::vector<double> &a_in, int k, std::vector<double> &evals,
+                 std::vector<double> &top_vecs) {
+    if (k > n) k = n;
+    if (n <= 2 || k <= 0) {  // nothing to gain: the full decomposition
+        std::vector<double> z;
+        if (!sym_eig(n, a_in, evals, z)) return false;
+        top_vecs.assign((size_t)n * std::max(k, 0), 0.0);
+        for (int j = 0; j < k; ++j)
+            for (int i = 0; i < n; ++i) top_vecs[(size_t)i * k + j] = z[(size_t)i * n + (n - 1 - j)];
+        return true;
+    }
+    std::vector<double> a((size_t)n * n);
+    double tnorm = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            a[(size_t)i * n + j] = 0.5 * (a_in[(size_t)i * n + j] + a_in[(size_t)j * n + i]);
+            tnorm = std::max(tnorm, std::fabs(a[(size_t)i * n + j]));
+        }
+    const std::vector<double> a_sym = a;
+    std::vector<double> d, e, vs;
+    std::vector<char> used;
+    tridiagonalise_keep(n, a, d, e, vs, used);
+    if (!ql_values(n, d, e, evals)) return false;
+    double t1 = 0.0;  // 1-norm of the tridiagonal: the scale of its rounding errors
+    for (int i = 0; i < n; ++i) t1 = std::max(t1, std::fabs(d[i]) + (i ? std::fabs(e[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(e[i]) : 0.0));
+    std::vector<double> tv((size_t)k * n);  // eigenvectors of the tridiagonal, one per row
+    std::vector<double> lam(k);
+    for (int j = 0; j < k; ++j) {
+        lam[j] = evals[n - 1 - j];
+        // eigenvalues closer than 1e-3 of the norm form a cluster: orthogonalise inside it, and nudge
+        // coinciding shifts apart so that the solves do not all return the same direction
+        std::vector<const double *> against;
+        double shift = lam[j];
+        for (int q = 0; q < j; ++q) {
+            if (std::fabs(lam[q] - lam[j]) <= 1e-3 * t1) against.push_back(&tv[(size_t)q * n]);
+        }
+        if (j > 0 && lam[j - 1] - shift < 10.0 * 2.3e-16 * t1) shift = lam[j - 1] - 10.0 * 2.3e-16 * t1 * (double)against.size();
+        if (!inverse_iteration(n, d, e, shift, t1, against, (unsigned)j, &tv[(size_t)j * n])) {
+            std::vector<double> z;  // rare: fall back to the full decomposition
+            if (!sym_eig(n, a_in, evals, z)) return false;
+            top_vecs.assign((size_t)n * k, 0.0);
+            for (int jj = 0; jj < k; ++jj)
+                for (int i = 0; i < n; ++i) top_vecs[(size_t)i * k + jj] = z[(size_t)i * n + (n - 1 - jj)];
+            return true;
+        }
+    }
+    // back-transformation: eigenvector of A = H_0 H_1 ... H_{n-3} x
+    for (int j = 0; j < k; ++j) {
+        double *x = &tv[(size_t)j * n];
+        for (int r = n - 3; r >= 0; --r) {
+            if (!used[r]) continue;
+            const double *v = &vs[(size_t)r * n];
+            double dot = 0.0;
+            for (int i = r + 1; i < n; ++i) dot += v[i] * x[i];
+            dot *= 2.0;
+            for (int i = r + 1; i < n; ++i) x[i] -= dot * v[i];
+        }
+    }
+    // accept only what A itself confirms
+    for (int j = 0; j < k; ++j) {
+        const double *x = &tv[(size_t)j * n];
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0;
+            const double *row = &a_sym[(size_t)i * n];
+            for (int c = 0; c < n; ++c) s += row[c] * x[c];
+            res = std::max(res, std::fabs(s - lam[j] * x[i]));
+        }
+        if (!(res <= 1e-11 * (tnorm > 0.0 ? tnorm * n : 1.0))) {
+            std::vector<double> z;
+            if (!sym_eig(n, a_in, evals, z)) return false;
+            top_vecs.assign((size_t)n * k, 0.0);
+            for (int jj = 0; jj < k; ++jj)
+                for (int i = 0; i < n; ++i) top_vecs[(size_t)i * k + jj] = z[(size_t)i * n + (n - 1 - jj)];
+            return true;
+        }
+    }
+    top_vecs.assign((size_t)n * k, 0.0);
+    for (int j = 0; j < k; ++j)
+        for (int i = 0; i < n; ++i) top_vecs[(size_t)i * k + j] = tv[(size_t)j * n + i];
+    return true;
+}
+
+namespace {
 
 }  // namespace
 

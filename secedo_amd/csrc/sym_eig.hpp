@@ -9,4 +9,11 @@ namespace secedo {
 // eigenvector of evals[k] in COLUMN k. Returns false if the QL iteration did not converge.
 bool sym_eig(int n, const std::vector<double> &a, std::vector<double> &evals, std::vector<double> &evecs);
 
+// All eigenvalues (ascending) but only the eigenvectors of the k LARGEST: top_vecs is n x k row-major,
+// column j = eigenvector of evals[n - 1 - j]. Householder reduction with the reflectors kept, values by
+// QL without accumulation, vectors by inverse iteration on the tridiagonal and back-transformation:
+// about a fifth of the work of sym_eig for k = 32 of 192. Falls back to sym_eig if a vector does not
+// verify against the matrix.
+bool sym_eig_top(int n, const std::vector<double> &a, int k, std::vector<double> &evals, std::vector<double> &top_vecs);
+
 }  // namespace secedo
