@@ -362,11 +362,14 @@ __global__ void k_completed(Raw in, const uint32_t *starts_by_rank, const uint32
 // flush chain (:356-373): flushed = c(l) whenever c(l) - flushed >= 4 * num_threads. One workgroup
 // per chromosome; the chain is sequential, so lane 0 walks LDS tiles of the counts.
 // The loci at which a flush happens are listed per chromosome (flush_loci[l0 ..), flush_count[c]).
+// (only when some id spans >= max_fragment_length -- Scalars::long_reads, set by k_read_info just
+// before: nothing reads the list otherwise, and the bookkeeping triples the cost of the serial walk).
 __global__ __launch_bounds__(TPB) void k_flush_chain(Raw in, const uint32_t *cnt, uint32_t threshold,
-                                                    uint32_t *flushed_out, uint32_t *flush_loci,
-                                                    uint32_t *flush_count) {
+                                                    const Scalars *sc, uint32_t *flushed_out,
+                                                    uint32_t *flush_loci, uint32_t *flush_count) {
     __shared__ uint32_t buf[2048];
-    __shared__ uint32_t s_flushed, s_listed;
+    __shared__ uint32_t hits[2048];  // flush loci of the tile: the serial walk touches LDS only
+    __shared__ uint32_t s_flushed, s_listed, s_hits;
     const uint32_t c = blockIdx.x;
     const uint32_t l0 = in.chr_locus_off[c], l1 = in.chr_locus_off[c + 1];
     if (threadIdx.x == 0) {
@@ -379,17 +382,29 @@ __global__ __launch_bounds__(TPB) void k_flush_chain(Raw in, const uint32_t *cnt
         for (uint32_t i = threadIdx.x; i < n; i += TPB) buf[i] = cnt[base + i];
         __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t f = s_flushed, listed = s_listed;
-            for (uint32_t i = 0; i < n; ++i) {
-                const uint32_t v = buf[i];
-                if (v - f >= threshold) {  // v >= f: the counts never decrease
-                    f = v;
-                    flush_loci[l0 + listed++] = base + i;
+            uint32_t f = s_flushed, h = 0;
+            if (sc->long_reads) {
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t v = buf[i];
+                    if (v - f >= threshold) {  // v >= f: the counts never decrease
+                        f = v;
+                        hits[h++] = base + i;
+                    }
+                }
+            } else {
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t v = buf[i];
+                    if (v - f >= threshold) f = v;
                 }
             }
             s_flushed = f;
-            s_listed = listed;
+            s_hits = h;
         }
+        __syncthreads();
+        const uint32_t h = s_hits, listed = s_listed;
+        for (uint32_t i = threadIdx.x; i < h; i += TPB) flush_loci[l0 + listed + i] = hits[i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_listed = listed + h;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -808,12 +823,15 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
             bases |= (uint32_t)(read_base[j] & 1u) << (dist - 1);
             bases |= (uint32_t)((read_base[j] >> 1) & 1u) << (16 + dist - 1);
         }
-        entry[d] = make_uint4(meta, masks, bases, l);
+        // the 16-byte record and the read index serve pairs of two multi-locus reads only
+        if (hi - lo > 1) {
+            entry[d] = make_uint4(meta, masks, bases, l);
+            entry_read[d] = r;
+        }
         entry32[d] = cib | (base << kC_BaseShift) | (tail ? kC_Tail : 0u) | (hi - lo > 1 ? kC_Multi : 0u)
                 | (wide ? kC_Wide : 0u) | (locus_rel[l] << 16);
         mask32[d] = (masks & 0xFFu) | (((masks >> 16) & 0xFFu) << 8) | ((bases & 0xFFu) << 16)
                 | (((bases >> 16) & 0xFFu) << 24);
-        entry_read[d] = r;
     }
 }
 
@@ -988,7 +1006,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         HIP_OK(hipEventRecord(pk.ev_fork, stream));
         HIP_OK(hipStreamWaitEvent(pk.side, pk.ev_fork, 0));
         hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, pk.side, raw, starts_by_rank, rbeg, mfl, cnt);
-        hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, pk.side, raw, cnt, 4u * num_threads, flushed,
+        hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, pk.side, raw, cnt, 4u * num_threads, sc, flushed,
                            flush_loci, flush_count);
         HIP_OK(hipEventRecord(pk.ev_join, pk.side));
         return std::string();

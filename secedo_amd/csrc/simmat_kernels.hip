@@ -17,7 +17,6 @@ namespace secedo {
 
 namespace {
 
-constexpr uint32_t META_TAIL = 1u << 18;
 constexpr uint32_t META_PREV_OVF = 1u << 19;
 constexpr uint32_t META_NEXT_OVF = 1u << 20;
 constexpr uint32_t C_CELL = 127u;
@@ -501,26 +500,29 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
             }
         } else {
             // a locus range that does not fit the staging buffers (a single very deep locus):
-            // pair it straight from HBM/L2 with the full entries, straight into HBM
+            // pair it straight from HBM/L2 with the compact entries, straight into HBM; the full
+            // entries are read (and exist) only for pairs of two multi-locus reads
             for (uint32_t e1 = ib + tid; e1 < ie; e1 += THREADS) {
-                const uint4 A1 = a.entry[e1];
-                const uint32_t l = A1.w;
+                const uint32_t r1 = a.entry32[e1];
+                const uint32_t l = la + (r1 >> 16);
                 const uint32_t j0 = diag ? e1 + 1 : offJ[l];
                 const uint32_t j1 = offJ[l + 1];
-                const uint32_t c1 = A1.x & 0xFFFFu;
-                const uint32_t row = (c1 - I * B) * B;
+                const uint32_t row = (r1 & C_CELL) * B;
                 for (uint32_t e2 = j0; e2 < j1; ++e2) {
-                    const uint32_t m2 = a.entry[e2].x;
-                    const uint32_t c2 = m2 & 0xFFFFu;
-                    if (c1 == c2) continue;
-                    if (A1.x & m2 & META_TAIL) continue;
+                    const uint32_t r2 = a.entry32[e2];
+                    const uint32_t x = r1 ^ r2, both = r1 & r2;
+                    if (diag && (x & C_CELL) == 0u) continue;  // same cell (:215)
+                    if (both & C_TAIL) continue;               // both never flushed (:407-408)
                     ++upd;
-                    const long long v = pair_value_full(a.slow, e1, e2);
-                    if (v == NO_PAIR) {
-                        ++skipped;
-                        continue;
+                    long long v = (x & (3u << C_BASE_SHIFT)) ? d01 : d10;
+                    if (both & C_MULTI) {
+                        v = pair_value_full(a.slow, e1, e2);
+                        if (v == NO_PAIR) {
+                            ++skipped;
+                            continue;
+                        }
                     }
-                    atomicAdd(&dst[row + (c2 - J * B)], (unsigned long long)v);
+                    atomicAdd(&dst[row + (r2 & C_CELL)], (unsigned long long)v);
                 }
             }
         }
