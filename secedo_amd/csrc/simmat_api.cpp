@@ -477,7 +477,9 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     // off-diagonal one and gets half the chunks). Cached per tile range.
     if (h->plan_tile_begin != tile_begin || h->plan_tile_end != tile_end || h->plan_ranges != h->pk.num_ranges
         || h->plan_blocks != h->pk.num_blocks) {
-        const uint32_t wgs_per_round = h->pk.block_cells == 128 ? 256u : 1024u;  // 1 resp. 4 per CU
+        // workgroups resident per CU (LDS-limited): 1 (128-cell tiles), 2 (64-cell tiles with staged masks,
+        // 512 threads), 4 (the other 64-cell variants)
+        const uint32_t wgs_per_round = h->pk.block_cells == 128 ? 256u : h->pk.stage_masks ? 512u : 1024u;
         uint32_t rounds = 1;
         if (const char *env = std::getenv("SECEDO_ROUNDS")) rounds = std::max(1, std::atoi(env));
         std::vector<uint32_t> weight(n_tiles);

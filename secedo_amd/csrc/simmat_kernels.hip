@@ -734,7 +734,7 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
         if (count_tile) return launch_acc<128, 1024, kCapJ128C, kCapL128C, 1024, false, true>(args, grid, stream);
         return launch_acc<128, 1024, kCapJ128, kCapL128, 512, false, false>(args, grid, stream);
     }
-    if (stage_masks) return launch_acc<64, 256, kCapJ64M, kCapL64M, 1024, true, false>(args, grid, stream);
+    if (stage_masks) return launch_acc<64, 512, kCapJ64M, kCapL64M, 1024, true, false>(args, grid, stream);
     if (count_tile) return launch_acc<64, 256, kCapJ64C, kCapL64C, 1024, false, true>(args, grid, stream);
     return launch_acc<64, 256, kCapJ64, kCapL64, 1024, false, false>(args, grid, stream);
 }
