@@ -462,7 +462,7 @@ __global__ void k_split_update(Raw in, const unsigned long long *skey, const uin
 // The binning key: cell block | locus (lbits bits) | cell in block (7 bits) -- bit fields, so that
 // taking it apart costs shifts instead of 64-bit divisions.
 constexpr uint32_t kCibBits = 7;
-constexpr uint32_t kNoEntry = 0xFFFFFFFFu;
+constexpr uint32_t kNoEntry = 0xFFFFFFFFu;  // low word of an entry_kc slot: the entry was dropped
 __device__ __forceinline__ unsigned long long bin_key(uint32_t blk, uint32_t l, uint32_t cib, uint32_t lbits) {
     return ((((unsigned long long)blk << lbits) | l) << kCibBits) | cib;
 }
@@ -472,12 +472,12 @@ __device__ __forceinline__ unsigned long long bin_key(uint32_t blk, uint32_t l, 
 __global__ void k_keys2(Raw in, const uint32_t *sval, const unsigned long long *incl,
                         const uint32_t *read_locus, uint32_t num_cells, uint32_t B,
                         uint32_t lbits, unsigned long long *key2, uint32_t *val2, uint32_t *t_read,
-                        uint32_t *entry_k, uint32_t *entry_cell, Scalars *sc) {
+                        unsigned long long *entry_kc, Scalars *sc) {
     const uint32_t n = in.n_entries;
     for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
         const unsigned long long cur = incl[s], prev = s ? incl[s - 1] : 0ull;
         if (incl_kept(cur) == incl_kept(prev)) {
-            if (entry_k) entry_k[sval[s]] = kNoEntry;
+            if (entry_kc) entry_kc[sval[s]] = kNoEntry;
             continue;
         }
         const uint32_t k = incl_kept(prev);
@@ -496,10 +496,9 @@ __global__ void k_keys2(Raw in, const uint32_t *sval, const unsigned long long *
         key2[k] = bin_key(blk, read_locus[k], cib, lbits);
         val2[k] = k;
         t_read[k] = incl_reads(cur) - 1;
-        if (entry_k) {  // counting path: back in pileup order, where the entries of a locus are adjacent
-            entry_k[sval[s]] = k;
-            entry_cell[sval[s]] = (blk << kCibBits) | cib;
-        }
+        // counting path: back in pileup order, where the entries of a locus are adjacent; one 8-byte
+        // scatter per entry carries k and (block, cell in block)
+        if (entry_kc) entry_kc[sval[s]] = ((unsigned long long)((blk << kCibBits) | cib) << 32) | k;
     }
 }
 
@@ -507,8 +506,8 @@ __global__ void k_keys2(Raw in, const uint32_t *sval, const unsigned long long *
 // pileup, so one wave per locus counts them per cell block in LDS and writes the locus' column of
 // the (block, locus) histogram with plain stores -- global atomics would all hit the handful of
 // addresses of the loci in flight.
-__global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, const uint32_t *entry_k,
-                                                 const uint32_t *entry_cell, uint32_t *blk_cnt) {
+__global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, const unsigned long long *entry_kc,
+                                                 uint32_t *blk_cnt) {
     extern __shared__ uint32_t lds_hist[];
     uint32_t *hist = lds_hist + (threadIdx.x >> 6) * nb;
     const uint32_t lane = threadIdx.x & 63u, L = in.n_loci;
@@ -518,8 +517,10 @@ __global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, const uin
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
-        for (uint32_t e = e0 + lane; e < e1; e += 64u)
-            if (entry_k[e] != kNoEntry) atomicAdd(&hist[entry_cell[e] >> kCibBits], 1u);
+        for (uint32_t e = e0 + lane; e < e1; e += 64u) {
+            const unsigned long long kc = entry_kc[e];
+            if ((uint32_t)kc != kNoEntry) atomicAdd(&hist[(uint32_t)(kc >> 32) >> kCibBits], 1u);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (uint32_t b = lane; b < nb; b += 64u) {
@@ -532,8 +533,8 @@ __global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, const uin
 
 // ... and places them: position = group offset + LDS cursor (arbitrary order inside the group).
 // grouped[pos] = cell-in-block << 32 | k, the final order inside a group being (cell, k)
-__global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, const uint32_t *entry_k,
-                                                  const uint32_t *entry_cell, const uint32_t *blk_off,
+__global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, const unsigned long long *entry_kc,
+                                                  const uint32_t *blk_off,
                                                   unsigned long long *grouped) {
     extern __shared__ uint32_t lds_hist[];
     uint32_t *cursor = lds_hist + (threadIdx.x >> 6) * nb;
@@ -545,9 +546,10 @@ __global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, const ui
         __builtin_amdgcn_wave_barrier();
         const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
         for (uint32_t e = e0 + lane; e < e1; e += 64u) {
-            const uint32_t k = entry_k[e];
+            const unsigned long long kc = entry_kc[e];
+            const uint32_t k = (uint32_t)kc;
             if (k == kNoEntry) continue;
-            const uint32_t cc = entry_cell[e];
+            const uint32_t cc = (uint32_t)(kc >> 32);
             const uint32_t pos = atomicAdd(&cursor[cc >> kCibBits], 1u);
             grouped[pos] = ((unsigned long long)(cc & ((1u << kCibBits) - 1u)) << 32) | k;
         }
@@ -860,7 +862,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     DevicePacked &pk = *out;
     // worst-case block count (64-cell blocks) for buffers sized before the tile size is chosen
     const size_t n_off_max = (size_t)((num_cells + 63) / 64) * ((size_t)L + 1);
-    enum { KEY_A, KEY_B, VAL_A, VAL_B, ELOC, WORK_A, WORK_B, RUNS, CUB, TMP, MISC, BIN };
+    enum { KEY_A, KEY_B, VAL_A, VAL_B, ELOC, WORK_A, WORK_B, RUNS, CUB, TMP, MISC, BIN, ENTRY_KC };
     auto &S = pk.scratch;
     // the counting scheme for read ids needs a table over the id space
     const size_t id_space_cap = std::min<size_t>((size_t)kIdSpaceFactor * E + 1024, (size_t)1 << 30);
@@ -891,8 +893,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     HIP_OK(S[ELOC].ensure(std::max<size_t>((size_t)E * 4, ((size_t)2 * L + 4 * 8192 + L / 64 + 16) * 4)));
     HIP_OK(S[WORK_A].ensure(((size_t)E + 1) * 4));
     HIP_OK(S[WORK_B].ensure(((size_t)2 * E + 2) * 4));
-    // RUNS: run_start[R+1] | run_rank[R] | starts_by_rank[R] | entry_cell[E], R <= E
-    HIP_OK(S[RUNS].ensure(((size_t)4 * E + 8) * 4));
+    // RUNS: run_start[R+1] | run_rank[R] | starts_by_rank[R], R <= E
+    HIP_OK(S[RUNS].ensure(((size_t)3 * E + 8) * 4));
+    if (!force_radix) HIP_OK(S[ENTRY_KC].ensure((size_t)E * 8));
     // TMP: read index per kept entry; BIN: key2 x2, val2 x2, per-cell squares
     HIP_OK(S[TMP].ensure((size_t)E * 4 + 64));
     HIP_OK(S[BIN].ensure((size_t)E * 24 + ((size_t)num_cells + 130) * 8 + 64));
@@ -965,7 +968,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *mark = S[KEY_A].as<uint32_t>();  // the unsorted keys / dense ids are dead
     uint32_t *arank = mark + (E + 1);
     uint32_t *run_start = S[RUNS].as<uint32_t>();
-    uint32_t *run_rank = run_start + E + 1, *starts_by_rank = run_rank + E, *entry_cell_buf = starts_by_rank + E;
+    uint32_t *run_rank = run_start + E + 1, *starts_by_rank = run_rank + E;
     uint32_t *split = S[TMP].as<uint32_t>();  // free until k_keys2 writes the read index per kept entry there
     HIP_OK(hipMemsetAsync(split, 0, (size_t)E * 4, stream));
     HIP_OK(pk.read_off.ensure(((size_t)E + 1) * 4));
@@ -1092,12 +1095,11 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *blk_off = pk.blk_off.as<uint32_t>();
     uint32_t *blk_cnt = S[KEY_A].as<uint32_t>();  // mark / arank are dead after k_ranks
     // counting path: per pileup entry its k and cell (entry -> locus and the per-read scratch are dead)
-    uint32_t *entry_k = force_radix ? nullptr : eloc;
-    uint32_t *entry_cell = force_radix ? nullptr : entry_cell_buf;
+    unsigned long long *entry_kc = force_radix ? nullptr : S[ENTRY_KC].as<unsigned long long>();
     if (force_radix) HIP_OK(hipMemsetAsync(blk_cnt, 0, (n_off + 1) * 4, stream));
     HIP_OK(hipMemsetAsync(per_cell_sq, 0, ((size_t)nb * B + 1) * 8, stream));
     hipLaunchKernelGGL(k_keys2, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, incl, read_locus, num_cells, B,
-                       lbits, key2_a, val2_a, t_read, entry_k, entry_cell, sc);
+                       lbits, key2_a, val2_a, t_read, entry_kc, sc);
     const uint32_t slice_grid = std::min<uint32_t>(2048, (n_kept + 4095) / 4096);
     if (force_radix) {
         if (n_kept) {
@@ -1112,13 +1114,13 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     } else {
         const uint32_t locus_grid = std::min<uint32_t>(blocks_for((uint64_t)L * 64), 8192);
         const size_t lds = (size_t)(TPB / 64) * nb * 4;
-        hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_k, entry_cell, blk_cnt);
+        hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_kc, blk_cnt);
         cub_cap = S[CUB].bytes;
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
         if (n_kept) {
             unsigned long long *grouped = key_b;  // the sorted entry keys are dead after k_dup_rule
-            hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_k, entry_cell,
-                               blk_off, grouped);
+            hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_kc, blk_off,
+                               grouped);
             hipLaunchKernelGGL(k_bin_rank, dim3(std::min<uint32_t>(1u << 16, (n_kept + 4095) / 4096)), dim3(TPB_RANK), 0,
                                stream, key2_a, grouped, n_kept, B, L, lbits, blk_off, key2_b, val2_b, per_cell_sq, sc);
         }
