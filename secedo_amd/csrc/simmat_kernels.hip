@@ -13,6 +13,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace secedo {
 
 namespace {
@@ -395,25 +397,29 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                         // exec-mask bookkeeping.
                         uint32_t multi_seen = 0;
                         const uint32_t last = total - 1u;
-                        constexpr int PPL = 2;  // pairs per lane and trip: independent LDS read chains (4 is no faster)
-                        for (uint32_t base = 0; base < ((a.debug & 2u) ? 0u : total); base += 64u * PPL) {
-                            if (MCAP > 0 && n_list > (uint32_t)(MCAP - 64 * PPL)) flush_list();
+                        // One trip = PPL pairs per lane (independent LDS read chains; 4 is no faster than
+                        // 2). Full trips need no bounds handling; the last trip clamps and masks, and
+                        // takes one pair per lane when 64 or fewer pairs are left.
+                        auto trip = [&](uint32_t base, auto ppl_c, auto tail_c) {
+                            constexpr int PPL = decltype(ppl_c)::value;
+                            constexpr bool TAIL = decltype(tail_c)::value;
+                            if (MCAP > 0 && n_list > (uint32_t)(MCAP - 128)) flush_list();
                             uint32_t pp[PPL], oo[PPL], ww[PPL];
                             uint2 rr[PPL];
 #pragma unroll
                             for (int u = 0; u < PPL; ++u) pp[u] = base + lane + 64u * u;
 #pragma unroll
-                            for (int u = 0; u < PPL; ++u) oo[u] = owner[min(pp[u], last)];
+                            for (int u = 0; u < PPL; ++u) oo[u] = owner[TAIL ? min(pp[u], last) : pp[u]];
 #pragma unroll
                             for (int u = 0; u < PPL; ++u) rr[u] = wrec[oo[u]];
 #pragma unroll
-                            for (int u = 0; u < PPL; ++u) ww[u] = sJ[rr[u].y + min(pp[u], last)];
+                            for (int u = 0; u < PPL; ++u) ww[u] = sJ[rr[u].y + (TAIL ? min(pp[u], last) : pp[u])];
 #pragma unroll
                             for (int u = 0; u < PPL; ++u) {
                                 const uint32_t x = rr[u].x ^ ww[u], both = rr[u].x & ww[u];
                                 // reads both never flushed do not pair (:407-408); inside a diagonal
                                 // tile equal cells do not pair (:215)
-                                const bool ok = pp[u] < total && (both & C_TAIL) == 0u
+                                const bool ok = (!TAIL || pp[u] < total) && (both & C_TAIL) == 0u
                                         && ((x & cell_test) != 0u || !diag);
                                 upd += ok ? 1u : 0u;
                                 const uint32_t cell = (rr[u].x >> 16) + (ww[u] & C_CELL);
@@ -437,6 +443,16 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                                     if (COUNTS) atomicAdd(&tile32[cell], differ ? 0x10000u : 1u);
                                     else atomicAdd(&tile64[cell], (unsigned long long)(differ ? d01 : d10));
                                 }
+                            }
+                        };
+                        using two = std::integral_constant<int, 2>;
+                        using one = std::integral_constant<int, 1>;
+                        if (!(a.debug & 2u)) {
+                            uint32_t base = 0;
+                            for (; base + 128u <= total; base += 128u) trip(base, two{}, std::false_type{});
+                            if (base < total) {
+                                if (total - base <= 64u) trip(base, one{}, std::true_type{});
+                                else trip(base, two{}, std::true_type{});
                             }
                         }
                         STAMP(t3);
