@@ -1,15 +1,18 @@
 // pack_device.hip -- device-side packing of the raw flat pileup (see pack_device.hpp).
 //
-// Pipeline (every step a grid-stride kernel or a hipCUB primitive on `stream`):
-//   1  entry -> locus, chromosome; sort entries by (chromosome, read id), stable     [radix sort]
-//   2  runs of equal key = reads; span check (a read longer than max_fragment_length would be split
-//      at a flush: host path); duplicate-position rule per (read, locus) group
-//      (reference: similarity_matrix.cpp:387-395)
+// Pipeline (every step a kernel or a hipCUB scan on `stream`; 3 scalar read-backs):
+//   1  entry -> locus; entries grouped by (chromosome, read id) in pileup order -- histogram over the
+//      dense id space, scan, scatter with an atomic cursor, rank inside the (short) group; the hipCUB
+//      radix sort when the ids are sparse or a group is too long for that
+//   2  duplicate-position rule per (read, locus) group (reference: similarity_matrix.cpp:387-395);
+//      reads = runs of equal key, cut further where a flush erases a read that outlives
+//      max_fragment_length (:368-371, :379-382; k_split_update, iterated with step 4)
 //   3  kept entries -> per-read lists (CSR), multi-locus statistics
 //   4  first-appearance rank of every read, completed-prefix count per locus, flush chain per
 //      chromosome (reference :348-373) -> number of flushed reads F_c -> tail flags (:407-408)
-//   5  entry records (window masks), binning sort by (cell block, locus, cell), block offsets,
-//      pair bound, locus ranges, final gather
+//   5  kept entries grouped by (cell block, locus, cell) -- per-locus LDS histograms, scan, placement,
+//      in-group ranking (or the radix sort) --, block offsets, pair bound, locus ranges, entry records
+//      (window masks) written at their final position
 #include "pack_device.hpp"
 
 #include <hip/hip_runtime.h>

@@ -31,3 +31,16 @@ def test_oracle_laplacian_zero_rows_and_fast_variant():
     w, v = so.eig_sym(lap)
     assert w[0] > -1e-14 and np.all(np.diff(w) >= 0)
     assert np.max(np.abs(lap @ v - v * w)) <= 1e-13
+
+
+def test_host_eigensolver_of_the_rayleigh_ritz_step(tmp_path):
+    """secedo_amd/csrc/sym_eig.cpp is plain C++ (the 192 x 192 projected eigenproblem of the block Lanczos
+    iteration): compiled and run here on random, clustered and degenerate matrices."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "sym_eig_test")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "secedo_amd", "csrc"),
+                    os.path.join(root, "tests", "cpp", "sym_eig_test.cpp"),
+                    os.path.join(root, "secedo_amd", "csrc", "sym_eig.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.strip() == "ok"
