@@ -71,6 +71,9 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
                           uint32_t max_fragment_length, double mutation_rate,
                           double homozygous_rate, double seq_error_rate, uint32_t num_threads,
                           int normalization, double *out);
+/* secedo_simmat_compute keeps its device buffers between calls (one set per device; the reference calls
+ * computeSimilarityMatrix once per sub-cluster of its recursion). This frees them. Never required. */
+void secedo_simmat_release_cache(void);
 
 /* ------------------------------------------------------------------------------------------
  * Staged interface (device-resident data, explicit stream, tile partition for multi-GPU).

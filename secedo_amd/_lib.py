@@ -62,6 +62,7 @@ SIGNATURES = {
     "secedo_simmat_compute": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32,
                                         C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double,
                                         C.c_uint32, C.c_int, _vp]),
+    "secedo_simmat_release_cache": (None, []),
     "secedo_simmat_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "secedo_simmat_destroy": (None, [_vp]),
     "secedo_simmat_set_pileup": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp,

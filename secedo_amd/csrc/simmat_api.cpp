@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -114,6 +116,48 @@ hipError_t buf_upload(DevBuf &b, const T *src, size_t n) {
     hipError_t e = b.ensure(n * sizeof(T));
     if (e != hipSuccess || n == 0) return e;
     return hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice);
+}
+
+}  // namespace
+
+namespace {
+
+// Handles kept for secedo_simmat_compute, one per device, handed out to one caller at a time (a second
+// concurrent caller on the same device gets a fresh handle). Deliberately not destroyed at process
+// exit: static destructors would run after the HIP runtime is gone; the driver reclaims the memory.
+// secedo_simmat_release_cache() frees them on request. SECEDO_ONE_SHOT_CACHE=0 turns the pool off.
+std::mutex g_pool_mutex;
+std::map<int, secedo_simmat_t *> &g_pool = *new std::map<int, secedo_simmat_t *>();
+
+bool pool_enabled() {
+    const char *env = std::getenv("SECEDO_ONE_SHOT_CACHE");
+    return !(env && std::atoi(env) == 0);
+}
+
+int one_shot_acquire(int device, secedo_simmat_t **h) {
+    if (pool_enabled()) {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        auto it = g_pool.find(device);
+        if (it != g_pool.end() && it->second) {
+            *h = it->second;
+            it->second = nullptr;
+            return SECEDO_OK;
+        }
+    }
+    return secedo_simmat_create(h, device);
+}
+
+void one_shot_release(int device, secedo_simmat_t *h, bool ok) {
+    if (!h) return;
+    if (ok && pool_enabled()) {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        secedo_simmat_t *&slot = g_pool[device];
+        if (!slot) {
+            slot = h;
+            return;
+        }
+    }
+    secedo_simmat_destroy(h);
 }
 
 }  // namespace
@@ -619,13 +663,18 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
     if (!out) return fail(SECEDO_E_INVALID_ARG, "out is null");
     int device = 0;
     if (const char *env = std::getenv("SECEDO_DEVICE")) device = std::atoi(env);
+    // The caller of the reference's signature calls this once per sub-cluster of the recursion
+    // (spectral_clustering.cpp:354-356): the handle with its device arenas, streams and tables is kept
+    // between calls (two thirds of a first call on C2 is allocation). A failed call drops its handle.
     secedo_simmat_t *h = nullptr;
-    int rc = secedo_simmat_create(&h, device);
+    int rc = one_shot_acquire(device, &h);
     if (rc != SECEDO_OK) return rc;
     struct Guard {
         secedo_simmat_t *h;
-        ~Guard() { secedo_simmat_destroy(h); }
-    } guard{h};
+        int device;
+        bool ok = false;
+        ~Guard() { one_shot_release(device, h, ok); }
+    } guard{h, device};
     rc = secedo_simmat_set_pileup(h, chr_locus_off, n_chr, locus_pos, locus_entry_off, read_ids,
                                   id_base16, id_base32, group_id_to_pos, n_groups);
     if (rc != SECEDO_OK) return rc;
@@ -642,7 +691,16 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
     rc = secedo_simmat_finalize(h, normalization, h->own_acc.as<int64_t>(), h->own_out.as<double>(), nullptr);
     if (rc != SECEDO_OK) return rc;
     HIP_TRY(hipMemcpy(out, h->own_out.p, out_bytes, hipMemcpyDeviceToHost));
+    guard.ok = true;
     return SECEDO_OK;
+}
+
+void secedo_simmat_release_cache(void) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (auto &slot : g_pool) {
+        if (slot.second) secedo_simmat_destroy(slot.second);
+        slot.second = nullptr;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
