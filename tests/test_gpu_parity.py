@@ -123,6 +123,67 @@ def test_edge_inputs():
         secedo_amd.compute_similarity_matrix(p, 2, 1000, np.arange(10, dtype=np.uint32), 0.01, 0.5, 0.01, 1)
 
 
+def test_ragged_and_degenerate_inputs_match_the_oracle():
+    """Shapes the packing has to survive, each against the oracle (matrix and work counters): empty
+    chromosomes between full ones, loci without entries, many tiny chromosomes, every entry in one cell
+    (no pair at all), all groups mapped to two rows, a flush threshold nothing reaches (every read is
+    a tail read: zero matrix), one locus only, unsorted read ids and huge sparse ids."""
+    rng = np.random.default_rng(123)
+
+    def chrom(n_loci, cov, n, pos0=100, ids=None, empty_every=0):
+        rows, pos = [], pos0
+        for l in range(n_loci):
+            pos += int(rng.integers(1, 400))
+            k = 0 if (empty_every and l % empty_every == 1) else cov
+            ents = []
+            for _ in range(k):
+                rid = next(ids) if ids is not None else int(rng.integers(0, 1 << 20))
+                ents.append((rid, int(rng.integers(0, n)), int(rng.integers(0, 4))))
+            rows.append((pos, ents))
+        return rows
+
+    def counter(start=0, step=1):
+        v = start
+        while True:
+            yield v
+            v += step
+
+    n = 70
+    cases = []
+    ids = counter()
+    cases.append(("empty chromosomes", from_rows([[], chrom(40, 12, n, ids=ids), [], [], chrom(30, 9, n, ids=ids), []]),
+                  n, None, 2))
+    ids = counter()
+    cases.append(("loci without entries", from_rows([chrom(90, 10, n, ids=ids, empty_every=3)]), n, None, 1))
+    ids = counter()
+    cases.append(("120 tiny chromosomes", from_rows([chrom(2, 8, n, ids=ids) for _ in range(120)]), n, None, 1))
+    ids = counter()
+    one_cell = from_rows([[(p, [(r, 5, b) for (r, _, b) in e]) for (p, e) in chrom(50, 10, n, ids=ids)]])
+    cases.append(("one cell only", one_cell, n, None, 1))
+    ids = counter()
+    cases.append(("two rows", from_rows([chrom(60, 14, n, ids=ids)]), 2, (np.arange(n) % 2).astype(np.uint32), 1))
+    ids = counter()
+    cases.append(("nothing flushed", from_rows([chrom(60, 10, n, ids=ids)]), n, None, 100000))
+    ids = counter()
+    cases.append(("one locus", from_rows([[(777, [(next(ids), c % n, c % 4) for c in range(300)])],
+                                           [(9000, [(next(ids), 0, 0)])]]), n, None, 1))
+    cases.append(("random sparse ids", from_rows([chrom(70, 12, n)]), n, None, 1))
+    ids = counter(4_000_000_000, -977)
+    cases.append(("descending huge ids", from_rows([chrom(50, 10, n, ids=ids)]), n, None, 1))
+    for name, p, cells, g2p, T in cases:
+        ref = ob.oracle_compute(p, cells, 1000, g2p, 0.01, 0.5, 0.01, T, "ADD_MIN")
+        counts_ref = (ob.oracle_last_updates(), ob.oracle_last_read_pairs())
+        with secedo_amd.SimilarityMatrixPlan(0) as plan:
+            plan.prepare(p, cells, 1000, g2p, T)
+            acc = plan.new_acc()
+            plan.accumulate(acc, 0.01, 0.5, 0.01)
+            got = plan.finalize(acc, "ADD_MIN").cpu().numpy()
+            assert plan.last_counts() == counts_ref, name
+        assert gu.normwise_err(got, ref) <= TOL, name
+        if name in ("one cell only", "nothing flushed"):
+            assert counts_ref[1] == 0 and not got.any(), name
+
+
 def test_cpp_host_without_torch(tmp_path):
     """Pure C++ host through include/secedo_simmat.hpp (system HIP runtime, no Python in the process),
     fed with the reference's binary pileup record format; must equal the Python-driven result."""
