@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace secedo {
 
@@ -60,7 +61,7 @@ struct Scalars {
     uint32_t regroup;     // a group too long for the in-group ranking: redo with the radix sorts
     uint32_t long_reads;  // some id's entries span >= max_fragment_length: flushes may split it (k_split_update)
     uint32_t split_changed;
-    uint32_t pad;
+    uint32_t id_exceeded;  // the id space is larger than the caller assumed (the size of the previous call)
     unsigned long long id_space;  // sum over chromosomes of (largest - smallest read id + 1)
     unsigned long long multi_entries;
     unsigned long long pair_bound;
@@ -74,6 +75,7 @@ struct Scalars {
 // stable sort gives. A group longer than kRankScanLimit raises Scalars::regroup and the caller
 // falls back to the radix sorts.
 constexpr uint32_t kRankScanLimit = 8192;
+constexpr int kNoRetry = 0, kRetryRadix = 1, kRetrySameScheme = 2;  // what an attempt asks of its caller
 constexpr int kMaxSplitRounds = 32;  // rounds of k_split_update before the host emulation takes over
 // the counting scheme for read ids needs a table over the id space: used while max id < factor * entries
 constexpr uint32_t kIdSpaceFactor = 4;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(TPB) void k_id_range(Raw in, uint32_t *id_max, uint
 
 // dense numbering of (chromosome, read id): id_base[c] + id - smallest id of c
 __global__ void k_id_bases(uint32_t n_chr, const uint32_t *id_max, const uint32_t *id_negmin, uint32_t *id_base,
-                           Scalars *sc) {
+                           unsigned long long assumed_space, Scalars *sc) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     unsigned long long sum = 0;
     uint32_t top = 0;
@@ -190,6 +192,8 @@ __global__ void k_id_bases(uint32_t n_chr, const uint32_t *id_max, const uint32_
     id_base[n_chr] = (uint32_t)min(sum, 0xFFFFFFFFull);
     sc->id_space = sum;
     sc->max_read_id = top;
+    // the caller may have sized the histogram from the previous call without waiting for this kernel
+    if (assumed_space && sum > assumed_space) sc->id_exceeded = 1;
 }
 
 // radix path: sort key (chromosome, read id) with the read id in id_bits bits
@@ -204,7 +208,8 @@ __global__ void k_entry_keys(Raw in, const uint32_t *entry_locus, uint32_t id_bi
 
 // counting path, entries by (chromosome, read id) through the dense numbering
 __global__ void k_id_hist(Raw in, const uint32_t *entry_locus, const uint32_t *id_base, const uint32_t *id_negmin,
-                          uint32_t *dense, uint32_t *hist) {
+                          const Scalars *sc, uint32_t *dense, uint32_t *hist) {
+    if (sc->id_exceeded) return;  // the table is too small: the caller starts over (k_id_rank)
     for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < in.n_entries; e += gridDim.x * TPB) {
         const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, entry_locus[e]);
         const uint32_t d = id_base[c] + (in.read_ids[e] - ~id_negmin[c]);
@@ -213,8 +218,9 @@ __global__ void k_id_hist(Raw in, const uint32_t *entry_locus, const uint32_t *i
     }
 }
 
-__global__ void k_id_scatter(const uint32_t *dense, uint32_t n, const uint32_t *id_off, uint32_t *hist,
-                             uint32_t *grouped) {
+__global__ void k_id_scatter(const uint32_t *dense, uint32_t n, const uint32_t *id_off, const Scalars *sc,
+                             uint32_t *hist, uint32_t *grouped) {
+    if (sc->id_exceeded) return;
     for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
         const uint32_t d = dense[e];
         grouped[id_off[d] + atomicSub(&hist[d], 1u) - 1u] = e;
@@ -225,7 +231,13 @@ __global__ void k_id_scatter(const uint32_t *dense, uint32_t n, const uint32_t *
 // end up in pileup order (by locus), as a stable sort leaves them
 __global__ void k_id_rank(Raw in, const uint32_t *dense, const uint32_t *id_off, const uint32_t *grouped,
                           unsigned long long *skey, uint32_t *sval, Scalars *sc) {
+    const bool void_run = sc->id_exceeded != 0;
     for (uint32_t p = blockIdx.x * TPB + threadIdx.x; p < in.n_entries; p += gridDim.x * TPB) {
+        if (void_run) {  // keep what follows inside its arrays until the host sees the flag and starts over
+            skey[p] = p;
+            sval[p] = p;
+            continue;
+        }
         const uint32_t e = grouped[p];
         const uint32_t d = dense[e];
         const uint32_t b = id_off[d], n = id_off[d + 1] - b;
@@ -857,9 +869,9 @@ int bits_for(unsigned long long max_value) {
 // too long for it sets *retry and the caller runs the attempt again with the radix sorts.
 std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_t mfl, uint32_t num_threads,
                          uint32_t block_cells, StageGeometry (*geometry)(uint32_t), bool allow_count_tile,
-                         bool force_radix, hipStream_t stream, DevicePacked *out, bool *need_host,
-                         bool *retry) {
-    *retry = false;
+                         bool force_radix, bool no_assumptions, hipStream_t stream, DevicePacked *out,
+                         bool *need_host, int *retry) {
+    *retry = kNoRetry;
     const uint32_t E = static_cast<uint32_t>(in.n_entries);
     const uint32_t L = in.n_loci, C = in.n_chr;
     DevicePacked &pk = *out;
@@ -932,12 +944,22 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     hipLaunchKernelGGL(k_entry_locus, dim3(blocks_for((uint64_t)L * 64)), dim3(TPB), 0, stream, raw, eloc);
     hipLaunchKernelGGL(k_id_range, dim3(std::min<uint32_t>(1024, (E + 4095) / 4096)), dim3(TPB), 0, stream, raw,
                        id_max, id_negmin);
-    hipLaunchKernelGGL(k_id_bases, dim3(1), dim3(64), 0, stream, C, id_max, id_negmin, id_base, sc);
+    // The size of the id space decides between the counting scheme and the radix sort and sizes the
+    // histogram. A handle that has packed before assumes the size of the previous call and does not wait
+    // (k_id_bases raises Scalars::id_exceeded if that was too small: the attempt is then void and
+    // repeated with the read-back).
+    const bool assume = !force_radix && !no_assumptions && pk.id_space_hint && pk.id_space_hint <= id_space_cap;
+    hipLaunchKernelGGL(k_id_bases, dim3(1), dim3(64), 0, stream, C, id_max, id_negmin, id_base,
+                       (unsigned long long)(assume ? pk.id_space_hint : 0), sc);
     Scalars hsc;
-    HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));  // read-back 1: the largest read id (size of the id space)
-    if (hsc.error == 3) return "positions must be strictly increasing within a chromosome";
-    const size_t id_space = (size_t)std::min<unsigned long long>(hsc.id_space, 1ull << 40);
+    std::memset(&hsc, 0, sizeof(hsc));
+    if (!assume) {
+        HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));  // read-back 1: the size of the id space
+        if (hsc.error == 3) return "positions must be strictly increasing within a chromosome";
+    }
+    const size_t id_space = assume ? (size_t)pk.id_space_hint
+                                   : (size_t)std::min<unsigned long long>(hsc.id_space, 1ull << 40);
     const bool counting = !force_radix && id_space <= id_space_cap;
     HIP_OK(S[WORK_A].ensure(std::max<size_t>((size_t)E + 1, counting ? id_space + 1 : 0) * 4));
     HIP_OK(S[WORK_B].ensure(std::max<size_t>((size_t)2 * E + 2, counting ? id_space + 1 : 0) * 4));
@@ -946,11 +968,12 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         uint32_t *hist = work_a, *id_off = work_b, *grouped = val_a;
         uint32_t *dense = S[KEY_A].as<uint32_t>();  // the radix path's unsorted keys live here
         HIP_OK(hipMemsetAsync(hist, 0, (id_space + 1) * 4, stream));
-        hipLaunchKernelGGL(k_id_hist, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_base, id_negmin, dense,
-                           hist);
+        hipLaunchKernelGGL(k_id_hist, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_base, id_negmin, sc,
+                           dense, hist);
         cub_cap = S[CUB].bytes;
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, hist, id_off, (int)(id_space + 1), stream));
-        hipLaunchKernelGGL(k_id_scatter, dim3(blocks_for(E)), dim3(TPB), 0, stream, dense, E, id_off, hist, grouped);
+        hipLaunchKernelGGL(k_id_scatter, dim3(blocks_for(E)), dim3(TPB), 0, stream, dense, E, id_off, sc, hist,
+                           grouped);
         hipLaunchKernelGGL(k_id_rank, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, dense, id_off, grouped, key_b,
                            val_b, sc);
     } else {
@@ -1032,8 +1055,15 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     HIP_OK(hipMemcpyAsync(&totals, incl + (E - 1), 8, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
+    if (hsc.error == 3) return "positions must be strictly increasing within a chromosome";
+    if (hsc.id_exceeded) {
+        pk.id_space_hint = 0;
+        *retry = kRetrySameScheme;
+        return std::string();
+    }
+    pk.id_space_hint = counting ? std::max<uint64_t>(hsc.id_space, 1) : 0;
     if (hsc.regroup) {
-        *retry = true;
+        *retry = kRetryRadix;
         return std::string();
     }
     if (hsc.need_host) {
@@ -1166,7 +1196,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     if (hsc.error == 1) return "group id outside group_id_to_pos";
     if (hsc.error == 2) return "group_id_to_pos maps outside the matrix";
     if (hsc.regroup) {
-        *retry = true;
+        *retry = kRetryRadix;
         return std::string();
     }
     pk.pair_bound = hsc.pair_bound;
@@ -1200,12 +1230,19 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     }
     bool force_radix = false;
     if (const char *env = std::getenv("SECEDO_PACK_GROUPING")) force_radix = std::string(env) == "radix";
-    bool retry = false;
-    std::string err = pack_attempt(in, num_cells, mfl, num_threads, block_cells, geometry, allow_count_tile,
-                                   force_radix, stream, out, need_host, &retry);
-    if (err.empty() && retry)
-        err = pack_attempt(in, num_cells, mfl, num_threads, block_cells, geometry, allow_count_tile, true, stream,
-                           out, need_host, &retry);
+    // an attempt can ask to be repeated: with the radix sorts (a group too long for the counting scheme),
+    // or as it was but without assuming the previous call's sizes
+    int retry = kNoRetry;
+    bool no_assumptions = false;
+    std::string err;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        err = pack_attempt(in, num_cells, mfl, num_threads, block_cells, geometry, allow_count_tile, force_radix,
+                           no_assumptions, stream, out, need_host, &retry);
+        if (!err.empty() || retry == kNoRetry) break;
+        if (retry == kRetryRadix) force_radix = true;
+        if (retry == kRetrySameScheme) no_assumptions = true;
+    }
+    if (err.empty() && retry != kNoRetry) *need_host = true;  // cannot happen: three attempts cover both requests
     return err;
 }
 

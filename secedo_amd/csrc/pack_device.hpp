@@ -50,6 +50,7 @@ struct DevicePacked {
     bool stage_masks = false;
     bool count_tile = false;
     uint32_t cap_entries = 0, cap_loci = 0;
+    uint64_t id_space_hint = 0;  // size of the read-id space of the previous call (0: unknown): saves a read-back
     // side stream for the branch of the pipeline nothing else waits for until the final gather
     // (completed counts + flush chain); created on first use
     hipStream_t side = nullptr;

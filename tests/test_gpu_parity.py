@@ -184,6 +184,34 @@ def test_ragged_and_degenerate_inputs_match_the_oracle():
             assert counts_ref[1] == 0 and not got.any(), name
 
 
+def test_one_handle_many_pileups():
+    """A handle that packs again assumes the previous call's read-id space instead of waiting for a
+    read-back; a pileup with a larger id space voids that attempt and repeats it. Growing, shrinking
+    and sparse id spaces on one handle, each against a fresh handle."""
+    def pile(seed, n_ids_scale):
+        p = random_pileup(seed, 90, 2, 300, 14, 250)
+        return FlatPileup(p.chr_locus_off, p.locus_pos, p.locus_entry_off,
+                          (p.read_ids.astype(np.uint64) * n_ids_scale).astype(np.uint32), p.id_base)
+
+    pileups = [pile(1, 1), pile(2, 3), pile(3, 1), pile(4, 1000), pile(5, 2), pile(1, 1)]
+    fresh = []
+    for p in pileups:
+        with secedo_amd.SimilarityMatrixPlan(0) as plan:
+            plan.prepare(p, 90, 1000, None, 4)
+            acc = plan.new_acc()
+            plan.accumulate(acc, 0.01, 0.5, 0.01)
+            fresh.append((plan.last_counts(), plan.finalize_raw(acc).clone()))
+    import torch
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        for p, (counts, mat) in zip(pileups, fresh):
+            plan.prepare(p, 90, 1000, None, 4)
+            assert plan.used_device_packing
+            acc = plan.new_acc()
+            plan.accumulate(acc, 0.01, 0.5, 0.01)
+            assert plan.last_counts() == counts
+            assert torch.equal(plan.finalize_raw(acc), mat)
+
+
 def test_cpp_host_without_torch(tmp_path):
     """Pure C++ host through include/secedo_simmat.hpp (system HIP runtime, no Python in the process),
     fed with the reference's binary pileup record format; must equal the Python-driven result."""
