@@ -269,9 +269,9 @@ __global__ void k_check_positions(Raw in, Scalars *sc) {
 struct HeadKeepOp {
     const unsigned long long *skey;
     const uint32_t *keep;
-    const uint32_t *split;  // 1 where a flush re-opens the id as a new read (k_split_update)
+    const uint32_t *split;  // 1 where a flush re-opens the id as a new read (k_split_update); null: nowhere
     __device__ __forceinline__ unsigned long long operator()(uint32_t s) const {
-        const unsigned long long head = (s == 0 || skey[s] != skey[s - 1] || split[s]) ? 1ull : 0ull;
+        const unsigned long long head = (s == 0 || skey[s] != skey[s - 1] || (split && split[s])) ? 1ull : 0ull;
         return head | ((unsigned long long)keep[s] << 32);
     }
 };
@@ -287,7 +287,7 @@ __global__ void k_dup_mark(Raw in, const unsigned long long *skey, const uint32_
         const uint32_t e = sval[s];
         const uint32_t l = entry_locus[e];
         const bool same_read = s > 0 && skey[s] == skey[s - 1];  // same id: a split starts at a new locus
-        mark[e] = (same_read && !split[s]) ? 0u : 1u;
+        mark[e] = (same_read && !(split && split[s])) ? 0u : 1u;
         if (s == 0) mark[n] = 0u;
         if (same_read && entry_locus[sval[s - 1]] == l) continue;  // not a group head
         uint32_t stored = s;  // position of the stored entry of this (read, locus)
@@ -995,8 +995,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *arank = mark + (E + 1);
     uint32_t *run_start = S[RUNS].as<uint32_t>();
     uint32_t *run_rank = run_start + E + 1, *starts_by_rank = run_rank + E;
-    uint32_t *split = S[TMP].as<uint32_t>();  // free until k_keys2 writes the read index per kept entry there
-    HIP_OK(hipMemsetAsync(split, 0, (size_t)E * 4, stream));
+    // cuts of reads that outlive max_fragment_length: none on the first build (null), later the flags of
+    // k_split_update in TMP, which is free until k_keys2 writes the read index per kept entry there
+    uint32_t *split = nullptr;
     HIP_OK(pk.read_off.ensure(((size_t)E + 1) * 4));
     HIP_OK(pk.read_locus.ensure((size_t)E * 4));
     HIP_OK(pk.read_base.ensure(E));
@@ -1075,6 +1076,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         // the id re-opens as a new read. Cut at the flush loci, rebuild, repeat until the cuts are stable
         // (they move forward with the flushes they cause: a few rounds).
         bool stable = false;
+        split = S[TMP].as<uint32_t>();
+        HIP_OK(hipMemsetAsync(split, 0, (size_t)E * 4, stream));
         for (int round = 0; round < kMaxSplitRounds && !stable; ++round) {
             HIP_OK(hipStreamWaitEvent(stream, pk.ev_join, 0));  // the chain of the previous build
             HIP_OK(hipMemsetAsync(&sc->split_changed, 0, 4, stream));
