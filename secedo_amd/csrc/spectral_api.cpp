@@ -144,7 +144,7 @@ struct Solver {
         SP_TRY(root.alloc((size_t)n * 8));
         SP_TRY(Q.alloc((kCycleBlocks + 1) * blk_stride * 8));
         SP_TRY(W.alloc(blk_stride * 8));
-        SP_TRY(Z.alloc(((size_t)pad16(n) + 16) * BW * 8));
+        SP_TRY(Z.alloc(((size_t)pad16(n) + 64) * BW * 8));
         SP_TRY(P.alloc((size_t)product_segments(n, n_rows) * pad16(n) * BW * 8));
         SP_TRY(Gp.alloc((size_t)gram_chunks(n) * (kCycleBlocks + 1) * BW * BW * 8));
         SP_TRY(G.alloc((size_t)(kCycleBlocks + 1) * BW * BW * 8));

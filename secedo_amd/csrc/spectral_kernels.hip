@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_init_block(uint32_t n, const double *ro
     }
 }
 
-// Z[j][c] = s[j] * X[j][c]; rows from n on (padding + 16 rows of slack) are zero
+// Z[j][c] = s[j] * X[j][c]; rows from n on (padding + 64 rows of slack) are zero
 __global__ __launch_bounds__(256) void k_scale_rows(uint32_t n, uint32_t n_pad, const double *s, const double *X,
                                                    double *Z) {
     const size_t total = (size_t)n_pad * BW;
@@ -81,43 +81,85 @@ __global__ __launch_bounds__(256) void k_scale_rows(uint32_t n, uint32_t n_pad, 
 }
 
 // P[seg][i][c] = sum over the segment's rows j of Z[j][c] * A[j][i], for the rows this rank holds
-// (A_rows = rows [row_begin, row_begin + n_rows) of the matrix). One wave owns 16 columns i and both
-// 16-wide halves of c: per step of 4 rows, one 8-byte load of A per lane feeds two MFMAs.
+// (A_rows = rows [row_begin, row_begin + n_rows) of the matrix).
+// A workgroup of four waves covers 128 columns i; a wave owns 32 of them as two interleaved MFMA
+// tiles (even and odd columns), so one 16-byte load of A per lane and step of 4 rows feeds four MFMAs
+// (2 column tiles x the two 16-wide halves of c). The rows of Z a step needs are the same for the four
+// waves: they are staged in LDS 64 rows at a time, double buffered (one barrier per 64 rows).
+// (Holding the next 64 rows' matrix values in registers as well costs occupancy and measured slower.)
+constexpr uint32_t kProdRows = 64;  // rows of Z per LDS stage; segments are multiples of it
 __global__ __launch_bounds__(256) void k_product_partial(const double *A_rows, uint32_t n, uint32_t row_begin,
                                                         uint32_t n_rows, const double *Z, uint32_t seg_rows,
                                                         uint32_t n_pad16, double *P) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t i0 = (blockIdx.x * 4u + wave) * 16u;
-    if (i0 >= n_pad16) return;
+    __shared__ __attribute__((aligned(16))) double Zs[2][kProdRows][BW];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t i0 = (blockIdx.x * 4u + wave) * 32u;
     const uint32_t col = lane & 15u, kq = lane >> 4;
-    const uint32_t ic = min(i0 + col, n - 1u);  // columns past n are computed from column n-1 and never read
-    // segments are multiples of 16 local rows: four steps of 4 rows per trip, the 12 loads of a trip in
-    // flight together; local rows past n_rows contribute a zero A
-    const uint32_t rows_pad = (n_rows + 15u) / 16u * 16u;
+    const uint32_t ie = i0 + 2u * col;  // the even column of this lane; ie + 1 the odd one
+    const bool pair_ok = ie + 1u < n && (n & 1u) == 0u;  // both inside, 16-byte aligned in every row: one load
+    const uint32_t ice = min(ie, n - 1u), ico = min(ie + 1u, n - 1u);  // columns past n: computed, never read
+    const uint32_t rows_pad = (n_rows + kProdRows - 1u) / kProdRows * kProdRows;
     const uint32_t j_begin = blockIdx.y * seg_rows, j_end = min(rows_pad, j_begin + seg_rows);
-    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    for (uint32_t j0 = j_begin; j0 < j_end; j0 += 16u) {
-        double a[4], z0[4], z1[4];
+    double4_t acc_e0 = {0.0, 0.0, 0.0, 0.0}, acc_e1 = acc_e0, acc_o0 = acc_e0, acc_o1 = acc_e0;
+    // stage: 64 rows x 32 doubles = 16 KiB, 64 bytes per thread (Z has kProdRows zero rows of slack)
+    auto stage = [&](uint32_t buf, uint32_t j0) {
+        const double2 *src = reinterpret_cast<const double2 *>(Z + (size_t)(row_begin + j0) * BW) + tid * 4u;
+        double2 *dst = reinterpret_cast<double2 *>(&Zs[buf][0][0]) + tid * 4u;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t jl = j0 + 4u * u + kq;
-            const double av = A_rows[(size_t)min(jl, n_rows - 1u) * n + ic];
-            a[u] = jl < n_rows ? av : 0.0;
-            z0[u] = Z[(size_t)(row_begin + jl) * BW + col];  // Z has 16 zero rows of slack past pad16(n)
-            z1[u] = Z[(size_t)(row_begin + jl) * BW + 16u + col];
+        for (int u = 0; u < 4; ++u) dst[u] = src[u];
+    };
+    if (j_begin < j_end) stage(0, j_begin);
+    __syncthreads();
+    uint32_t buf = 0;
+    for (uint32_t j0 = j_begin; j0 < j_end; j0 += kProdRows, buf ^= 1u) {
+        if (j0 + kProdRows < j_end) stage(buf ^ 1u, j0 + kProdRows);
+        if (i0 < n_pad16) {
+#pragma unroll 2
+            for (uint32_t q = 0; q < kProdRows; q += 16u) {
+                double ae[4], ao[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t jl = j0 + q + 4u * u + kq;
+                    const double *row = A_rows + (size_t)min(jl, n_rows - 1u) * n;
+                    if (pair_ok) {
+                        const double2 v = *reinterpret_cast<const double2 *>(row + ie);
+                        ae[u] = v.x;
+                        ao[u] = v.y;
+                    } else {
+                        ae[u] = row[ice];
+                        ao[u] = row[ico];
+                    }
+                    if (jl >= n_rows) ae[u] = ao[u] = 0.0;  // local rows past the block contribute nothing
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double z0 = Zs[buf][q + 4u * u + kq][col], z1 = Zs[buf][q + 4u * u + kq][16u + col];
+                    acc_e0 = __builtin_amdgcn_mfma_f64_16x16x4f64(z0, ae[u], acc_e0, 0, 0, 0);
+                    acc_e1 = __builtin_amdgcn_mfma_f64_16x16x4f64(z1, ae[u], acc_e1, 0, 0, 0);
+                    acc_o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(z0, ao[u], acc_o0, 0, 0, 0);
+                    acc_o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(z1, ao[u], acc_o1, 0, 0, 0);
+                }
+            }
         }
+        __syncthreads();  // the next stage is complete, this one free to be overwritten
+    }
+    if (i0 >= n_pad16) return;
+    // C/D layout of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg
+    if (ie < n_pad16) {
+        double *p = P + ((size_t)blockIdx.y * n_pad16 + ie) * BW;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(z0[u], a[u], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(z1[u], a[u], acc1, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) {
+            p[kq + 4u * r] = acc_e0[r];
+            p[16u + kq + 4u * r] = acc_e1[r];
         }
     }
-    // C/D layout of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg
-    double *p = P + ((size_t)blockIdx.y * n_pad16 + i0 + col) * BW;
+    if (ie + 1u < n_pad16) {
+        double *p = P + ((size_t)blockIdx.y * n_pad16 + ie + 1u) * BW;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        p[kq + 4u * r] = acc0[r];
-        p[16u + kq + 4u * r] = acc1[r];
+        for (int r = 0; r < 4; ++r) {
+            p[kq + 4u * r] = acc_o0[r];
+            p[16u + kq + 4u * r] = acc_o1[r];
+        }
     }
 }
 
@@ -284,19 +326,19 @@ hipError_t init_block(uint32_t n, const double *root, double *X, hipStream_t str
 
 uint32_t product_segments(uint32_t n, uint32_t n_rows) {
     // enough waves to fill 256 CUs: a workgroup column covers 64 matrix columns
-    const uint32_t cols = (pad16(n) + 63u) / 64u;
+    const uint32_t cols = (pad16(n) + 127u) / 128u;
     const uint32_t want = (2048u + cols - 1u) / cols;
-    const uint32_t most = std::max(1u, pad16(n_rows) / 64u);  // at least 64 rows per segment
+    const uint32_t most = std::max(1u, (n_rows + 127u) / 128u);  // at least 128 rows per segment
     return std::max(1u, std::min({want, 64u, most}));
 }
 
 hipError_t product_partial(const double *A_rows, uint32_t n, uint32_t row_begin, uint32_t n_rows, const double *s,
                            const double *X, double *Z, double *P, double *Ypart, hipStream_t stream) {
-    const uint32_t nz = pad16(n) + 16u, n16 = pad16(n), n_seg = product_segments(n, n_rows);
-    const uint32_t seg_rows = ((pad16(n_rows) + n_seg - 1u) / n_seg + 15u) / 16u * 16u;
+    const uint32_t nz = pad16(n) + kProdRows, n16 = pad16(n), n_seg = product_segments(n, n_rows);
+    const uint32_t seg_rows = ((n_rows + n_seg - 1u) / n_seg + kProdRows - 1u) / kProdRows * kProdRows;
     hipLaunchKernelGGL(k_scale_rows, dim3(grid_for((size_t)nz * BW)), dim3(256), 0, stream, n, nz, s, X, Z);
     if (n_rows)
-        hipLaunchKernelGGL(k_product_partial, dim3((n16 + 63u) / 64u, n_seg), dim3(256), 0, stream, A_rows, n, row_begin,
+        hipLaunchKernelGGL(k_product_partial, dim3((n16 + 127u) / 128u, n_seg), dim3(256), 0, stream, A_rows, n, row_begin,
                            n_rows, Z, seg_rows, n16, P);
     hipLaunchKernelGGL(k_product_reduce, dim3(grid_for((size_t)n * BW)), dim3(256), 0, stream, n, n_rows ? n_seg : 0u,
                        n16, P, Ypart);
