@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace secedo {
 namespace spectral {
@@ -96,7 +97,6 @@ __global__ __launch_bounds__(256) void k_product_partial(const double *A_rows, u
     const uint32_t i0 = (blockIdx.x * 4u + wave) * 32u;
     const uint32_t col = lane & 15u, kq = lane >> 4;
     const uint32_t ie = i0 + 2u * col;  // the even column of this lane; ie + 1 the odd one
-    const bool pair_ok = ie + 1u < n && (n & 1u) == 0u;  // both inside, 16-byte aligned in every row: one load
     const uint32_t ice = min(ie, n - 1u), ico = min(ie + 1u, n - 1u);  // columns past n: computed, never read
     const uint32_t rows_pad = (n_rows + kProdRows - 1u) / kProdRows * kProdRows;
     const uint32_t j_begin = blockIdx.y * seg_rows, j_end = min(rows_pad, j_begin + seg_rows);
@@ -108,38 +108,47 @@ __global__ __launch_bounds__(256) void k_product_partial(const double *A_rows, u
 #pragma unroll
         for (int u = 0; u < 4; ++u) dst[u] = src[u];
     };
+    // 64 rows against the staged Z. FAST: the wave's 32 columns and the 64 rows all lie inside the block
+    // and the row pitch keeps 16-byte alignment -- straight-line code, the four loads of a group of 16
+    // rows in flight together. Otherwise every access is clamped and masked (edges only).
+    auto rows64 = [&](uint32_t j0, uint32_t buf, auto fast_c) {
+        constexpr bool FAST = decltype(fast_c)::value;
+#pragma unroll 2
+        for (uint32_t q = 0; q < kProdRows; q += 16u) {
+            double ae[4], ao[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t jl = j0 + q + 4u * u + kq;
+                if (FAST) {
+                    const double2 v = *reinterpret_cast<const double2 *>(A_rows + (size_t)jl * n + ie);
+                    ae[u] = v.x;
+                    ao[u] = v.y;
+                } else {
+                    const double *row = A_rows + (size_t)min(jl, n_rows - 1u) * n;
+                    const double ve = row[ice], vo = row[ico];
+                    ae[u] = jl < n_rows ? ve : 0.0;  // local rows past the block contribute nothing
+                    ao[u] = jl < n_rows ? vo : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double z0 = Zs[buf][q + 4u * u + kq][col], z1 = Zs[buf][q + 4u * u + kq][16u + col];
+                acc_e0 = __builtin_amdgcn_mfma_f64_16x16x4f64(z0, ae[u], acc_e0, 0, 0, 0);
+                acc_e1 = __builtin_amdgcn_mfma_f64_16x16x4f64(z1, ae[u], acc_e1, 0, 0, 0);
+                acc_o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(z0, ao[u], acc_o0, 0, 0, 0);
+                acc_o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(z1, ao[u], acc_o1, 0, 0, 0);
+            }
+        }
+    };
+    const bool cols_inside = i0 + 32u <= n && (n & 1u) == 0u;  // wave-uniform
     if (j_begin < j_end) stage(0, j_begin);
     __syncthreads();
     uint32_t buf = 0;
     for (uint32_t j0 = j_begin; j0 < j_end; j0 += kProdRows, buf ^= 1u) {
         if (j0 + kProdRows < j_end) stage(buf ^ 1u, j0 + kProdRows);
         if (i0 < n_pad16) {
-#pragma unroll 2
-            for (uint32_t q = 0; q < kProdRows; q += 16u) {
-                double ae[4], ao[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t jl = j0 + q + 4u * u + kq;
-                    const double *row = A_rows + (size_t)min(jl, n_rows - 1u) * n;
-                    if (pair_ok) {
-                        const double2 v = *reinterpret_cast<const double2 *>(row + ie);
-                        ae[u] = v.x;
-                        ao[u] = v.y;
-                    } else {
-                        ae[u] = row[ice];
-                        ao[u] = row[ico];
-                    }
-                    if (jl >= n_rows) ae[u] = ao[u] = 0.0;  // local rows past the block contribute nothing
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double z0 = Zs[buf][q + 4u * u + kq][col], z1 = Zs[buf][q + 4u * u + kq][16u + col];
-                    acc_e0 = __builtin_amdgcn_mfma_f64_16x16x4f64(z0, ae[u], acc_e0, 0, 0, 0);
-                    acc_e1 = __builtin_amdgcn_mfma_f64_16x16x4f64(z1, ae[u], acc_e1, 0, 0, 0);
-                    acc_o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(z0, ao[u], acc_o0, 0, 0, 0);
-                    acc_o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(z1, ao[u], acc_o1, 0, 0, 0);
-                }
-            }
+            if (cols_inside && j0 + kProdRows <= n_rows) rows64(j0, buf, std::true_type{});
+            else rows64(j0, buf, std::false_type{});
         }
         __syncthreads();  // the next stage is complete, this one free to be overwritten
     }
