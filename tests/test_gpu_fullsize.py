@@ -90,3 +90,30 @@ def test_c5_full_size_properties():
             del m
     assert counts["device"] == counts["host"]
     assert counts["device"][0] == 10517284027  # the updates the bench line reports for C5
+
+
+def test_c2_matrix_through_the_spectral_step_and_em():
+    """The consumers at C2 size: similarity matrix of the two-clone synthetic pileup (resident in HBM) ->
+    smallest eigenpairs against LAPACK -> the second eigenvector splits the clones (the reference's
+    FIEDLER rule) -> EM refinement started from that split keeps it and agrees with the oracle."""
+    from oracle import spectral_oracle as so
+    n = CONFIGS["C2"][0]
+    p = synth_config("C2")
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        plan.prepare(p, n, 1000, None, 8)
+        acc = plan.new_acc()
+        plan.accumulate(acc, 0.01, 0.5, 0.01)
+        sim = plan.finalize(acc, "ADD_MIN").clone()
+    vals, vecs, info = secedo_amd.smallest_eigenpairs(sim, 20, 7)
+    assert info["converged"]
+    w, v = so.eig_sym(so.laplacian_fast(sim.cpu().numpy()))
+    assert np.max(np.abs(vals - w[:20])) <= 1e-8
+    fiedler = vecs[:, 1].cpu().numpy()
+    assert abs(abs(float(fiedler @ v[:, 1])) - 1.0) <= 1e-8  # separated eigenvalue: same vector up to sign
+    side = fiedler >= 0
+    assert np.all(side[: n // 2] == side[0]) and np.all(side[n // 2:] == side[-1]) and side[0] != side[-1]
+    prob = np.where(side == side[-1], 0.9, 0.1)  # cluster b = the clone of the upper half
+    ref, it_ref = ob.oracle_em(p, np.arange(n, dtype=np.uint32), 1e-3, prob)
+    got, it = secedo_amd.expectation_maximization(p, np.arange(n, dtype=np.uint32), 8, 1e-3, prob)
+    assert it == it_ref and np.max(np.abs(got - ref)) <= 1e-9
+    assert np.all(got[: n // 2] < 0.05) and np.all(got[n // 2:] > 0.95)
