@@ -142,6 +142,25 @@ int secedo_simmat_accumulate(secedo_simmat_t *handle, double mutation_rate, doub
                              int64_t *d_acc, void *stream);
 int secedo_simmat_finalize(secedo_simmat_t *handle, int normalization, const int64_t *d_acc,
                            double *d_out, void *stream);
+/* A rank that keeps its row block of the matrix without ever receiving other ranks' tiles (BASELINE
+ * config 5, no all-gather) accumulates every tile that touches its rows itself -- each off-diagonal
+ * tile is then computed by two ranks, and nothing but one scalar is exchanged:
+ *   tiles_of_rows       the tiles (global indices, ascending) with their row block or their column
+ *                       block inside [row_begin, row_end); tile_ids == NULL only counts
+ *   accumulate_list     accumulate() for a list of tiles instead of a range
+ *   max_of_tiles        max(0, max D) over the listed tiles, to be max-reduced over the ranks
+ *                       (synchronises `stream`)
+ *   finalize_rows_max   finalize_rows with that maximum instead of the one of the whole accumulator */
+int secedo_simmat_tiles_of_rows(const secedo_simmat_t *handle, uint32_t row_begin, uint32_t row_end,
+                                uint32_t *tile_ids, uint32_t *n_tile_ids);
+int secedo_simmat_accumulate_list(secedo_simmat_t *handle, double mutation_rate, double homozygous_rate,
+                                  double seq_error_rate, const uint32_t *tile_ids, uint32_t n_tile_ids,
+                                  int64_t *d_acc, void *stream);
+int secedo_simmat_max_of_tiles(secedo_simmat_t *handle, const int64_t *d_acc, const uint32_t *tile_ids,
+                               uint32_t n_tile_ids, double *max_value, void *stream);
+int secedo_simmat_finalize_rows_max(secedo_simmat_t *handle, int normalization, const int64_t *d_acc,
+                                    uint32_t row_begin, uint32_t row_end, double max_value, double *d_out_rows,
+                                    void *stream);
 /* finalize for a row block only: d_out_rows[(row_end - row_begin) * num_cells] receives rows
  * [row_begin, row_end) of the normalised matrix (the maximum that ADD_MIN / SCALE_MAX_1 need is still
  * taken over the whole accumulator). For ranks that keep the matrix sharded by rows (BASELINE config

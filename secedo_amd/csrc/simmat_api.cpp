@@ -89,6 +89,9 @@ struct secedo_simmat {
     DevBuf tile_row, tile_col, lut, counters, max_bits, slow_args, slab, plan_wg_tile, plan_wg_begin;
     uint32_t plan_tile_begin = 0xFFFFFFFFu, plan_tile_end = 0, plan_ranges = 0, plan_blocks = 0, plan_workgroups = 0;
     DevBuf own_acc, own_out;  // used by the one-shot entry point only
+    DevBuf tile_ids;          // tile list of accumulate_list / max_of_tiles
+    std::vector<uint16_t> host_tile_row, host_tile_col;
+    uint64_t plan_list_hash = 0;  // 0: the cached workgroup plan belongs to a contiguous tile range
 
     // LLR table of the last accumulate()
     bool have_model = false, have_lut = false, have_slow = false;
@@ -428,6 +431,8 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
         }
         HIP_TRY(h->tile_row.upload(trow));
         HIP_TRY(h->tile_col.upload(tcol));
+        h->host_tile_row = trow;
+        h->host_tile_col = tcol;
     }
     HIP_TRY(h->counters.ensure(16 * sizeof(unsigned long long)));
     HIP_TRY(h->max_bits.ensure(sizeof(unsigned long long)));
@@ -455,12 +460,24 @@ int secedo_simmat_zero_acc(secedo_simmat_t *h, int64_t *d_acc, void *stream) {
     return SECEDO_OK;
 }
 
-int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double theta,
-                             uint32_t tile_begin, uint32_t tile_end, int64_t *d_acc, void *stream) {
+// tiles [tile_begin, tile_end) when list == nullptr, else the n_list tiles of `list` (global indices)
+static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double theta, uint32_t tile_begin,
+                           uint32_t tile_end, const uint32_t *list, uint32_t n_list, int64_t *d_acc, void *stream) {
     if (!h || !d_acc) return fail(SECEDO_E_INVALID_ARG, "null argument");
     if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
-    if (tile_begin > tile_end || tile_end > h->num_tiles)
+    if (!list && (tile_begin > tile_end || tile_end > h->num_tiles))
         return fail(SECEDO_E_INVALID_ARG, "tile range outside [0, num_tiles]");
+    uint64_t list_hash = 0;
+    if (list) {
+        list_hash = 0xcbf29ce484222325ull;  // FNV-1a over the ids: key of the cached workgroup plan
+        for (uint32_t k = 0; k < n_list; ++k) {
+            if (list[k] >= h->num_tiles) return fail(SECEDO_E_INVALID_ARG, "tile id outside [0, num_tiles)");
+            list_hash = (list_hash ^ list[k]) * 0x100000001b3ull;
+        }
+        list_hash |= 1ull;
+        tile_begin = 0;
+        tile_end = n_list;
+    }
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
 
@@ -516,11 +533,19 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     a.tile_row = h->tile_row.as<uint16_t>();
     a.tile_col = h->tile_col.as<uint16_t>();
     a.tile_begin = tile_begin;
+    a.tile_ids = nullptr;
+    if (list) {
+        if (h->plan_list_hash != list_hash) {
+            HIP_TRY(h->tile_ids.ensure((size_t)std::max(n_list, 1u) * 4));
+            if (n_list) HIP_TRY(hipMemcpy(h->tile_ids.p, list, (size_t)n_list * 4, hipMemcpyHostToDevice));
+        }
+        a.tile_ids = h->tile_ids.as<uint32_t>();
+    }
     // Workgroups: every tile is cut into chunks of locus ranges so that the launch fills the 256 CUs
     // in whole rounds of about equally loaded workgroups (a diagonal tile holds half the pairs of an
     // off-diagonal one and gets half the chunks). Cached per tile range.
     if (h->plan_tile_begin != tile_begin || h->plan_tile_end != tile_end || h->plan_ranges != h->pk.num_ranges
-        || h->plan_blocks != h->pk.num_blocks) {
+        || h->plan_blocks != h->pk.num_blocks || h->plan_list_hash != list_hash) {
         // workgroups resident per CU (LDS-limited): 1 (128-cell tiles), 2 (64-cell tiles with staged masks,
         // 512 threads), 4 (the other 64-cell variants)
         const uint32_t wgs_per_round = h->pk.block_cells == 128 ? 256u : h->pk.stage_masks ? 512u : 1024u;
@@ -528,17 +553,10 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
         if (const char *env = std::getenv("SECEDO_ROUNDS")) rounds = std::max(1, std::atoi(env));
         std::vector<uint32_t> weight(n_tiles);
         uint64_t total_weight = 0;
-        {
-            // tile index -> (row, col) of the upper triangle, row-major
-            uint32_t t = 0;
-            for (uint32_t i = 0; i < h->pk.num_blocks; ++i) {
-                for (uint32_t j = i; j < h->pk.num_blocks; ++j, ++t) {
-                    if (t >= tile_begin && t < tile_end) {
-                        weight[t - tile_begin] = (i == j) ? 1u : 2u;
-                        total_weight += weight[t - tile_begin];
-                    }
-                }
-            }
+        for (uint32_t k = 0; k < n_tiles; ++k) {
+            const uint32_t t = list ? list[k] : tile_begin + k;
+            weight[k] = (h->host_tile_row[t] == h->host_tile_col[t]) ? 1u : 2u;
+            total_weight += weight[k];
         }
         const uint64_t slots = static_cast<uint64_t>(wgs_per_round) * rounds;
         std::vector<uint32_t> wg_begin(n_tiles + 1, 0);
@@ -558,6 +576,7 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
         h->plan_workgroups = wg_begin[n_tiles];
         h->plan_tile_begin = tile_begin;
         h->plan_tile_end = tile_end;
+        h->plan_list_hash = list_hash;
         h->plan_ranges = h->pk.num_ranges;
         h->plan_blocks = h->pk.num_blocks;
     }
@@ -581,6 +600,81 @@ int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double t
     HIP_TRY(secedo::launch_accumulate(a, h->pk.block_cells, h->pk.stage_masks, count_tile, n_tiles, s));
     HIP_TRY(hipEventRecord(h->ev_end, s));
     h->timed = true;
+    return SECEDO_OK;
+}
+
+int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double theta, uint32_t tile_begin,
+                             uint32_t tile_end, int64_t *d_acc, void *stream) {
+    return accumulate_impl(h, eps, hr, theta, tile_begin, tile_end, nullptr, 0, d_acc, stream);
+}
+
+int secedo_simmat_accumulate_list(secedo_simmat_t *h, double eps, double hr, double theta, const uint32_t *tile_ids,
+                                  uint32_t n_tile_ids, int64_t *d_acc, void *stream) {
+    if (!tile_ids && n_tile_ids) return fail(SECEDO_E_INVALID_ARG, "tile_ids is null");
+    static const uint32_t none = 0;
+    return accumulate_impl(h, eps, hr, theta, 0, 0, tile_ids ? tile_ids : &none, n_tile_ids, d_acc, stream);
+}
+
+int secedo_simmat_tiles_of_rows(const secedo_simmat_t *h, uint32_t row_begin, uint32_t row_end, uint32_t *tile_ids,
+                                uint32_t *n_tile_ids) {
+    if (!h || !n_tile_ids) return fail(SECEDO_E_INVALID_ARG, "null argument");
+    if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
+    if (row_begin > row_end || row_end > h->pk.num_cells) return fail(SECEDO_E_INVALID_ARG, "row range outside the matrix");
+    uint32_t n = 0;
+    if (row_begin < row_end) {
+        const uint32_t B = h->pk.block_cells, b0 = row_begin / B, b1 = (row_end - 1) / B;
+        for (uint32_t t = 0; t < h->num_tiles; ++t) {
+            const uint32_t I = h->host_tile_row[t], J = h->host_tile_col[t];
+            if ((I >= b0 && I <= b1) || (J >= b0 && J <= b1)) {
+                if (tile_ids) tile_ids[n] = t;
+                ++n;
+            }
+        }
+    }
+    *n_tile_ids = n;
+    return SECEDO_OK;
+}
+
+int secedo_simmat_max_of_tiles(secedo_simmat_t *h, const int64_t *d_acc, const uint32_t *tile_ids, uint32_t n_tile_ids,
+                               double *max_value, void *stream) {
+    if (!h || !d_acc || !max_value || (!tile_ids && n_tile_ids)) return fail(SECEDO_E_INVALID_ARG, "null argument");
+    if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
+    if (!h->have_lut) return fail(SECEDO_E_STATE, "accumulate was not called");
+    for (uint32_t k = 0; k < n_tile_ids; ++k)
+        if (tile_ids[k] >= h->num_tiles) return fail(SECEDO_E_INVALID_ARG, "tile id outside [0, num_tiles)");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DevBuf ids;
+    HIP_TRY(ids.ensure((size_t)std::max(n_tile_ids, 1u) * 4));
+    if (n_tile_ids) HIP_TRY(hipMemcpyAsync(ids.p, tile_ids, (size_t)n_tile_ids * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(secedo::launch_tile_max(d_acc, h->tile_row.as<uint16_t>(), h->tile_col.as<uint16_t>(), ids.as<uint32_t>(),
+                                    n_tile_ids, h->pk.block_cells, h->scale_log2, h->max_bits.as<unsigned long long>(),
+                                    s));
+    unsigned long long bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, h->max_bits.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(max_value, &bits, 8);
+    return SECEDO_OK;
+}
+
+int secedo_simmat_finalize_rows_max(secedo_simmat_t *h, int normalization, const int64_t *d_acc, uint32_t row_begin,
+                                    uint32_t row_end, double max_value, double *d_out_rows, void *stream) {
+    if (normalization < 0 || normalization > 2)
+        return fail(SECEDO_E_INVALID_NORMALIZATION, "Invalid normalization: " + std::to_string(normalization));
+    if (!h || !d_acc || !d_out_rows) return fail(SECEDO_E_INVALID_ARG, "null argument");
+    if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
+    if (!h->have_lut) return fail(SECEDO_E_STATE, "accumulate was not called");
+    if (row_begin > row_end || row_end > h->pk.num_cells) return fail(SECEDO_E_INVALID_ARG, "row range outside the matrix");
+    if (!(max_value >= 0.0)) return fail(SECEDO_E_INVALID_ARG, "max_value must be the (non-negative) maximum of D");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned long long bits;
+    std::memcpy(&bits, &max_value, 8);
+    HIP_TRY(hipMemcpyAsync(h->max_bits.p, &bits, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // `bits` lives on this stack frame
+    HIP_TRY(secedo::launch_finalize(d_acc, h->tile_row.as<uint16_t>(), h->tile_col.as<uint16_t>(), h->num_tiles,
+                                    h->pk.num_cells, h->pk.block_cells, h->scale_log2, normalization,
+                                    h->max_bits.as<unsigned long long>(), row_begin, row_end, d_out_rows, s, true));
     return SECEDO_OK;
 }
 

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     // workgroup -> (tile, chunk of the tile's locus ranges); diagonal tiles hold half the pairs and
     // get half the chunks, so that all workgroups of a launch carry about the same work
     const uint32_t t_local = a.wg_tile[blockIdx.x];
-    const uint32_t t = a.tile_begin + t_local;
+    const uint32_t t = a.tile_ids ? a.tile_ids[t_local] : a.tile_begin + t_local;
     const uint32_t chunk = blockIdx.x - a.tile_wg_begin[t_local];
     const uint32_t n_chunks_t = a.tile_wg_begin[t_local + 1] - a.tile_wg_begin[t_local];
     const uint32_t chunk_ranges = (a.num_ranges + n_chunks_t - 1) / n_chunks_t;
@@ -596,7 +596,8 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
 // single-locus ratios: exact integer arithmetic). One thread per cell pair of a tile.
 template <int B, bool COUNTS>
 __global__ __launch_bounds__(256) void reduce_slabs(const void *slab, const uint32_t *tile_wg_begin,
-                                                   uint32_t tile_begin, const long long *lut, long long *acc) {
+                                                   uint32_t tile_begin, const uint32_t *tile_ids,
+                                                   const long long *lut, long long *acc) {
     const uint32_t t_local = blockIdx.x / (B * B / 256);
     const uint32_t cell = (blockIdx.x % (B * B / 256)) * 256 + threadIdx.x;
     const uint32_t w0 = tile_wg_begin[t_local], w1 = tile_wg_begin[t_local + 1];
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(256) void reduce_slabs(const void *slab, const uint
         const long long *p = reinterpret_cast<const long long *>(slab) + cell;
         for (uint32_t w = w0; w < w1; ++w) sum += p[(size_t)w * B * B];
     }
-    if (sum) acc[(size_t)(tile_begin + t_local) * B * B + cell] += sum;
+    if (sum) acc[(size_t)(tile_ids ? tile_ids[t_local] : tile_begin + t_local) * B * B + cell] += sum;
 }
 
 // max over i < j of D[i][j], clamped at 0 (the diagonal is zero): bits of a non-negative double
@@ -623,13 +624,14 @@ __global__ __launch_bounds__(256) void reduce_slabs(const void *slab, const uint
 // accumulator linearly (cells beyond num_cells hold zero and do not move a maximum clamped at 0).
 template <int B>
 __global__ __launch_bounds__(256) void reduce_max(const long long *acc, const uint16_t *tile_row,
-                                                  const uint16_t *tile_col, uint32_t n_tiles, double scale,
-                                                  unsigned long long *out_bits) {
+                                                  const uint16_t *tile_col, const uint32_t *tile_ids,
+                                                  uint32_t n_tiles, double scale, unsigned long long *out_bits) {
     const size_t total = (size_t)n_tiles * B * B;
     long long best = 0;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const uint32_t t = (uint32_t)(idx / (B * B)), rc = (uint32_t)(idx % (B * B));
-        long long v = acc[idx];
+        const uint32_t rc = (uint32_t)(idx % (B * B));
+        const uint32_t t = tile_ids ? tile_ids[idx / (B * B)] : (uint32_t)(idx / (B * B));
+        long long v = acc[(size_t)t * B * B + rc];
         if (tile_row[t] == tile_col[t]) {  // a diagonal tile holds each pair in either orientation
             const uint32_t r = rc / B, c = rc % B;
             v = r < c ? v + acc[(size_t)t * B * B + c * B + r] : 0;
@@ -724,7 +726,7 @@ hipError_t launch_acc(const AccumulateArgs &args, uint32_t grid, hipStream_t str
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
     hipLaunchKernelGGL((reduce_slabs<B, COUNTS>), dim3(args.n_tiles * (B * B / 256)), dim3(256), 0, stream,
-                       args.slab, args.tile_wg_begin, args.tile_begin, args.lut,
+                       args.slab, args.tile_wg_begin, args.tile_begin, args.tile_ids, args.lut,
                        reinterpret_cast<long long *>(args.acc));
     return hipGetLastError();
 }
@@ -755,25 +757,37 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
     return launch_acc<64, 256, kCapJ64, kCapL64, 1024, false, false>(args, grid, stream);
 }
 
-hipError_t launch_finalize(const int64_t *acc, const uint16_t *tile_row, const uint16_t *tile_col, uint32_t n_tiles,
-                           uint32_t n, uint32_t block_cells, int scale_log2, int mode,
-                           unsigned long long *d_max_bits, uint32_t row_begin, uint32_t row_end, double *out,
-                           hipStream_t stream) {
+hipError_t launch_tile_max(const int64_t *acc, const uint16_t *tile_row, const uint16_t *tile_col,
+                           const uint32_t *tile_ids, uint32_t n_tiles, uint32_t block_cells, int scale_log2,
+                           unsigned long long *d_max_bits, hipStream_t stream) {
     const double scale = ldexp(1.0, -scale_log2);
+    hipError_t e = hipMemsetAsync(d_max_bits, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess || n_tiles == 0) return e;
     const size_t total = (size_t)n_tiles * block_cells * block_cells;
     const uint32_t grid = (uint32_t)std::min<size_t>((total + 255) / 256, 256 * 8);
     const long long *a = reinterpret_cast<const long long *>(acc);
+    if (block_cells == 128) {
+        hipLaunchKernelGGL((reduce_max<128>), dim3(grid), dim3(256), 0, stream, a, tile_row, tile_col, tile_ids, n_tiles,
+                           scale, d_max_bits);
+    } else {
+        hipLaunchKernelGGL((reduce_max<64>), dim3(grid), dim3(256), 0, stream, a, tile_row, tile_col, tile_ids, n_tiles,
+                           scale, d_max_bits);
+    }
+    return hipGetLastError();
+}
+
+// keep_max: d_max_bits already holds the maximum to normalise with (e.g. reduced over ranks)
+hipError_t launch_finalize(const int64_t *acc, const uint16_t *tile_row, const uint16_t *tile_col, uint32_t n_tiles,
+                           uint32_t n, uint32_t block_cells, int scale_log2, int mode,
+                           unsigned long long *d_max_bits, uint32_t row_begin, uint32_t row_end, double *out,
+                           hipStream_t stream, bool keep_max) {
+    const double scale = ldexp(1.0, -scale_log2);
+    const long long *a = reinterpret_cast<const long long *>(acc);
     if (n_tiles == 0) return hipSuccess;
-    if (mode == 0 || mode == 2) {
-        hipError_t e = hipMemsetAsync(d_max_bits, 0, sizeof(unsigned long long), stream);
+    if ((mode == 0 || mode == 2) && !keep_max) {
+        hipError_t e = launch_tile_max(acc, tile_row, tile_col, nullptr, n_tiles, block_cells, scale_log2, d_max_bits,
+                                       stream);
         if (e != hipSuccess) return e;
-        if (block_cells == 128) {
-            hipLaunchKernelGGL((reduce_max<128>), dim3(grid), dim3(256), 0, stream, a, tile_row, tile_col, n_tiles,
-                               scale, d_max_bits);
-        } else {
-            hipLaunchKernelGGL((reduce_max<64>), dim3(grid), dim3(256), 0, stream, a, tile_row, tile_col, n_tiles,
-                               scale, d_max_bits);
-        }
     }
     if (block_cells == 128) {
         hipLaunchKernelGGL((write_matrix<128>), dim3(n_tiles * 16), dim3(256), 0, stream, a, tile_row, tile_col, n,

@@ -51,7 +51,8 @@ struct AccumulateArgs {
     // tiles: upper-triangular block pairs, row-major
     const uint16_t *tile_row;
     const uint16_t *tile_col;
-    uint32_t tile_begin;       // first tile of this launch
+    uint32_t tile_begin;       // first tile of this launch (tile_ids == nullptr)
+    const uint32_t *tile_ids;  // or: the launch's tiles by global index (a rank's row block)
     uint32_t n_tiles;          // tiles of this launch
     uint32_t n_workgroups;     // = tile_wg_begin[n_tiles]
     const uint32_t *wg_tile;   // workgroup -> tile (relative to tile_begin)
@@ -80,6 +81,10 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
 hipError_t launch_finalize(const int64_t *acc, const uint16_t *tile_row, const uint16_t *tile_col, uint32_t n_tiles,
                            uint32_t n, uint32_t block_cells, int scale_log2, int mode,
                            unsigned long long *d_max_bits, uint32_t row_begin, uint32_t row_end, double *out,
-                           hipStream_t stream);
+                           hipStream_t stream, bool keep_max = false);
+// d_max_bits = bits of max(0, max D) over the listed tiles (tile_ids == nullptr: all n_tiles)
+hipError_t launch_tile_max(const int64_t *acc, const uint16_t *tile_row, const uint16_t *tile_col,
+                           const uint32_t *tile_ids, uint32_t n_tiles, uint32_t block_cells, int scale_log2,
+                           unsigned long long *d_max_bits, hipStream_t stream);
 
 }  // namespace secedo

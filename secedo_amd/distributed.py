@@ -49,12 +49,38 @@ def sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate
     return acc
 
 
-def row_range(num_cells, rank, world):
+def row_range(num_cells, rank, world, align=1):
     """Rows [lo, hi) of the matrix that `rank` keeps when the matrix stays sharded (contiguous, as even
-    as possible)."""
-    per, extra = divmod(num_cells, world)
+    as possible). With align = the tile edge the cuts fall on cell-block boundaries, so that no cell
+    block (and none of its tiles) is shared by two ranks."""
+    units = (num_cells + align - 1) // align
+    per, extra = divmod(units, world)
     lo = rank * per + min(rank, extra)
-    return lo, lo + per + (1 if rank < extra else 0)
+    hi = lo + per + (1 if rank < extra else 0)
+    return min(lo * align, num_cells), min(hi * align, num_cells)
+
+
+def sharded_rows(plan, acc, mutation_rate, homozygous_rate, seq_error_rate, rank, world, normalization="ADD_MIN",
+                 group=None):
+    """This rank's row block of the normalised matrix with nothing gathered (BASELINE config 5): the rank
+    accumulates every tile that touches its rows (an off-diagonal tile is computed by the two ranks that
+    own its row block and its column block: twice the pair work in total, no tile ever travels), the
+    ranks agree on the maximum that ADD_MIN / SCALE_MAX_1 need with one scalar all-reduce, and each
+    normalises its rows (cut on cell-block boundaries). `acc` from plan.new_acc(), zeroed here.
+    Returns (rows tensor, row_begin)."""
+    import torch
+    import torch.distributed as dist
+    lo, hi = row_range(plan.num_cells, rank, world, plan.block_cells)
+    ids = plan.tiles_of_rows(lo, hi)
+    acc.zero_()
+    plan.accumulate_list(acc, mutation_rate, homozygous_rate, seq_error_rate, ids)
+    local_max = plan.max_of_tiles(acc, ids)
+    if world > 1:
+        t = torch.tensor([local_max], dtype=torch.float64,
+                         device=acc.device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        local_max = float(t.item())
+    return plan.finalize_rows_max(acc, lo, hi, local_max, normalization), lo
 
 
 class _DevicePointer:

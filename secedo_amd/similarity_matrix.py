@@ -241,8 +241,45 @@ class SimilarityMatrixPlan:
             out = self._torch.empty((row_end - row_begin, self.num_cells), dtype=self._torch.float64,
                                     device="cuda:%d" % self.device)
         assert out.dtype == self._torch.float64 and out.is_contiguous()
+        if row_end == row_begin:
+            return out
         _lib.check(_lib.lib().secedo_simmat_finalize_rows(
             self._h, norm, C.c_void_p(acc.data_ptr()), row_begin, row_end, C.c_void_p(out.data_ptr()),
+            self._stream()))
+        return out
+
+    def tiles_of_rows(self, row_begin, row_end):
+        """Global indices of the tiles that touch rows [row_begin, row_end) with their row block or their
+        column block: what a rank accumulates itself to own that row block without any exchange."""
+        n = C.c_uint32(0)
+        _lib.check(_lib.lib().secedo_simmat_tiles_of_rows(self._h, row_begin, row_end, None, C.byref(n)))
+        ids = np.empty(n.value, dtype=np.uint32)
+        _lib.check(_lib.lib().secedo_simmat_tiles_of_rows(self._h, row_begin, row_end, _lib.ptr(ids), C.byref(n)))
+        return ids
+
+    def accumulate_list(self, acc, mutation_rate, homozygous_rate, seq_error_rate, tile_ids):
+        ids = np.ascontiguousarray(tile_ids, dtype=np.uint32)
+        _lib.check(_lib.lib().secedo_simmat_accumulate_list(
+            self._h, mutation_rate, homozygous_rate, seq_error_rate, _lib.ptr(ids), len(ids),
+            C.c_void_p(acc.data_ptr()), self._stream()))
+
+    def max_of_tiles(self, acc, tile_ids) -> float:
+        ids = np.ascontiguousarray(tile_ids, dtype=np.uint32)
+        out = C.c_double(0.0)
+        _lib.check(_lib.lib().secedo_simmat_max_of_tiles(
+            self._h, C.c_void_p(acc.data_ptr()), _lib.ptr(ids), len(ids), C.byref(out), self._stream()))
+        return out.value
+
+    def finalize_rows_max(self, acc, row_begin, row_end, max_value, normalization="ADD_MIN", out=None):
+        """finalize_rows with the maximum of D given by the caller (max-reduced over the ranks)."""
+        norm = to_enum(normalization)
+        if out is None:
+            out = self._torch.empty((row_end - row_begin, self.num_cells), dtype=self._torch.float64,
+                                    device="cuda:%d" % self.device)
+        if row_end == row_begin:
+            return out  # a rank without rows (more ranks than cell blocks)
+        _lib.check(_lib.lib().secedo_simmat_finalize_rows_max(
+            self._h, norm, C.c_void_p(acc.data_ptr()), row_begin, row_end, max_value, C.c_void_p(out.data_ptr()),
             self._stream()))
         return out
 

@@ -85,3 +85,7 @@ def test_row_ranges_partition_the_matrix():
             assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
             sizes = [hi - lo for lo, hi in edges]
             assert max(sizes) - min(sizes) <= 1
+            aligned = [row_range(n, r, world, 128) for r in range(world)]
+            assert aligned[0][0] == 0 and aligned[-1][1] == n
+            assert all(aligned[r][1] == aligned[r + 1][0] for r in range(world - 1))
+            assert all(lo % 128 == 0 for lo, _ in aligned)

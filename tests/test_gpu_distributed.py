@@ -58,6 +58,11 @@ def _spectral_worker(rank, world, port, out_dir):
             sd.sharded_accumulate(plan, acc, 0.01, 0.5, 0.01, rank, world)
             lo, hi = sd.row_range(n, rank, world)  # 3 ranks: 22 + 21 + 21 rows
             rows = plan.finalize_rows(acc, lo, hi, "ADD_MIN")
+            # the same row block with nothing gathered: this rank accumulates every tile touching its rows
+            own, own_lo = sd.sharded_rows(plan, plan.new_acc(), 0.01, 0.5, 0.01, rank, world, "ADD_MIN")
+            own_hi = own_lo + own.shape[0]  # cut on cell-block boundaries: one 64-cell block here, rank 0 has it
+            assert (own_lo, own_hi) == sd.row_range(n, rank, world, plan.block_cells)
+            assert torch.equal(own, plan.finalize_rows(acc, own_lo, own_hi, "ADD_MIN"))
             vals, vecs, info = sd.sharded_eigenpairs(rows, lo, n, 20, 7)
             assert info["converged"]
             np.save(os.path.join(out_dir, "vals%d.npy" % rank), vals)

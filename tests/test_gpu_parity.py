@@ -212,6 +212,46 @@ def test_one_handle_many_pileups():
             assert torch.equal(plan.finalize_raw(acc), mat)
 
 
+def test_row_blocks_without_any_gather():
+    """BASELINE config 5 in small: every rank accumulates the tiles that touch its rows (tiles_of_rows /
+    accumulate_list), the ranks only agree on one maximum, and the row blocks they normalise tile the
+    single-launch matrix bit for bit -- for three normalisations, 64- and 128-cell tiles, uneven splits."""
+    import torch
+    from secedo_amd.distributed import row_range
+    n = 400
+    p = random_pileup(611, n, 2, 500, 60, 1500, dup_frac=0.02)
+    for block, world in ((64, 3), (128, 2), (64, 5)):
+        with secedo_amd.SimilarityMatrixPlan(0) as plan:
+            plan.prepare(p, n, 1000, None, 8, block_cells=block)
+            full = plan.new_acc()
+            plan.accumulate(full, 0.01, 0.5, 0.01)
+            counts_full = plan.last_counts()
+            accs, ids, maxima, updates = [], [], [], 0
+            ranges = [row_range(n, rank, world, 1 if world == 5 else plan.block_cells) for rank in range(world)]
+            for rank in range(world):
+                lo, hi = ranges[rank]
+                ids.append(plan.tiles_of_rows(lo, hi))
+                acc = plan.new_acc()
+                plan.accumulate_list(acc, 0.01, 0.5, 0.01, ids[-1])
+                updates += plan.last_counts()[0]
+                maxima.append(plan.max_of_tiles(acc, ids[-1]))
+                accs.append(acc)
+                # the listed tiles equal the single launch's, the others stay untouched
+                b2 = plan.block_cells ** 2
+                mask = np.zeros(plan.num_tiles, dtype=bool)
+                mask[ids[-1]] = True
+                sel = torch.from_numpy(mask).cuda()
+                assert torch.equal(acc.view(-1, b2)[sel], full.view(-1, b2)[sel])
+                assert not acc.view(-1, b2)[~sel].any()
+            assert sorted(set(np.concatenate(ids).tolist())) == list(range(plan.num_tiles))
+            # off-diagonal tiles are done twice (more often only if a cut splits a cell block: world 5)
+            assert counts_full[0] < updates and (world == 5 or updates <= 2 * counts_full[0])
+            for norm in secedo_amd.NORMALIZATIONS:
+                whole = plan.finalize(full, norm).clone()
+                blocks = [plan.finalize_rows_max(accs[r], *ranges[r], max(maxima), norm) for r in range(world)]
+                assert torch.equal(torch.cat(blocks), whole), (block, world, norm)
+
+
 def test_cpp_host_without_torch(tmp_path):
     """Pure C++ host through include/secedo_simmat.hpp (system HIP runtime, no Python in the process),
     fed with the reference's binary pileup record format; must equal the Python-driven result."""
