@@ -88,4 +88,4 @@ def test_row_ranges_partition_the_matrix():
             aligned = [row_range(n, r, world, 128) for r in range(world)]
             assert aligned[0][0] == 0 and aligned[-1][1] == n
             assert all(aligned[r][1] == aligned[r + 1][0] for r in range(world - 1))
-            assert all(lo % 128 == 0 for lo, _ in aligned)
+            assert all(lo % 128 == 0 or lo == n for lo, _ in aligned)
