@@ -5,9 +5,14 @@
 // (reference: sequenced_data.hpp:26-37) and `Mat` the owning row-major matrix subset the boundary
 // returns (reference: util/mat.hpp:86 constructor, :117 element access, rows()/cols()).
 //
-// usage: shim_test <pileup.bin> <num_cells> <mfl> <num_threads> <normalization> <out.f64>
+// With a seventh argument the consumers run too (secedo_pipeline.hpp): the 7 smallest eigenpairs of the
+// matrix and the EM refinement started from the sign of the second eigenvector; appended to out.f64
+// are 7 eigenvalues, 7 eigenvectors (column-major) and the refined probabilities.
+//
+// usage: shim_test <pileup.bin> <num_cells> <mfl> <num_threads> <normalization> <out.f64> [consumers]
 //   pileup.bin = the reference's binary pileup records (u32 position, u16 coverage,
 //   u32 read_ids[coverage], u16 id_base[coverage]; util/pileup_reader.cpp:166-179), one chromosome.
+#include "secedo_pipeline.hpp"
 #include "secedo_simmat.hpp"
 
 #include <cstdio>
@@ -39,7 +44,7 @@ class Mat {
 };
 
 int main(int argc, char **argv) {
-    if (argc != 7) {
+    if (argc != 7 && argc != 8) {
         std::fprintf(stderr, "usage: %s pileup.bin num_cells mfl num_threads normalization out.f64\n", argv[0]);
         return 2;
     }
@@ -64,6 +69,16 @@ int main(int argc, char **argv) {
                 static_cast<uint32_t>(std::atoi(argv[4])), "", argv[5]);
         std::ofstream out(argv[6], std::ios::binary);
         out.write(reinterpret_cast<const char *>(m.data()), sizeof(double) * n * n);
+        if (argc == 8) {
+            std::vector<double> values, vectors;
+            secedo_amd::smallest_eigenpairs(m, 7, 7, &values, &vectors);
+            std::vector<double> prob(n);
+            for (uint32_t i = 0; i < n; ++i) prob[i] = vectors[static_cast<size_t>(n) + i] >= 0 ? 0.9 : 0.1;
+            secedo_amd::expectation_maximization<PosData>({chromosome}, identity, 1, 1e-3, &prob);
+            out.write(reinterpret_cast<const char *>(values.data()), sizeof(double) * values.size());
+            out.write(reinterpret_cast<const char *>(vectors.data()), sizeof(double) * vectors.size());
+            out.write(reinterpret_cast<const char *>(prob.data()), sizeof(double) * prob.size());
+        }
     } catch (const std::logic_error &e) {
         std::fprintf(stderr, "logic_error: %s\n", e.what());
         return 3;

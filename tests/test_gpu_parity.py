@@ -280,6 +280,17 @@ def test_cpp_host_without_torch(tmp_path):
         ref = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 4, norm)
         assert gu.normwise_err(got, ref) <= TOL
         assert np.array_equal(got, secedo_amd.compute_similarity_matrix(p, n, 1000, None, 0.01, 0.5, 0.01, 4, "", norm))
+    # the consumers through include/secedo_pipeline.hpp: eigenpairs and EM refinement, C++ vs the Python mirror
+    out = str(tmp_path / "consumers.f64")
+    subprocess.run([exe, path, str(n), "1000", "4", "ADD_MIN", out, "consumers"], check=True)
+    blob = np.fromfile(out, dtype=np.float64)
+    sim = blob[:n * n].reshape(n, n)
+    vals, vecs, prob = blob[n * n:n * n + 7], blob[n * n + 7:n * n + 7 + 7 * n].reshape(7, n).T, blob[-n:]
+    vals_py, vecs_py, _ = secedo_amd.smallest_eigenpairs(sim, 7, 7)
+    assert np.array_equal(vals, vals_py) and np.array_equal(vecs, vecs_py)
+    start = np.where(vecs[:, 1] >= 0, 0.9, 0.1)
+    prob_py, _ = secedo_amd.expectation_maximization(p, np.arange(n, dtype=np.uint32), 1, 1e-3, start)
+    assert np.array_equal(prob, prob_py)
 
 
 PACK_CASES = [
