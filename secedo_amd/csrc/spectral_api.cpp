@@ -124,7 +124,7 @@ struct Solver {
     const double *A = nullptr;  // rows [row_begin, row_begin + n_rows) of the matrix
     secedo_allreduce_sum_fn allreduce = nullptr;
     void *allreduce_ctx = nullptr;
-    Buf s, root, sums, Q, W, Z, P, Ypart, Gp, G, M;
+    Buf s, root, sums, Q, W, Z, P, Ypart, Gp, G, Gall, M;
     size_t blk_stride = 0;
 
     int setup(const double *d_rows, uint32_t row_begin_, uint32_t n_rows_, uint32_t n_, secedo_allreduce_sum_fn fn,
@@ -149,6 +149,8 @@ struct Solver {
         SP_TRY(Gp.alloc((size_t)gram_chunks(n) * (kCycleBlocks + 1) * BW * BW * 8));
         SP_TRY(G.alloc((size_t)(kCycleBlocks + 1) * BW * BW * 8));
         SP_TRY(M.alloc((size_t)(kCycleBlocks + 1) * BW * BW * 8));
+        // Gram-Schmidt coefficients of a whole cycle (6 steps x 2 passes x up to 6 blocks): read back once
+        SP_TRY(Gall.alloc((size_t)kCycleBlocks * 2 * kCycleBlocks * BW * BW * 8));
         return SECEDO_OK;
     }
     double *block(uint32_t b) const { return Q.d() + b * blk_stride; }
@@ -258,18 +260,27 @@ int solve(int device_id, const double *d_rows, uint32_t row_begin, uint32_t n_ro
             if ((rc = sv.product(sv.block(j), sv.W.d()))) return rc;
             ++inf.block_products;
             for (int pass = 0; pass < 2; ++pass) {  // classical Gram-Schmidt, twice
-                if ((rc = sv.gram_host(j + 1, sv.Q.d(), sv.W.d(), g))) return rc;
-                for (uint32_t blk = 0; blk <= j; ++blk)
-                    for (uint32_t a = 0; a < BW; ++a)
-                        for (uint32_t c = 0; c < BW; ++c)
-                            H[(size_t)(blk * BW + a) * m + j * BW + c] += g[((size_t)blk * BW + a) * BW + c];
-                // the coefficients are still in G on the device
-                SP_TRY(block_combine(n, sv.Q.d(), sv.blk_stride, j + 1, sv.G.d(), -1.0, 1.0, sv.W.d(), stream));
+                // the coefficients stay on the device; the host needs them only for the projection H
+                double *coef = sv.Gall.d() + (size_t)(j * 2 + pass) * kCycleBlocks * BW * BW;
+                SP_TRY(gram(n, sv.Q.d(), sv.blk_stride, j + 1, sv.W.d(), sv.Gp.d(), coef, stream));
+                SP_TRY(block_combine(n, sv.Q.d(), sv.blk_stride, j + 1, coef, -1.0, 1.0, sv.W.d(), stream));
             }
             if ((rc = sv.orthonormalise(sv.W.d(), sv.block(j + 1), R, alive))) return rc;
             note_alive(j + 1);
             if (j + 1 == kCycleBlocks) R_last = R;
         }
+        // H[blk, j] = sum of the two passes' coefficients of step j (one read-back per cycle; the
+        // orthonormalisation of the last step has synchronised the stream)
+        g.resize((size_t)kCycleBlocks * 2 * kCycleBlocks * BW * BW);
+        SP_TRY(hipMemcpyAsync(g.data(), sv.Gall.d(), g.size() * 8, hipMemcpyDeviceToHost, stream));
+        SP_TRY(hipStreamSynchronize(stream));
+        for (uint32_t j = 0; j < kCycleBlocks; ++j)
+            for (int pass = 0; pass < 2; ++pass)
+                for (uint32_t blk = 0; blk <= j; ++blk)
+                    for (uint32_t a = 0; a < BW; ++a)
+                        for (uint32_t c = 0; c < BW; ++c)
+                            H[(size_t)(blk * BW + a) * m + j * BW + c]
+                                    += g[(((size_t)(j * 2 + pass) * kCycleBlocks + blk) * BW + a) * BW + c];
         // the projection is symmetric: take the computed block upper triangle, mirror it
         for (uint32_t r = 0; r < m; ++r)
             for (uint32_t c = 0; c < m; ++c)
