@@ -206,6 +206,19 @@ __global__ void k_entry_keys(Raw in, const uint32_t *entry_locus, uint32_t id_bi
     }
 }
 
+// Per entry in sorted order: locus (30 bits) | base << 30. Written once with the one gather by entry
+// index; the kernels of stages 2-4 then read it sequentially instead of gathering through sval.
+constexpr uint32_t kSlocLocusMask = 0x3FFFFFFFu;
+__device__ __forceinline__ uint32_t sloc_pack(uint32_t locus, uint32_t id_base) { return locus | (id_base << 30); }
+__device__ __forceinline__ uint32_t sloc_locus(uint32_t v) { return v & kSlocLocusMask; }
+__device__ __forceinline__ uint32_t sloc_base(uint32_t v) { return v >> 30; }
+
+// radix path (the counting path writes sloc in k_id_rank)
+__global__ void k_sorted_locus(Raw in, const uint32_t *sval, const uint32_t *entry_locus, uint32_t n, uint32_t *sloc) {
+    for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB)
+        sloc[s] = sloc_pack(entry_locus[sval[s]], in.id_base(sval[s]));
+}
+
 // counting path, entries by (chromosome, read id) through the dense numbering
 __global__ void k_id_hist(Raw in, const uint32_t *entry_locus, const uint32_t *id_base, const uint32_t *id_negmin,
                           const Scalars *sc, uint32_t *dense, uint32_t *hist) {
@@ -230,12 +243,14 @@ __global__ void k_id_scatter(const uint32_t *dense, uint32_t n, const uint32_t *
 // rank inside the read's group = number of its entries with a smaller index: the entries of a read
 // end up in pileup order (by locus), as a stable sort leaves them
 __global__ void k_id_rank(Raw in, const uint32_t *dense, const uint32_t *id_off, const uint32_t *grouped,
-                          unsigned long long *skey, uint32_t *sval, Scalars *sc) {
+                          const uint32_t *entry_locus, unsigned long long *skey, uint32_t *sval, uint32_t *sloc,
+                          Scalars *sc) {
     const bool void_run = sc->id_exceeded != 0;
     for (uint32_t p = blockIdx.x * TPB + threadIdx.x; p < in.n_entries; p += gridDim.x * TPB) {
         if (void_run) {  // keep what follows inside its arrays until the host sees the flag and starts over
             skey[p] = p;
             sval[p] = p;
+            sloc[p] = 0;
             continue;
         }
         const uint32_t e = grouped[p];
@@ -250,6 +265,7 @@ __global__ void k_id_rank(Raw in, const uint32_t *dense, const uint32_t *id_off,
         }
         skey[b + rank] = d;  // equal keys <=> same read; ascending in (chromosome, read id)
         sval[b + rank] = e;
+        sloc[b + rank] = sloc_pack(entry_locus[e], in.id_base(e));  // the one gather by entry index
     }
 }
 
@@ -281,23 +297,23 @@ __device__ __forceinline__ uint32_t incl_kept(unsigned long long v) { return (ui
 // duplicate-position rule (:387-395) per (read, locus) group of the sorted order, and the mark of
 // every read's first entry (in pileup order) for the appearance rank
 __global__ void k_dup_mark(Raw in, const unsigned long long *skey, const uint32_t *sval,
-                           const uint32_t *entry_locus, const uint32_t *split, uint32_t n, uint32_t *keep,
+                           const uint32_t *sloc, const uint32_t *split, uint32_t n, uint32_t *keep,
                            uint32_t *mark) {
     for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
         const uint32_t e = sval[s];
-        const uint32_t l = entry_locus[e];
+        const uint32_t l = sloc_locus(sloc[s]);
         const bool same_read = s > 0 && skey[s] == skey[s - 1];  // same id: a split starts at a new locus
         mark[e] = (same_read && !(split && split[s])) ? 0u : 1u;
         if (s == 0) mark[n] = 0u;
-        if (same_read && entry_locus[sval[s - 1]] == l) continue;  // not a group head
+        if (same_read && sloc_locus(sloc[s - 1]) == l) continue;  // not a group head
         uint32_t stored = s;  // position of the stored entry of this (read, locus)
         bool have = true;
         keep[s] = 0u;
-        for (uint32_t t = s + 1; t < n && skey[t] == skey[s] && entry_locus[sval[t]] == l; ++t) {
+        for (uint32_t t = s + 1; t < n && skey[t] == skey[s] && sloc_locus(sloc[t]) == l; ++t) {
             keep[t] = 0u;
             if (have) {
                 // second mate at the stored position: equal base -> ignored; different -> both go
-                if ((in.id_base(sval[t]) & 3u) != (in.id_base(sval[stored]) & 3u)) have = false;
+                if (sloc_base(sloc[t]) != sloc_base(sloc[stored])) have = false;
             } else {
                 stored = t;  // the position is free again: this entry is appended
                 have = true;
@@ -309,16 +325,16 @@ __global__ void k_dup_mark(Raw in, const unsigned long long *skey, const uint32_
 
 // run starts (reads) and the per-read lists of kept entries (CSR payload)
 __global__ void k_runs_csr(Raw in, const unsigned long long *incl, const uint32_t *sval,
-                           const uint32_t *entry_locus, uint32_t n, uint32_t *run_start, uint32_t *read_locus,
+                           const uint32_t *sloc, uint32_t n, uint32_t *run_start, uint32_t *read_locus,
                            uint8_t *read_base) {
     for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
         const unsigned long long cur = incl[s], prev = s ? incl[s - 1] : 0ull;
         if (incl_reads(cur) != incl_reads(prev)) run_start[incl_reads(cur) - 1] = s;
         if (s == n - 1) run_start[incl_reads(cur)] = n;
         if (incl_kept(cur) != incl_kept(prev)) {
-            const uint32_t e = sval[s], k = incl_kept(prev);
-            read_locus[k] = entry_locus[e];
-            read_base[k] = (uint8_t)(in.id_base(e) & 3u);
+            const uint32_t k = incl_kept(prev), v = sloc[s];
+            read_locus[k] = sloc_locus(v);
+            read_base[k] = (uint8_t)sloc_base(v);
         }
     }
 }
@@ -326,7 +342,7 @@ __global__ void k_runs_csr(Raw in, const unsigned long long *incl, const uint32_
 // per read: span check, offsets into the per-read lists, appearance rank, start position in rank
 // order, entries of multi-locus reads; per chromosome the first rank
 __global__ __launch_bounds__(TPB) void k_read_info(Raw in, const unsigned long long *incl, const uint32_t *run_start,
-                                                  const uint32_t *sval, const uint32_t *entry_locus,
+                                                  const uint32_t *sval, const uint32_t *sloc,
                                                   const uint32_t *arank, uint32_t mfl, uint32_t *run_rank,
                                                   uint32_t *starts_by_rank, uint32_t *rbeg, uint32_t *read_off,
                                                   Scalars *sc) {
@@ -336,8 +352,8 @@ __global__ __launch_bounds__(TPB) void k_read_info(Raw in, const unsigned long l
     unsigned long long multi = 0;
     for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r < n_runs; r += gridDim.x * TPB) {
         const uint32_t s0 = run_start[r], s1 = run_start[r + 1];
-        const uint32_t e0 = sval[s0], e1 = sval[s1 - 1];
-        const uint32_t p0 = in.locus_pos[entry_locus[e0]], p1 = in.locus_pos[entry_locus[e1]];
+        const uint32_t e0 = sval[s0];
+        const uint32_t p0 = in.locus_pos[sloc_locus(sloc[s0])], p1 = in.locus_pos[sloc_locus(sloc[s1 - 1])];
         // a read whose entries reach start + mfl can be flushed before its last entry arrives and is
         // then re-opened as a new read (:368-371, :379-382): k_split_update finds where
         if (p1 - p0 >= mfl) sc->long_reads = 1;
@@ -433,8 +449,7 @@ __global__ __launch_bounds__(TPB) void k_flush_chain(Raw in, const uint32_t *cnt
 // of an erased id opens a new read that starts there (:379-382). One thread per id walks the id's
 // entries (a handful) against the chromosome's flush loci. The cuts change the read starts, hence the
 // completed counts, hence possibly later flushes: the caller iterates until nothing changes.
-__global__ void k_split_update(Raw in, const unsigned long long *skey, const uint32_t *sval,
-                               const uint32_t *entry_locus, uint32_t mfl, const uint32_t *flush_loci,
+__global__ void k_split_update(Raw in, const unsigned long long *skey, const uint32_t *sloc, uint32_t mfl, const uint32_t *flush_loci,
                                const uint32_t *flush_count, uint32_t *split, Scalars *sc) {
     const uint32_t n = in.n_entries;
     for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
@@ -442,15 +457,15 @@ __global__ void k_split_update(Raw in, const unsigned long long *skey, const uin
         uint32_t end = s + 1;
         while (end < n && skey[end] == skey[s]) ++end;
         if (end == s + 1) continue;
-        const uint32_t l_first = entry_locus[sval[s]];
-        const uint32_t p_first = in.locus_pos[l_first], p_last = in.locus_pos[entry_locus[sval[end - 1]]];
+        const uint32_t l_first = sloc_locus(sloc[s]);
+        const uint32_t p_first = in.locus_pos[l_first], p_last = in.locus_pos[sloc_locus(sloc[end - 1])];
         if (p_last - p_first < mfl) continue;  // never in a flushed prefix before its last entry
         const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l_first);
         const uint32_t *fl = flush_loci + in.chr_locus_off[c];
         const uint32_t n_fl = flush_count[c];
         uint32_t seg_start = p_first, l_prev = l_first;
         for (uint32_t t = s + 1; t < end; ++t) {
-            const uint32_t l_t = entry_locus[sval[t]];
+            const uint32_t l_t = sloc_locus(sloc[t]);
             uint32_t cut = 0;
             if (l_t != l_prev) {
                 // the first flush locus after l_prev whose position has reached seg_start + mfl
@@ -910,7 +925,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     HIP_OK(S[WORK_B].ensure(((size_t)2 * E + 2) * 4));
     // RUNS: run_start[R+1] | run_rank[R] | starts_by_rank[R], R <= E
     HIP_OK(S[RUNS].ensure(((size_t)3 * E + 8) * 4));
-    if (!force_radix) HIP_OK(S[ENTRY_KC].ensure((size_t)E * 8));
+    // ENTRY_KC: locus per entry in sorted order (stages 2-4), later (k, cell) per entry (counting path)
+    HIP_OK(S[ENTRY_KC].ensure((size_t)E * 8));
+    uint32_t *sloc = S[ENTRY_KC].as<uint32_t>();
     // TMP: read index per kept entry; BIN: key2 x2, val2 x2, per-cell squares
     HIP_OK(S[TMP].ensure((size_t)E * 4 + 64));
     HIP_OK(S[BIN].ensure((size_t)E * 24 + ((size_t)num_cells + 130) * 8 + 64));
@@ -974,14 +991,15 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, hist, id_off, (int)(id_space + 1), stream));
         hipLaunchKernelGGL(k_id_scatter, dim3(blocks_for(E)), dim3(TPB), 0, stream, dense, E, id_off, sc, hist,
                            grouped);
-        hipLaunchKernelGGL(k_id_rank, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, dense, id_off, grouped, key_b,
-                           val_b, sc);
+        hipLaunchKernelGGL(k_id_rank, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, dense, id_off, grouped, eloc,
+                           key_b, val_b, sloc, sc);
     } else {
         const uint32_t id_bits = (uint32_t)bits_for(hsc.max_read_id);
         hipLaunchKernelGGL(k_entry_keys, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_bits, key_a, val_a);
         cub_cap = S[CUB].bytes;
         HIP_OK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_cap, key_a, key_b, val_a, val_b, (int)E, 0,
                                                    (int)id_bits + bits_for(C), stream));
+        hipLaunchKernelGGL(k_sorted_locus, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, val_b, eloc, E, sloc);
     }
     const unsigned long long *skey = key_b;
     const uint32_t *sval = val_b;
@@ -1018,7 +1036,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     // sequential (one lane per chromosome) and only the final gather needs its result: it runs on a
     // side stream, next to the grouping of the kept entries.
     auto build_reads = [&]() -> std::string {
-        hipLaunchKernelGGL(k_dup_mark, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sval, eloc, split, E, keep,
+        hipLaunchKernelGGL(k_dup_mark, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sval, sloc, split, E, keep,
                            mark);
         {
             hipcub::CountingInputIterator<uint32_t> positions(0u);
@@ -1029,10 +1047,10 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         }
         cub_cap = S[CUB].bytes;
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, mark, arank, (int)E + 1, stream));
-        hipLaunchKernelGGL(k_runs_csr, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, incl, sval, eloc, E, run_start,
+        hipLaunchKernelGGL(k_runs_csr, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, incl, sval, sloc, E, run_start,
                            read_locus, read_base);
         hipLaunchKernelGGL(k_read_info, dim3(std::min<uint32_t>(blocks_for(E), 2048)), dim3(TPB), 0, stream, raw, incl,
-                           run_start, sval, eloc, arank, mfl, run_rank, starts_by_rank, rbeg, read_off, sc);
+                           run_start, sval, sloc, arank, mfl, run_rank, starts_by_rank, rbeg, read_off, sc);
         HIP_OK(hipEventRecord(pk.ev_fork, stream));
         HIP_OK(hipStreamWaitEvent(pk.side, pk.ev_fork, 0));
         hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, pk.side, raw, starts_by_rank, rbeg, mfl, cnt);
@@ -1081,7 +1099,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         for (int round = 0; round < kMaxSplitRounds && !stable; ++round) {
             HIP_OK(hipStreamWaitEvent(stream, pk.ev_join, 0));  // the chain of the previous build
             HIP_OK(hipMemsetAsync(&sc->split_changed, 0, 4, stream));
-            hipLaunchKernelGGL(k_split_update, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sval, eloc, mfl,
+            hipLaunchKernelGGL(k_split_update, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sloc, mfl,
                                flush_loci, flush_count, split, sc);
             HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
             HIP_OK(hipStreamSynchronize(stream));
@@ -1226,7 +1244,7 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     const uint64_t E64 = in.n_entries;
     const uint32_t L = in.n_loci;
     const size_t n_off_max = (size_t)((num_cells + 63) / 64) * ((size_t)L + 1);
-    if (E64 >= (1ull << 31) || L == 0 || E64 == 0 || (uint64_t)4 * num_threads > 0xFFFFFFFFull
+    if (E64 >= (1ull << 31) || L == 0 || L >= (1u << 30) || E64 == 0 || (uint64_t)4 * num_threads > 0xFFFFFFFFull
         || n_off_max >= (1ull << 31)) {
         *need_host = true;  // sizes this path does not cover (incl. the empty pileup)
         return std::string();
