@@ -135,3 +135,16 @@ def test_argument_errors():
             0, a.ctypes.data, 10, 11, 2, 0.0, 0, np.empty(11).ctypes.data, np.empty((2, 10)).ctypes.data, None))
     with pytest.raises(ValueError):
         secedo_amd.smallest_eigenpairs(np.zeros((3, 4)))
+
+
+def test_divide_cluster_demo_runs_end_to_end():
+    """tools/divide_cluster_demo.py: filter -> matrix -> eigenpairs -> Fiedler cut -> EM, resident in HBM, on the
+    64-cell two-clone pileup: the split must be pure."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "divide_cluster_demo.py"), "C1"], check=True,
+                         capture_output=True, text=True).stdout.strip().splitlines()[-1]
+    line = json.loads(out)
+    assert line["cells"] == 64 and line["split_purity"] == 1.0
