@@ -14,13 +14,16 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <new>
+#include <queue>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -434,7 +437,7 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
         h->host_tile_row = trow;
         h->host_tile_col = tcol;
     }
-    HIP_TRY(h->counters.ensure(16 * sizeof(unsigned long long)));
+    HIP_TRY(h->counters.ensure((16 + 2048 * 9) * sizeof(unsigned long long)));  // [16..): diagnostic builds
     HIP_TRY(h->max_bits.ensure(sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, 16 * sizeof(unsigned long long), s));
     h->prepared = true;
@@ -551,25 +554,43 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         const uint32_t wgs_per_round = h->pk.block_cells == 128 ? 256u : h->pk.stage_masks ? 512u : 1024u;
         uint32_t rounds = 1;
         if (const char *env = std::getenv("SECEDO_ROUNDS")) rounds = std::max(1, std::atoi(env));
-        std::vector<uint32_t> weight(n_tiles);
-        uint64_t total_weight = 0;
+        // weight of a tile = the time it takes: per row-side entry a fixed part (the batch set-up) and a
+        // part per column entry of the same locus (the pairs; half of them in a diagonal tile). Fitted to
+        // the per-workgroup times on C2: the fixed part is worth 5.7 pairs.
+        const uint32_t Bc = h->pk.block_cells;
+        auto cells_of = [&](uint32_t blk) { return (double)std::min(Bc, h->pk.num_cells - blk * Bc); };
+        const double per_cell_locus = h->pk.num_loci ? (double)h->pk.num_entries / h->pk.num_cells / h->pk.num_loci : 0.0;
+        std::vector<double> weight(n_tiles);
+        double total_weight = 0;
         for (uint32_t k = 0; k < n_tiles; ++k) {
             const uint32_t t = list ? list[k] : tile_begin + k;
-            weight[k] = (h->host_tile_row[t] == h->host_tile_col[t]) ? 1u : 2u;
+            const uint32_t I = h->host_tile_row[t], J = h->host_tile_col[t];
+            const double depth = per_cell_locus * cells_of(J) * (I == J ? 0.5 : 1.0);  // column entries per locus
+            weight[k] = cells_of(I) * (5.7 + depth);
             total_weight += weight[k];
         }
-        const uint64_t slots = static_cast<uint64_t>(wgs_per_round) * rounds;
+        // whole rounds of workgroups, shared out so that the slowest chunk is as fast as possible: every
+        // tile starts with one chunk and the next one always goes to the tile whose chunks are heaviest
+        const uint64_t slots = static_cast<uint64_t>(wgs_per_round) * std::max<uint64_t>(rounds, (n_tiles + wgs_per_round - 1) / wgs_per_round);
+        const uint32_t max_chunks = std::max(1u, h->pk.num_ranges);
+        std::vector<uint32_t> chunks(n_tiles, 1u);
+        if (total_weight > 0 && n_tiles < slots && n_tiles <= 2 * wgs_per_round) {  // more tiles: one workgroup each
+            std::priority_queue<std::pair<double, uint32_t>> heaviest;  // (weight per chunk, tile)
+            for (uint32_t k = 0; k < n_tiles; ++k) heaviest.push({weight[k], k});
+            for (uint64_t given = n_tiles; given < slots && !heaviest.empty();) {
+                const uint32_t k = heaviest.top().second;
+                heaviest.pop();
+                if (chunks[k] >= max_chunks) continue;  // one range per chunk at least
+                ++chunks[k];
+                ++given;
+                heaviest.push({weight[k] / chunks[k], k});
+            }
+        }
         std::vector<uint32_t> wg_begin(n_tiles + 1, 0);
         std::vector<uint32_t> wg_tile;
         for (uint32_t t = 0; t < n_tiles; ++t) {
-            uint64_t c = total_weight ? (weight[t] * slots + total_weight / 2) / total_weight : 1;
-            c = std::max<uint64_t>(1, std::min<uint64_t>(c, h->pk.num_ranges ? h->pk.num_ranges : 1));
-            // a chunk count that leaves the last chunk empty would waste a workgroup
-            const uint32_t per = (h->pk.num_ranges + static_cast<uint32_t>(c) - 1) / static_cast<uint32_t>(c);
-            if (per) c = (h->pk.num_ranges + per - 1) / per;
-            if (c == 0) c = 1;
-            wg_begin[t + 1] = wg_begin[t] + static_cast<uint32_t>(c);
-            for (uint64_t k = 0; k < c; ++k) wg_tile.push_back(t);
+            wg_begin[t + 1] = wg_begin[t] + chunks[t];
+            for (uint32_t k = 0; k < chunks[t]; ++k) wg_tile.push_back(t);
         }
         HIP_TRY(h->plan_wg_tile.upload(wg_tile));
         HIP_TRY(h->plan_wg_begin.upload(wg_begin));
@@ -732,6 +753,16 @@ int secedo_simmat_last_counts(secedo_simmat_t *h, uint64_t *updates, uint64_t *r
                          (double)st[9] / st[8], (double)st[10] / st[8], (double)st[11] / st[8]);
             std::fprintf(stderr, "[stamps] per wave: post-trip %.0f, batch loop total %.0f\n",
                          (double)st[12] / st[8], (double)st[13] / st[8]);
+            std::fprintf(stderr, "[stamps] longest wave lifetime %llu cyc; ranges %u workgroups %u\n", st[14],
+                         h->pk.num_ranges, h->plan_workgroups);
+            std::vector<unsigned long long> wg(std::min<uint32_t>(h->plan_workgroups, 2048u));
+            HIP_TRY(hipMemcpy(wg.data(), h->counters.as<unsigned long long>() + 16, wg.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<unsigned long long> det(wg.size() * 8);
+            HIP_TRY(hipMemcpy(det.data(), h->counters.as<unsigned long long>() + 16 + 2048, det.size() * 8, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < wg.size(); ++k)
+                std::fprintf(stderr, "[stamps-wg] %zu %llu %llu %llu | hwid %llx ranges %llu listflush %llu endbarrier %llu slab %llu | realbegin %llu realend %llu batchloop %llu\n", k,
+                             wg[k] & 0xFFFFFFFFull, (wg[k] >> 32) & 0xFFF, (wg[k] >> 44) & 0xFFF, det[k * 8], det[k * 8 + 1] / 1000,
+                             det[k * 8 + 2] / 1000, det[k * 8 + 3] / 1000, det[k * 8 + 4] / 1000, det[k * 8 + 5], det[k * 8 + 6], det[k * 8 + 7] / 1000);
         }
     }
     return SECEDO_OK;

@@ -43,6 +43,11 @@ __device__ __forceinline__ unsigned long long stamp() {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return t;
 }
+__device__ __forceinline__ unsigned long long stamp_real() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
 #define STAMP(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = stamp(); __builtin_amdgcn_sched_barrier(0)
 #else
 #define STAMP(var)
@@ -178,10 +183,38 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     const uint32_t t = a.tile_ids ? a.tile_ids[t_local] : a.tile_begin + t_local;
     const uint32_t chunk = blockIdx.x - a.tile_wg_begin[t_local];
     const uint32_t n_chunks_t = a.tile_wg_begin[t_local + 1] - a.tile_wg_begin[t_local];
-    const uint32_t chunk_ranges = (a.num_ranges + n_chunks_t - 1) / n_chunks_t;
     const uint32_t I = a.tile_row[t], J = a.tile_col[t];
     const bool diag = (I == J);
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t *offI = a.blk_off + (size_t)I * a.stride;
+    const uint32_t *offJ = a.blk_off + (size_t)J * a.stride;
+    // A tile's chunks are equal shares of its row-side entries (the pair work per row entry is even
+    // along the genome); a chunk walks the locus ranges its share touches and, in the first and the
+    // last of them, only its own row entries -- chunk boundaries need not be range boundaries.
+    uint32_t r_begin = 0, r_end = a.num_ranges;
+    uint32_t row_begin = 0u, row_end = 0xFFFFFFFFu;
+    if (n_chunks_t > 1u) {
+        const uint32_t L = a.stride - 1u;
+        const uint32_t e0 = offI[0];
+        const unsigned long long n_row = offI[L] - e0;
+        row_begin = e0 + (uint32_t)(n_row * chunk / n_chunks_t);
+        row_end = e0 + (uint32_t)(n_row * (chunk + 1u) / n_chunks_t);
+        uint32_t before = 0, upto = 0;
+        for (uint32_t base = 0; base < a.num_ranges; base += THREADS) {
+            const uint32_t k = base + tid;
+            bool ends_before = false, begins_inside = false;
+            if (k < a.num_ranges) {
+                ends_before = offI[a.range_off[k + 1u]] <= row_begin;
+                begins_inside = offI[a.range_off[k]] < row_end;
+            }
+            before += (uint32_t)__syncthreads_count(ends_before);
+            upto += (uint32_t)__syncthreads_count(begins_inside);
+        }
+        r_begin = __builtin_amdgcn_readfirstlane(before);
+        r_end = __builtin_amdgcn_readfirstlane(upto);
+        row_begin = __builtin_amdgcn_readfirstlane(row_begin);
+        row_end = __builtin_amdgcn_readfirstlane(row_end);
+    }
 
     if (COUNTS) {
         for (uint32_t i = tid; i < B * B; i += THREADS) tile32[i] = 0u;
@@ -193,16 +226,13 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
             sLut[i] = a.lut[(i / SLUT_DIM) * LUT_DIM + (i % SLUT_DIM)];
     }
 
-    const uint32_t r_begin = min(a.num_ranges, chunk * chunk_ranges);
-    const uint32_t r_end = min(a.num_ranges, r_begin + chunk_ranges);
-    const uint32_t *offI = a.blk_off + (size_t)I * a.stride;
-    const uint32_t *offJ = a.blk_off + (size_t)J * a.stride;
     const long long d10 = a.lut[1 * LUT_DIM + 0], d01 = a.lut[0 * LUT_DIM + 1];
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B;
     unsigned long long n_updates = 0, n_pairs = 0;
 #ifdef SECEDO_STAMPS
     unsigned long long st_setup = 0, st_fill = 0, st_trip = 0, st_batches = 0, st_trips = 0, st_bar1 = 0, st_stage = 0, st_pref = 0, st_post = 0, st_t3 = 0, st_loop = 0;
     const unsigned long long st_begin = stamp();
+    const unsigned long long st_real_begin = stamp_real();
 #endif
     uint32_t upd = 0, skipped = 0;  // per range, 32-bit, per lane
     uint32_t n_list = 0;            // deferred joint pairs in this wave's list (wave-uniform)
@@ -211,6 +241,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     // means dependent HBM reads: the hot loop only appends them to a per-wave list, and the list is
     // worked off 64 pairs at a time -- every lane busy, one memory latency for 64 pairs.
     auto flush_list = [&]() {
+        if (a.debug & 16u) { n_list = 0; return; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (uint32_t q = lane; q < n_list; q += 64u) {
@@ -272,16 +303,18 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     // the next range's column side, in flight in registers while the current range is paired
     uint32_t pJ[JPT], pM[MASKS ? JPT : 1], pO[OPT];
     uint32_t pRec = 0, pM1 = 0;  // this wave's first row-side batch of the next range
-    uint32_t n_la = 0, n_lb = 0, n_ib = 0, n_ie = 0, n_jb = 0, n_je = 0;
+    uint32_t n_la = 0, n_lb = 0, n_ib = 0, n_ie = 0, n_jb = 0, n_je = 0, n_dsh = 0;
     bool n_staged = false;
 
     auto prefetch = [&](uint32_t r) {
-        n_la = a.range_off[r];
-        n_lb = a.range_off[r + 1];
-        n_ib = offI[n_la];
-        n_ie = offI[n_lb];
-        n_jb = offJ[n_la];
-        n_je = offJ[n_lb];
+        n_la = __builtin_amdgcn_readfirstlane(a.range_off[r]);  // wave-uniform: keep them in SGPRs
+        n_lb = __builtin_amdgcn_readfirstlane(a.range_off[r + 1]);
+        const uint32_t range_ib = __builtin_amdgcn_readfirstlane(offI[n_la]);
+        n_ib = max(range_ib, row_begin);  // this chunk's part of the range's row side
+        n_ie = max(n_ib, min((uint32_t)__builtin_amdgcn_readfirstlane(offI[n_lb]), row_end));
+        n_dsh = n_ib - range_ib;
+        n_jb = __builtin_amdgcn_readfirstlane(offJ[n_la]);
+        n_je = __builtin_amdgcn_readfirstlane(offJ[n_lb]);
         n_staged = (n_je - n_jb) <= (uint32_t)CAPJ && (n_lb - n_la) <= (uint32_t)CAPL;
         if (n_staged) {
 #pragma unroll
@@ -307,8 +340,9 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     };
 
     if (r_begin < r_end) prefetch(r_begin);
+    STAMP(t_pro);
     for (uint32_t r = r_begin; r < r_end; ++r) {
-        const uint32_t la = n_la, lb = n_lb, ib = n_ib, ie = n_ie, jb = n_jb, je = n_je;
+        const uint32_t la = n_la, lb = n_lb, ib = n_ib, ie = n_ie, jb = n_jb, je = n_je, dsh = n_dsh;
         const bool staged = n_staged;
         STAMP(tb0);
         __syncthreads();  // every wave is done with the previous range (first time: with zeroing)
@@ -362,7 +396,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
                 uint32_t j0 = 0, c = 0;
                 if (i < nI) {
                     const uint32_t lrel = rec >> 16;
-                    j0 = diag ? i + 1u : (uint32_t)sOff[lrel];
+                    j0 = diag ? i + dsh + 1u : (uint32_t)sOff[lrel];  // diagonal: entries after this one
                     const uint32_t j1 = sOff[lrel + 1];
                     c = j1 > j0 ? j1 - j0 : 0u;
                 }
@@ -549,8 +583,11 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
         n_updates += upd_all;
         n_pairs += (unsigned long long)upd_all - skipped;
     }
+    STAMP(t_le);
     if (MCAP > 0 && n_list) flush_list();
+    STAMP(t_fl);
     __syncthreads();
+    STAMP(t_eb);
 
     // flush: the workgroup's tile goes to its own slab with plain coalesced stores; reduce_slabs adds
     // the slabs of a tile into the accumulator (joint terms and deep ranges went there directly)
@@ -564,18 +601,41 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
         for (uint32_t i = tid; i < B * B / 2; i += THREADS) out[i] = src[i];
     }
 
+    STAMP(t_sl);
+#ifdef SECEDO_STAMPS
+    if (threadIdx.x == 0u && blockIdx.x < 2048u) {
+        unsigned long long *w = a.counters + 16 + 2048 + (size_t)blockIdx.x * 8;
+        w[0] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); w[1] = t_le - t_pro; w[2] = t_fl - t_le; w[3] = t_eb - t_fl; w[4] = t_sl - t_eb; w[5] = st_real_begin; w[6] = stamp_real(); w[7] = st_loop;
+        a.counters[16 + blockIdx.x] = ((t_sl - st_begin) & 0xFFFFFFFFull) | ((unsigned long long)r_begin << 32) | ((unsigned long long)r_end << 44);
+    }
+#endif
     // work counters: wave reduction, one atomic per wave
     n_pairs -= skipped_list;
     for (int off = 32; off > 0; off >>= 1) {
         n_updates += __shfl_down(n_updates, off);
         n_pairs += __shfl_down(n_pairs, off);
     }
-    if (lane == 0u && (n_updates | n_pairs)) {
-        atomicAdd(&a.counters[0], n_updates);
-        atomicAdd(&a.counters[1], n_pairs);
+    // ... and one per workgroup: thousands of same-address atomics at the end of a launch queue up in
+    // the memory system and delay the workgroups still running (the staging area is free by now)
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(sJ);
+    if (lane == 0u) {
+        red[(tid >> 6) * 2] = n_updates;
+        red[(tid >> 6) * 2 + 1] = n_pairs;
+    }
+    __syncthreads();
+    if (tid == 0u) {
+        unsigned long long u = 0, q = 0;
+        for (int w = 0; w < WAVES; ++w) {
+            u += red[w * 2];
+            q += red[w * 2 + 1];
+        }
+        if (u | q) {
+            atomicAdd(&a.counters[0], u);
+            atomicAdd(&a.counters[1], q);
+        }
     }
 #ifdef SECEDO_STAMPS
-    if (lane == 0u) {
+    if (tid == 0u) {  // wave 0 of every workgroup stands for its workgroup
         atomicAdd(&a.counters[2], st_setup);
         atomicAdd(&a.counters[3], st_fill);
         atomicAdd(&a.counters[4], st_trip);
@@ -588,6 +648,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
         atomicAdd(&a.counters[11], st_pref);
         atomicAdd(&a.counters[12], st_post);
         atomicAdd(&a.counters[13], st_loop);
+        atomicMax(&a.counters[14], stamp() - st_begin);
     }
 #endif
 }
@@ -764,7 +825,9 @@ hipError_t launch_tile_max(const int64_t *acc, const uint16_t *tile_row, const u
     hipError_t e = hipMemsetAsync(d_max_bits, 0, sizeof(unsigned long long), stream);
     if (e != hipSuccess || n_tiles == 0) return e;
     const size_t total = (size_t)n_tiles * block_cells * block_cells;
-    const uint32_t grid = (uint32_t)std::min<size_t>((total + 255) / 256, 256 * 8);
+    // every workgroup ends in one atomicMax on the same word, and same-address atomics are served one
+    // after the other (~10 ns each): at least 16 cells per thread
+    const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min<size_t>((total + 256 * 16 - 1) / (256 * 16), 256 * 8));
     const long long *a = reinterpret_cast<const long long *>(acc);
     if (block_cells == 128) {
         hipLaunchKernelGGL((reduce_max<128>), dim3(grid), dim3(256), 0, stream, a, tile_row, tile_col, tile_ids, n_tiles,

@@ -106,6 +106,33 @@ def test_tile_ranges_compose_bitwise():
         assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("clustered,block", [(True, 64), (False, 128), (False, 64)])
+def test_chunks_cut_inside_locus_ranges(clustered, block):
+    """Few tiles and many locus ranges: every tile is shared by tens of workgroups whose shares of the row
+    entries begin and end inside a range (all three tile variants; exact counters catch a pair counted
+    twice or dropped at a cut)."""
+    from secedo_amd.synth import synth_pileup
+    n = 300
+    p = synth_pileup(n, 8000, 3, 300 if clustered else 30000, 0.15 if clustered else 0.4, seed=77)
+    ref, raw = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 4, "ADD_MIN", want_raw=True)
+    u_ref, pairs_ref = ob.oracle_last_updates(), ob.oracle_last_read_pairs()
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        plan.prepare(p, n, 1000, None, 4, block_cells=block)
+        acc = plan.new_acc()
+        plan.accumulate(acc, 0.01, 0.5, 0.01)
+        d = plan.finalize_raw(acc).cpu().numpy()
+        u, pairs = plan.last_counts()
+        again = plan.new_acc()
+        nt = plan.num_tiles
+        plan.accumulate(again, 0.01, 0.5, 0.01, 0, nt // 2)  # other chunk counts per tile, same sums
+        plan.accumulate(again, 0.01, 0.5, 0.01, nt // 2, nt)
+        import torch
+        torch.cuda.synchronize()
+        assert torch.equal(acc, again)
+    assert (u, pairs) == (u_ref, pairs_ref)
+    assert gu.normwise_err(d, raw) <= TOL
+
+
 def test_edge_inputs():
     # empty pileup, empty chromosome, single cell
     empty = from_rows([[]])
