@@ -17,6 +17,10 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -43,9 +47,63 @@ struct Buf {
     T *as() const { return static_cast<T *>(p); }
 };
 
+// Scratch of one refinement: one allocation, carved up. The reference refines once per sub-cluster of
+// its recursion (spectral_clustering.cpp:425-426), and hipMalloc + hipFree of nine buffers cost more than
+// the kernels: the allocation is kept per device between calls (grown when too small) and handed to one
+// caller at a time; a concurrent caller allocates its own. secedo_simmat_release_cache() frees it,
+// SECEDO_ONE_SHOT_CACHE=0 turns the pool off.
+struct Arena {
+    void *p = nullptr;
+    size_t bytes = 0;
+    bool busy = false;
+    hipError_t ensure(size_t n) {
+        if (p && n <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        const size_t want = n + n / 8 + 256;
+        const hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+std::mutex g_arena_mutex;
+std::map<int, Arena> g_arenas;  // leaked at exit on purpose: the HIP runtime may be gone by then
+
+struct ArenaLease {
+    Arena own;
+    Arena *a = &own;
+    explicit ArenaLease(int device) {
+        const char *e = std::getenv("SECEDO_ONE_SHOT_CACHE");
+        if (e && std::strcmp(e, "0") == 0) return;
+        std::lock_guard<std::mutex> lock(g_arena_mutex);
+        Arena &slot = g_arenas[device];
+        if (!slot.busy) {
+            slot.busy = true;
+            a = &slot;
+        }
+    }
+    ~ArenaLease() {
+        if (a == &own) {
+            own.release();
+        } else {
+            std::lock_guard<std::mutex> lock(g_arena_mutex);
+            a->busy = false;
+        }
+    }
+    ArenaLease(const ArenaLease &) = delete;
+    ArenaLease &operator=(const ArenaLease &) = delete;
+};
+
 struct Flags {
     uint32_t error;  // 1: group id >= n_cells (prob index), 2: group outside id_to_pos / position >= n_cells
     uint32_t done;
+    uint32_t iterations;  // E-steps run (counted on the device: iterations are launched in batches)
 };
 
 __device__ __forceinline__ uint32_t id_base_at(const uint16_t *b16, const uint32_t *b32, uint64_t e) {
@@ -87,7 +145,8 @@ __global__ void k_em_cell_offsets(const uint32_t *sorted_key, uint32_t n, uint32
 // cluster_center (:19-39) for both clusters: centres[l][0..3] = log centre A, [4..7] = log centre B
 __global__ __launch_bounds__(256) void k_em_centres(const uint64_t *off, uint32_t n_loci, const uint16_t *b16,
                                                    const uint32_t *b32, const double *prob_b, double theta,
-                                                   double *centres) {
+                                                   double *centres, const Flags *flags) {
+    if (flags->done) return;  // settled earlier in this batch of iterations
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
     for (uint32_t l = wave; l < n_loci; l += n_waves) {
@@ -125,10 +184,11 @@ __global__ __launch_bounds__(256) void k_em_centres(const uint64_t *off, uint32_
 
 // ll_a[cell] += sum over the cell's entries of centre_a[locus][base], same for b (:77-80, :142-145)
 __global__ __launch_bounds__(256) void k_em_cell_sums(const uint32_t *cell_off, const uint32_t *val, uint32_t n_cells,
-                                                     const double *centres, double *ll_a, double *ll_b) {
+                                                     const double *centres, double *ll_a, double *ll_b,
+                                                     const Flags *flags) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t cell = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    if (cell >= n_cells) return;
+    if (cell >= n_cells || flags->done) return;
     double sa = 0.0, sb = 0.0;
     for (uint32_t i = cell_off[cell] + lane; i < cell_off[cell + 1]; i += 64u) {
         const uint32_t v = val[i];
@@ -149,6 +209,7 @@ __global__ __launch_bounds__(256) void k_em_cell_sums(const uint32_t *cell_off, 
 // expectation_step (:100-123), one workgroup
 __global__ __launch_bounds__(1024) void k_em_estep(uint32_t n_cells, const double *ll_a, const double *ll_b,
                                                   double *prob_b, Flags *flags) {
+    if (flags->done) return;
     __shared__ double part[1024];
     __shared__ int moved;
     double sum = 0.0;
@@ -169,7 +230,10 @@ __global__ __launch_bounds__(1024) void k_em_estep(uint32_t n_cells, const doubl
         prob_b[i] = prob;
     }
     __syncthreads();
-    if (threadIdx.x == 0) flags->done = moved ? 0u : 1u;
+    if (threadIdx.x == 0) {
+        flags->done = moved ? 0u : 1u;
+        flags->iterations += 1u;
+    }
 }
 
 int bits_for(uint32_t max_value) {
@@ -195,37 +259,45 @@ int refine(int device_id, const uint64_t *d_off, uint32_t n_loci, uint64_t n_ent
     if (max_iterations == 0) max_iterations = 1000;
     const uint32_t E = (uint32_t)n_entries;
 
-    Buf key_a, key_b, val_a, val_b, cub, cell_off, centres, ll, flags;
-    EM_TRY(key_a.alloc((size_t)E * 4));
-    EM_TRY(key_b.alloc((size_t)E * 4));
-    EM_TRY(val_a.alloc((size_t)E * 4));
-    EM_TRY(val_b.alloc((size_t)E * 4));
-    EM_TRY(cell_off.alloc(((size_t)n_cells + 1) * 4));
-    EM_TRY(centres.alloc((size_t)std::max(n_loci, 1u) * 8 * sizeof(double)));
-    EM_TRY(ll.alloc((size_t)n_cells * 2 * sizeof(double)));
-    EM_TRY(flags.alloc(sizeof(Flags)));
-    EM_TRY(hipMemsetAsync(flags.p, 0, sizeof(Flags), stream));
-    EM_TRY(hipMemsetAsync(ll.p, 0, (size_t)n_cells * 2 * sizeof(double), stream));  // :130-131
-    double *ll_a = ll.as<double>(), *ll_b = ll_a + n_cells;
+    // sizes first (the sort's temporary storage is a query), then one allocation carved up
+    size_t sort_tmp = 0;
+    if (E)
+        EM_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                                  (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)E, 0,
+                                                  bits_for(n_cells - 1), stream));
+    size_t total = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = total;
+        total += (bytes + 255) / 256 * 256;
+        return at;
+    };
+    const size_t o_key_a = carve((size_t)E * 4), o_key_b = carve((size_t)E * 4), o_val_a = carve((size_t)E * 4),
+                 o_val_b = carve((size_t)E * 4), o_cub = carve(sort_tmp), o_cell_off = carve(((size_t)n_cells + 1) * 4),
+                 o_centres = carve((size_t)std::max(n_loci, 1u) * 8 * sizeof(double)),
+                 o_ll = carve((size_t)n_cells * 2 * sizeof(double)), o_flags = carve(sizeof(Flags));
+    ArenaLease lease(device_id);
+    EM_TRY(lease.a->ensure(total));
+    unsigned char *base = static_cast<unsigned char *>(lease.a->p);
+    uint32_t *key_a = reinterpret_cast<uint32_t *>(base + o_key_a), *key_b = reinterpret_cast<uint32_t *>(base + o_key_b);
+    uint32_t *val_a = reinterpret_cast<uint32_t *>(base + o_val_a), *val_b = reinterpret_cast<uint32_t *>(base + o_val_b);
+    uint32_t *cell_off = reinterpret_cast<uint32_t *>(base + o_cell_off);
+    double *centres = reinterpret_cast<double *>(base + o_centres);
+    Flags *flags = reinterpret_cast<Flags *>(base + o_flags);
+    double *ll_a = reinterpret_cast<double *>(base + o_ll), *ll_b = ll_a + n_cells;
+    EM_TRY(hipMemsetAsync(flags, 0, sizeof(Flags), stream));
+    EM_TRY(hipMemsetAsync(ll_a, 0, (size_t)n_cells * 2 * sizeof(double), stream));  // :130-131
     const uint32_t locus_grid = std::max(1u, std::min((n_loci + 3u) / 4u, 16384u));
-    const uint32_t *sorted_val = val_a.as<uint32_t>();
+    const uint32_t *sorted_val = val_a;
     if (E) {
         hipLaunchKernelGGL(k_em_keys, dim3(locus_grid), dim3(256), 0, stream, d_off, n_loci, d_b16, d_b32, d_id_to_pos,
-                           n_groups, n_cells, key_a.as<uint32_t>(), val_a.as<uint32_t>(), flags.as<Flags>());
-        size_t need = 0;
-        EM_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, key_a.as<uint32_t>(), key_b.as<uint32_t>(),
-                                                  val_a.as<uint32_t>(), val_b.as<uint32_t>(), (int)E, 0,
+                           n_groups, n_cells, key_a, val_a, flags);
+        EM_TRY(hipcub::DeviceRadixSort::SortPairs(base + o_cub, sort_tmp, key_a, key_b, val_a, val_b, (int)E, 0,
                                                   bits_for(n_cells - 1), stream));
-        EM_TRY(cub.alloc(need));
-        EM_TRY(hipcub::DeviceRadixSort::SortPairs(cub.p, need, key_a.as<uint32_t>(), key_b.as<uint32_t>(),
-                                                  val_a.as<uint32_t>(), val_b.as<uint32_t>(), (int)E, 0,
-                                                  bits_for(n_cells - 1), stream));
-        sorted_val = val_b.as<uint32_t>();
+        sorted_val = val_b;
     }
-    hipLaunchKernelGGL(k_em_cell_offsets, dim3((n_cells + 256) / 256), dim3(256), 0, stream, key_b.as<uint32_t>(), E,
-                       n_cells, cell_off.as<uint32_t>());
+    hipLaunchKernelGGL(k_em_cell_offsets, dim3((n_cells + 256) / 256), dim3(256), 0, stream, key_b, E, n_cells, cell_off);
     Flags h{};
-    EM_TRY(hipMemcpyAsync(&h, flags.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+    EM_TRY(hipMemcpyAsync(&h, flags, sizeof(h), hipMemcpyDeviceToHost, stream));
     EM_TRY(hipStreamSynchronize(stream));
     if (h.error == 1)
         return secedo::api_fail(SECEDO_E_INVALID_ARG,
@@ -234,19 +306,24 @@ int refine(int device_id, const uint64_t *d_off, uint32_t n_loci, uint64_t n_ent
     if (h.error == 2)
         return secedo::api_fail(SECEDO_E_INVALID_ARG, "a group id is outside id_to_pos or maps outside prob_cluster_b");
 
+    // Iterations are launched four at a time: a kernel returns at once when an earlier E-step of its
+    // batch has settled, so the host reads the flags (a synchronisation, ~40 us) once per batch.
     uint32_t it = 0;
     for (;;) {
         if (it == max_iterations)
             return secedo::api_fail(SECEDO_E_LIMIT, "the EM refinement did not settle within max_iterations");
-        ++it;
-        if (n_loci)
-            hipLaunchKernelGGL(k_em_centres, dim3(locus_grid), dim3(256), 0, stream, d_off, n_loci, d_b16, d_b32, d_prob,
-                               theta, centres.as<double>());
-        hipLaunchKernelGGL(k_em_cell_sums, dim3((n_cells + 3u) / 4u), dim3(256), 0, stream, cell_off.as<uint32_t>(),
-                           sorted_val, n_cells, centres.as<double>(), ll_a, ll_b);
-        hipLaunchKernelGGL(k_em_estep, dim3(1), dim3(1024), 0, stream, n_cells, ll_a, ll_b, d_prob, flags.as<Flags>());
-        EM_TRY(hipMemcpyAsync(&h, flags.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+        const uint32_t batch = std::min(4u, max_iterations - it);
+        for (uint32_t k = 0; k < batch; ++k) {
+            if (n_loci)
+                hipLaunchKernelGGL(k_em_centres, dim3(locus_grid), dim3(256), 0, stream, d_off, n_loci, d_b16, d_b32,
+                                   d_prob, theta, centres, flags);
+            hipLaunchKernelGGL(k_em_cell_sums, dim3((n_cells + 3u) / 4u), dim3(256), 0, stream, cell_off, sorted_val,
+                               n_cells, centres, ll_a, ll_b, flags);
+            hipLaunchKernelGGL(k_em_estep, dim3(1), dim3(1024), 0, stream, n_cells, ll_a, ll_b, d_prob, flags);
+        }
+        EM_TRY(hipMemcpyAsync(&h, flags, sizeof(h), hipMemcpyDeviceToHost, stream));
         EM_TRY(hipStreamSynchronize(stream));
+        it = h.iterations;
         if (h.done) break;
     }
     EM_TRY(hipGetLastError());
@@ -255,6 +332,14 @@ int refine(int device_id, const uint64_t *d_off, uint32_t n_loci, uint64_t n_ent
 }
 
 }  // namespace
+
+namespace secedo {
+void em_release_cache() {
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    for (auto &slot : g_arenas)
+        if (!slot.second.busy) slot.second.release();
+}
+}  // namespace secedo
 
 extern "C" {
 

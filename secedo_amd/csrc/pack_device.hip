@@ -19,6 +19,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -32,6 +34,7 @@ DevicePacked::~DevicePacked() {
     if (side) (void)hipStreamDestroy(side);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (mailbox) (void)hipHostFree(mailbox);
 }
 
 hipError_t DeviceArena::ensure(size_t n) {
@@ -65,6 +68,87 @@ struct Scalars {
     unsigned long long id_space;  // sum over chromosomes of (largest - smallest read id + 1)
     unsigned long long multi_entries;
     unsigned long long pair_bound;
+};
+
+// Scalar read-backs. hipMemcpyAsync + hipStreamSynchronize leaves the GPU idle for 30-40 us per
+// read-back (interrupt, wake-up, the first launches after it); instead a one-lane kernel publishes the
+// scalars into pinned host memory and the host polls the sequence word next to them.
+struct Mailbox {
+    Scalars sc;
+    unsigned long long totals;
+    unsigned long long seq;
+};
+
+__global__ void k_publish(const Scalars *sc, const unsigned long long *totals, Mailbox *box, unsigned long long seq) {
+    if (threadIdx.x == 0) {
+        box->sc = *sc;
+        box->totals = totals ? *totals : 0ull;
+        __hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t read_scalars(DevicePacked &pk, hipStream_t stream, const Scalars *sc, const unsigned long long *totals,
+                        Scalars *out, unsigned long long *out_totals) {
+    static const bool plain = [] {
+        const char *e = std::getenv("SECEDO_PACK_READBACK");
+        return e && std::strcmp(e, "memcpy") == 0;
+    }();
+    hipError_t e;
+    if (!plain && !pk.mailbox && !pk.mailbox_failed) {
+        if (hipHostMalloc(&pk.mailbox, sizeof(Mailbox), hipHostMallocDefault) == hipSuccess) {
+            std::memset(pk.mailbox, 0, sizeof(Mailbox));
+        } else {  // no pinned memory to be had: the plain copies below
+            (void)hipGetLastError();
+            pk.mailbox = nullptr;
+            pk.mailbox_failed = true;
+        }
+    }
+    if (!plain && pk.mailbox) {
+        Mailbox *box = static_cast<Mailbox *>(pk.mailbox);
+        const unsigned long long seq = ++pk.mailbox_seq;
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, stream, sc, totals, box, seq);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        // poll; every few thousand polls ask the runtime whether the stream died or drained without
+        // the word arriving (then the plain copy below reports what happened)
+        bool arrived = false;
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(&box->seq, __ATOMIC_ACQUIRE) == seq) {
+                arrived = true;
+                break;
+            }
+            if ((spins & 0xFFFu) == 0xFFFu) {
+                const hipError_t q = hipStreamQuery(stream);
+                if (q != hipErrorNotReady) {
+                    arrived = __atomic_load_n(&box->seq, __ATOMIC_ACQUIRE) == seq;
+                    if (q != hipSuccess) return q;
+                    break;
+                }
+            }
+        }
+        if (arrived) {
+            *out = box->sc;
+            if (out_totals) *out_totals = box->totals;
+            return hipSuccess;
+        }
+    }
+    if (out_totals) {
+        *out_totals = 0;
+        if (totals && (e = hipMemcpyAsync(out_totals, totals, 8, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    }
+    if ((e = hipMemcpyAsync(out, sc, sizeof(*out), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    return hipStreamSynchronize(stream);
+}
+
+// SECEDO_PACK_TRACE=1: host-side time stamps of the packing's launch sequence on stderr
+struct HostTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    HostTrace() : on(std::getenv("SECEDO_PACK_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) const {
+        if (on)
+            std::fprintf(stderr, "[pack-trace] %8.1f us  %s\n",
+                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
+    }
 };
 
 // Grouping without a sort (entries by read id, kept entries by (cell block, locus)): histogram of
@@ -957,6 +1041,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     HIP_OK(hipMemsetAsync(sc, 0, sizeof(Scalars) + sizeof(uint32_t) * ((size_t)3 * C + 1), stream));
 
     // ---- 1: entries grouped by (chromosome, read id), pileup order inside a read ---------------
+    const HostTrace trace;
+    trace.mark("begin");
     hipLaunchKernelGGL(k_check_positions, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, sc);
     hipLaunchKernelGGL(k_entry_locus, dim3(blocks_for((uint64_t)L * 64)), dim3(TPB), 0, stream, raw, eloc);
     hipLaunchKernelGGL(k_id_range, dim3(std::min<uint32_t>(1024, (E + 4095) / 4096)), dim3(TPB), 0, stream, raw,
@@ -971,8 +1057,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     Scalars hsc;
     std::memset(&hsc, 0, sizeof(hsc));
     if (!assume) {
-        HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipStreamSynchronize(stream));  // read-back 1: the size of the id space
+        HIP_OK(read_scalars(pk, stream, sc, nullptr, &hsc, nullptr));  // read-back 1: the size of the id space
         if (hsc.error == 3) return "positions must be strictly increasing within a chromosome";
     }
     const size_t id_space = assume ? (size_t)pk.id_space_hint
@@ -1071,9 +1156,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
 
     // read-back 2: status flags, R, number of kept entries, multi-locus statistics
     unsigned long long totals = 0;  // reads | kept entries << 32
-    HIP_OK(hipMemcpyAsync(&totals, incl + (E - 1), 8, hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));
+    trace.mark("reads built (launched)");
+    HIP_OK(read_scalars(pk, stream, sc, incl + (E - 1), &hsc, &totals));
+    trace.mark("read-back 2 arrived");
     if (hsc.error == 3) return "positions must be strictly increasing within a chromosome";
     if (hsc.id_exceeded) {
         pk.id_space_hint = 0;
@@ -1101,8 +1186,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             HIP_OK(hipMemsetAsync(&sc->split_changed, 0, 4, stream));
             hipLaunchKernelGGL(k_split_update, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sloc, mfl,
                                flush_loci, flush_count, split, sc);
-            HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
-            HIP_OK(hipStreamSynchronize(stream));
+            HIP_OK(read_scalars(pk, stream, sc, nullptr, &hsc, nullptr));
             if (!hsc.split_changed) {
                 stable = true;
                 break;
@@ -1110,9 +1194,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             HIP_OK(hipMemsetAsync(&sc->multi_entries, 0, 8, stream));  // k_read_info adds to it
             const std::string err = build_reads();
             if (!err.empty()) return err;
-            HIP_OK(hipMemcpyAsync(&totals, incl + (E - 1), 8, hipMemcpyDeviceToHost, stream));
-            HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
-            HIP_OK(hipStreamSynchronize(stream));
+            HIP_OK(read_scalars(pk, stream, sc, incl + (E - 1), &hsc, &totals));
         }
         if (!stable) {
             *need_host = true;  // did not settle: the exact sequential emulation decides
@@ -1154,6 +1236,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     HIP_OK(hipMemsetAsync(per_cell_sq, 0, ((size_t)nb * B + 1) * 8, stream));
     hipLaunchKernelGGL(k_keys2, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, incl, read_locus, num_cells, B,
                        lbits, key2_a, val2_a, t_read, entry_kc, sc);
+    trace.mark("k_keys2 launched");
     const uint32_t slice_grid = std::min<uint32_t>(2048, (n_kept + 4095) / 4096);
     if (force_radix) {
         if (n_kept) {
@@ -1169,8 +1252,10 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         const uint32_t locus_grid = std::min<uint32_t>(blocks_for((uint64_t)L * 64), 8192);
         const size_t lds = (size_t)(TPB / 64) * nb * 4;
         hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_kc, blk_cnt);
+        trace.mark("k_bin_hist launched");
         cub_cap = S[CUB].bytes;
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
+        trace.mark("offset scan launched");
         if (n_kept) {
             unsigned long long *grouped = key_b;  // the sorted entry keys are dead after k_dup_rule
             hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_kc, blk_off,
@@ -1212,8 +1297,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
                            pk.entry32.as<uint32_t>(), pk.mask32.as<uint32_t>(), pk.entry_read.as<uint32_t>());
     }
     // read-back 3: errors of the group mapping, pair bound (-> tile variant), number of ranges
-    HIP_OK(hipMemcpyAsync(&hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));
+    trace.mark("records launched");
+    HIP_OK(read_scalars(pk, stream, sc, nullptr, &hsc, nullptr));
+    trace.mark("read-back 3 arrived");
     if (hsc.error == 1) return "group id outside group_id_to_pos";
     if (hsc.error == 2) return "group_id_to_pos maps outside the matrix";
     if (hsc.regroup) {

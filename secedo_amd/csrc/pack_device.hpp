@@ -55,6 +55,10 @@ struct DevicePacked {
     // (completed counts + flush chain); created on first use
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // pinned host words the packing's scalar read-backs arrive in (polled; see read_scalars)
+    void *mailbox = nullptr;
+    unsigned long long mailbox_seq = 0;
+    bool mailbox_failed = false;
     DevicePacked() = default;
     DevicePacked(const DevicePacked &) = delete;
     DevicePacked &operator=(const DevicePacked &) = delete;

@@ -171,6 +171,7 @@ void one_shot_release(int device, secedo_simmat_t *h, bool ok) {
 namespace secedo {
 // for the other translation units of the library (spectral_api.cpp): one error slot per thread
 int api_fail(int code, const std::string &msg) { return fail(code, msg); }
+void em_release_cache();  // em_device.hip
 }  // namespace secedo
 
 extern "C" {
@@ -821,6 +822,7 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
 }
 
 void secedo_simmat_release_cache(void) {
+    secedo::em_release_cache();
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (auto &slot : g_pool) {
         if (slot.second) secedo_simmat_destroy(slot.second);

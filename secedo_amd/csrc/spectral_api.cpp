@@ -60,71 +60,13 @@ struct Buf {
             return secedo::api_fail(SECEDO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));    \
     } while (0)
 
-// W^T W = R^T R with the columns scaled to unit norm first. A column whose norm is rounding noise,
-// or whose part outside the span of the columns before it is below 1e-5 of its norm, is dropped: it
-// keeps its coefficients on the surviving directions in R (W = Q R still holds up to the dropped
-// remainder), its row of R and its row and column of R^-1 are zero, so the orthonormalised block
-// Q = W R^-1 has a zero column there. Returns R (upper triangular, row-major), R^-1, and who survived.
-void cholesky_drop(const std::vector<double> &G, std::vector<double> &R, std::vector<double> &Rinv,
-                   std::vector<char> &alive) {
-    const int n = (int)BW;
-    std::vector<double> d(n, 0.0), S((size_t)n * n, 0.0);
-    alive.assign(n, 1);
-    for (int c = 0; c < n; ++c) {
-        const double g = G[(size_t)c * n + c];
-        if (g > 1e-26) d[c] = std::sqrt(g);  // norm above 1e-13
-        else alive[c] = 0;                   // an exhausted direction
-    }
-    for (int c = 0; c < n; ++c) {
-        if (!alive[c]) continue;
-        double piv = 1.0;
-        for (int k = 0; k < c; ++k) {
-            if (!alive[k]) continue;
-            double v = G[(size_t)k * n + c] / (d[k] * d[c]);
-            for (int t = 0; t < k; ++t) v -= S[(size_t)t * n + k] * S[(size_t)t * n + c];
-            v /= S[(size_t)k * n + k];
-            S[(size_t)k * n + c] = v;
-            piv -= v * v;
-        }
-        if (piv <= 1e-10) alive[c] = 0;  // dependent on the columns before it
-        else S[(size_t)c * n + c] = std::sqrt(piv);
-    }
-    R.assign((size_t)n * n, 0.0);
-    Rinv.assign((size_t)n * n, 0.0);
-    for (int r = 0; r < n; ++r)
-        for (int c = r; c < n; ++c) R[(size_t)r * n + c] = S[(size_t)r * n + c] * d[c];
-    // inverse of the surviving triangle by back substitution
-    for (int c = 0; c < n; ++c) {
-        if (!alive[c]) continue;
-        Rinv[(size_t)c * n + c] = 1.0 / R[(size_t)c * n + c];
-        for (int r = c - 1; r >= 0; --r) {
-            if (!alive[r]) continue;
-            double v = 0.0;
-            for (int t = r + 1; t <= c; ++t)
-                if (alive[t]) v -= R[(size_t)r * n + t] * Rinv[(size_t)t * n + c];
-            Rinv[(size_t)r * n + c] = v / R[(size_t)r * n + r];
-        }
-    }
-}
-
-std::vector<double> matmul32(const std::vector<double> &a, const std::vector<double> &b) {
-    std::vector<double> c((size_t)BW * BW, 0.0);
-    for (uint32_t i = 0; i < BW; ++i)
-        for (uint32_t k = 0; k < BW; ++k) {
-            const double v = a[(size_t)i * BW + k];
-            if (v == 0.0) continue;
-            for (uint32_t j = 0; j < BW; ++j) c[(size_t)i * BW + j] += v * b[(size_t)k * BW + j];
-        }
-    return c;
-}
-
 struct Solver {
     uint32_t n = 0, row_begin = 0, n_rows = 0;
     hipStream_t stream = nullptr;
     const double *A = nullptr;  // rows [row_begin, row_begin + n_rows) of the matrix
     secedo_allreduce_sum_fn allreduce = nullptr;
     void *allreduce_ctx = nullptr;
-    Buf s, root, sums, Q, W, Z, P, Ypart, Gp, G, Gall, M;
+    Buf s, root, sums, Q, W, Z, P, Ypart, Gp, G, Gall, M, Rfirst, Rblk, alive_dev;
     size_t blk_stride = 0;
 
     int setup(const double *d_rows, uint32_t row_begin_, uint32_t n_rows_, uint32_t n_, secedo_allreduce_sum_fn fn,
@@ -151,6 +93,9 @@ struct Solver {
         SP_TRY(M.alloc((size_t)(kCycleBlocks + 1) * BW * BW * 8));
         // Gram-Schmidt coefficients of a whole cycle (6 steps x 2 passes x up to 6 blocks): read back once
         SP_TRY(Gall.alloc((size_t)kCycleBlocks * 2 * kCycleBlocks * BW * BW * 8));
+        SP_TRY(Rfirst.alloc((size_t)BW * BW * 8));
+        SP_TRY(Rblk.alloc((size_t)(kCycleBlocks + 1) * BW * BW * 8));
+        SP_TRY(alive_dev.alloc((size_t)(kCycleBlocks + 1) * BW * 4));
         return SECEDO_OK;
     }
     double *block(uint32_t b) const { return Q.d() + b * blk_stride; }
@@ -180,33 +125,25 @@ struct Solver {
         SP_TRY(product_finish(n, s.d(), x, Ypart.d(), y, stream));
         return SECEDO_OK;
     }
-    // G[blk] = Q[blk]^T w for blk < nblk, to the host
-    int gram_host(uint32_t nblk, const double *basis, const double *w, std::vector<double> &out) {
-        SP_TRY(secedo::spectral::gram(n, basis, blk_stride, nblk, w, Gp.d(), G.d(), stream));
-        out.resize((size_t)nblk * BW * BW);
-        SP_TRY(hipMemcpyAsync(out.data(), G.d(), out.size() * 8, hipMemcpyDeviceToHost, stream));
-        SP_TRY(hipStreamSynchronize(stream));
-        return SECEDO_OK;
-    }
     int upload_small(const std::vector<double> &m) {
         SP_TRY(hipMemcpyAsync(M.d(), m.data(), m.size() * 8, hipMemcpyHostToDevice, stream));
         return SECEDO_OK;
     }
-    // dst = orthonormalised src (Cholesky QR, twice); R with src = dst R. src is overwritten.
-    int orthonormalise(double *src, double *dst, std::vector<double> &R, std::vector<char> &alive) {
-        std::vector<double> g, r1, r1inv, r2, r2inv;
-        std::vector<char> alive1;
-        int rc = gram_host(1, src, src, g);
-        if (rc) return rc;
-        cholesky_drop(g, r1, r1inv, alive1);
-        if ((rc = upload_small(r1inv))) return rc;
-        SP_TRY(secedo::spectral::block_combine(n, src, blk_stride, 1, M.d(), 1.0, 0.0, dst, stream));
-        if ((rc = gram_host(1, dst, dst, g))) return rc;
-        cholesky_drop(g, r2, r2inv, alive);
-        if ((rc = upload_small(r2inv))) return rc;
-        SP_TRY(secedo::spectral::block_combine(n, dst, blk_stride, 1, M.d(), 1.0, 0.0, src, stream));
+    // Q[blk] = orthonormalised src (Cholesky QR, twice; src is overwritten). Nothing comes back to the
+    // host here: R with src = Q[blk] R goes to Rblk[blk] and the surviving columns to alive_dev[blk], which
+    // the cycle reads once, with the Gram-Schmidt coefficients.
+    int orthonormalise(double *src, uint32_t blk) {
+        using namespace secedo::spectral;
+        double *dst = block(blk);
+        double *R = static_cast<double *>(Rblk.p) + (size_t)blk * BW * BW;
+        uint32_t *alive = static_cast<uint32_t *>(alive_dev.p) + (size_t)blk * BW;
+        SP_TRY(gram(n, src, blk_stride, 1, src, Gp.d(), G.d(), stream));
+        SP_TRY(cholesky_drop(G.d(), nullptr, M.d(), Rfirst.d(), nullptr, stream));
+        SP_TRY(block_combine(n, src, blk_stride, 1, M.d(), 1.0, 0.0, dst, stream));
+        SP_TRY(gram(n, dst, blk_stride, 1, dst, Gp.d(), G.d(), stream));
+        SP_TRY(cholesky_drop(G.d(), Rfirst.d(), M.d(), R, alive, stream));
+        SP_TRY(block_combine(n, dst, blk_stride, 1, M.d(), 1.0, 0.0, src, stream));
         SP_TRY(hipMemcpyAsync(dst, src, blk_stride * 8, hipMemcpyDeviceToDevice, stream));
-        R = matmul32(r2, r1);
         return SECEDO_OK;
     }
 };
@@ -239,12 +176,9 @@ int solve(int device_id, const double *d_rows, uint32_t row_begin, uint32_t n_ro
     if (rc) return rc;
     if ((rc = sv.scales())) return rc;
     SP_TRY(init_block(n, sv.root.d(), sv.W.d(), stream));
-    std::vector<double> R, R_last;
-    std::vector<char> alive;
-    std::vector<char> basis_alive((size_t)(kCycleBlocks + 1) * BW, 1);
-    auto note_alive = [&](uint32_t blk) { std::copy(alive.begin(), alive.end(), basis_alive.begin() + blk * BW); };
-    if ((rc = sv.orthonormalise(sv.W.d(), sv.block(0), R, alive))) return rc;
-    note_alive(0);
+    std::vector<double> R_last((size_t)BW * BW);
+    std::vector<uint32_t> basis_alive((size_t)(kCycleBlocks + 1) * BW, 1);
+    if ((rc = sv.orthonormalise(sv.W.d(), 0))) return rc;
 
     const uint32_t m = kCycleBlocks * BW;
     std::vector<double> H((size_t)m * m), theta, U, g;
@@ -265,14 +199,15 @@ int solve(int device_id, const double *d_rows, uint32_t row_begin, uint32_t n_ro
                 SP_TRY(gram(n, sv.Q.d(), sv.blk_stride, j + 1, sv.W.d(), sv.Gp.d(), coef, stream));
                 SP_TRY(block_combine(n, sv.Q.d(), sv.blk_stride, j + 1, coef, -1.0, 1.0, sv.W.d(), stream));
             }
-            if ((rc = sv.orthonormalise(sv.W.d(), sv.block(j + 1), R, alive))) return rc;
-            note_alive(j + 1);
-            if (j + 1 == kCycleBlocks) R_last = R;
+            if ((rc = sv.orthonormalise(sv.W.d(), j + 1))) return rc;
         }
-        // H[blk, j] = sum of the two passes' coefficients of step j (one read-back per cycle; the
-        // orthonormalisation of the last step has synchronised the stream)
+        // The one read-back of the cycle: H[blk, j] = sum of the two passes' coefficients of step j, who
+        // survived the orthonormalisations, and the R of the last step (for the residuals).
         g.resize((size_t)kCycleBlocks * 2 * kCycleBlocks * BW * BW);
         SP_TRY(hipMemcpyAsync(g.data(), sv.Gall.d(), g.size() * 8, hipMemcpyDeviceToHost, stream));
+        SP_TRY(hipMemcpyAsync(basis_alive.data(), sv.alive_dev.p, basis_alive.size() * 4, hipMemcpyDeviceToHost, stream));
+        SP_TRY(hipMemcpyAsync(R_last.data(), static_cast<const double *>(sv.Rblk.p) + (size_t)kCycleBlocks * BW * BW,
+                              R_last.size() * 8, hipMemcpyDeviceToHost, stream));
         SP_TRY(hipStreamSynchronize(stream));
         for (uint32_t j = 0; j < kCycleBlocks; ++j)
             for (int pass = 0; pass < 2; ++pass)
@@ -334,8 +269,7 @@ int solve(int device_id, const double *d_rows, uint32_t row_begin, uint32_t n_ro
             SP_TRY(hipStreamSynchronize(stream));
             break;
         }
-        if ((rc = sv.orthonormalise(sv.W.d(), sv.block(0), R, alive))) return rc;
-        note_alive(0);
+        if ((rc = sv.orthonormalise(sv.W.d(), 0))) return rc;
     }
     if (info) *info = inf;
     return SECEDO_OK;

@@ -309,6 +309,76 @@ inline uint32_t grid_for(size_t total) {
     return (uint32_t)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 256 * 16));
 }
 
+// Cholesky factor of a 32 x 32 Gram matrix with column dropping, its inverse, and the product with the
+// factor of an earlier pass -- one workgroup, one thread per matrix element (on the host this cost two
+// synchronisations per block step). A column whose norm is below 1e-13, or whose part outside the span
+// of the columns before it is below 1e-5 of its norm, is dropped: it keeps its coefficients on the
+// surviving directions in R, its row of R and its row and column of R^-1 are zero, so the
+// orthonormalised block W R^-1 has a zero column there.
+// Right-looking elimination on the matrix scaled to unit diagonal. Thread (r, c) keeps element (r, c) in
+// a register; only the pivot row goes through LDS, one barrier per pivot; who is alive is recomputed by
+// every thread from the same values. The inverse is built row by row from the bottom in registers too:
+// thread (col, t) owns X[t][col], a row's inner products are summed by a shuffle tree over 32 lanes.
+__global__ __launch_bounds__(1024) void k_cholesky_drop(const double *G, const double *R_prev, double *Rinv_out,
+                                                       double *R_out, uint32_t *alive_out) {
+    constexpr int N = 32;
+    __shared__ double prow[N][N];  // prow[k][c]: row k of the scaled matrix when k becomes the pivot
+    __shared__ double R[N][N + 1];
+    __shared__ double rdiag_inv[N];
+    const int tid = threadIdx.x, r = tid / N, c = tid % N;
+    const double g_rr = G[r * N + r], g_cc = G[c * N + c];
+    // lanes 0..31 of every wave hold c = 0..31: norm above 1e-13, else an exhausted direction
+    uint32_t alive = (uint32_t)__ballot(g_cc > 1e-26);
+    const double d_r = g_rr > 1e-26 ? sqrt(g_rr) : 0.0, d_c = g_cc > 1e-26 ? sqrt(g_cc) : 0.0;
+    double x = 0.0;  // element (r, c) of the scaled matrix, upper triangle
+    if (r == c) x = 1.0;
+    else if (c > r && ((alive >> r) & 1u) && ((alive >> c) & 1u)) x = G[tid] / (d_r * d_c);
+    double s_own = 0.0;  // element (r, c) of the factor of the scaled matrix
+    if (r == 0) prow[0][c] = x;
+    __syncthreads();
+    for (int k = 0; k < N; ++k) {
+        // every thread takes the same decision from the same LDS word
+        const double piv = prow[k][k];
+        const bool use = ((alive >> k) & 1u) && piv > 1e-10;  // else exhausted, or dependent on the columns before
+        if (((alive >> k) & 1u) && !use) alive &= ~(1u << k);
+        if (use) {
+            // one reciprocal square root instead of a square root and two divisions on the critical path
+            // of 32 dependent pivots (a last-bit difference in R is immaterial: the QR is done twice)
+            const double inv_sk = rsqrt(piv);
+            const double skr = r > k && ((alive >> r) & 1u) ? prow[k][r] * inv_sk : 0.0;
+            const double skc = c > k && ((alive >> c) & 1u) ? prow[k][c] * inv_sk : 0.0;
+            if (r == k) s_own = (c == k) ? piv * inv_sk : skc;
+            if (r > k && c >= r) x -= skr * skc;
+        }
+        if (r == k + 1) prow[k + 1][c] = x;  // the next pivot row is final now
+        __syncthreads();
+    }
+    R[r][c] = (c >= r && ((alive >> r) & 1u)) ? s_own * d_c : 0.0;
+    __syncthreads();
+    if (tid < N) rdiag_inv[tid] = ((alive >> tid) & 1u) ? 1.0 / R[tid][tid] : 0.0;
+    __syncthreads();
+    // R^-1 on the surviving triangle: X[row][col] = (delta - sum_{t > row} R[row][t] X[t][col]) / R[row][row]
+    {
+        const int col = tid / N, t = tid % N;
+        double xt = 0.0;  // X[t][col]
+        const bool col_alive = (alive >> col) & 1u;
+        for (int row = N - 1; row >= 0; --row) {
+            if (!((alive >> row) & 1u)) continue;  // uniform; the row of R^-1 stays zero
+            double v = t > row ? R[row][t] * xt : 0.0;
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (t == row && col >= row && col_alive) xt = ((row == col ? 1.0 : 0.0) - v) * rdiag_inv[row];
+        }
+        Rinv_out[t * N + col] = xt;
+    }
+    double v = R[r][c];
+    if (R_prev) {  // R of the two passes together: this pass's factor times the first one's
+        v = 0.0;
+        for (int t = 0; t < N; ++t) v += R[r][t] * R_prev[t * N + c];
+    }
+    R_out[tid] = v;
+    if (tid < N && alive_out) alive_out[tid] = (alive >> tid) & 1u;
+}
+
 }  // namespace
 
 hipError_t row_sums(const double *A_rows, uint32_t n, uint32_t row_begin, uint32_t n_rows, double *sums,
@@ -367,6 +437,12 @@ hipError_t gram(uint32_t n, const double *Q, size_t blk_stride, uint32_t nblk, c
     const uint32_t chunks = gram_chunks(n);
     hipLaunchKernelGGL(k_gram_partial, dim3(chunks, nblk), dim3(256), 0, stream, n, Q, blk_stride, W, nblk, Gp);
     hipLaunchKernelGGL(k_gram_reduce, dim3(nblk * 4u), dim3(256), 0, stream, chunks, nblk, Gp, G);
+    return hipGetLastError();
+}
+
+hipError_t cholesky_drop(const double *G, const double *R_prev, double *Rinv, double *R, uint32_t *alive,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(k_cholesky_drop, dim3(1), dim3(1024), 0, stream, G, R_prev, Rinv, R, alive);
     return hipGetLastError();
 }
 

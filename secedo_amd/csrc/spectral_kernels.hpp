@@ -49,6 +49,12 @@ hipError_t gram(uint32_t n, const double *Q, size_t blk_stride, uint32_t nblk, c
 hipError_t block_combine(uint32_t n, const double *Q, size_t blk_stride, uint32_t nblk, const double *M,
                          double alpha, double beta, double *out, hipStream_t stream);
 
+// Cholesky factor R (upper triangular, row-major 32 x 32) of a Gram matrix G = W^T W with column dropping
+// (see k_cholesky_drop), Rinv = its inverse on the surviving columns, alive[32] = who survived. With
+// R_prev the R that is written is R * R_prev (the factor of two passes together). All on the device.
+hipError_t cholesky_drop(const double *G, const double *R_prev, double *Rinv, double *R, uint32_t *alive,
+                         hipStream_t stream);
+
 // out (column-major n x k) = the first k columns of Y, each scaled to unit norm and signed so that
 // its component of largest magnitude (lowest index on ties) is positive
 hipError_t write_vectors(uint32_t n, const double *Y, uint32_t k, double *out, hipStream_t stream);

@@ -22,6 +22,35 @@ inline double pythag(double a, double b) {
     return std::hypot(a, b);
 }
 
+// Inner products and updates of the Rayleigh-Ritz step (sym_eig_top is on the critical path of every
+// restart cycle). Eight independent partial sums: the order of the additions is fixed by the code, so
+// the result does not depend on the machine, and the compiler may keep the sums in vector registers
+// (AVX2 clone picked at load time where the CPU has it).
+#if defined(__x86_64__) && defined(__clang__) && !defined(__HIP_DEVICE_COMPILE__)
+#define SECEDO_SIMD_CLONES __attribute__((target_clones("avx2", "default")))
+#else
+#define SECEDO_SIMD_CLONES
+#endif
+
+SECEDO_SIMD_CLONES double dot8(const double *x, const double *y, int n) {
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int i = 0;
+    for (; i + 8 <= n; i += 8)
+        for (int u = 0; u < 8; ++u) s[u] += x[i + u] * y[i + u];
+    for (int u = 0; i < n; ++i, ++u) s[u] += x[i] * y[i];
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+// y += alpha * x
+SECEDO_SIMD_CLONES void axpy(double alpha, const double *x, double *y, int n) {
+    for (int i = 0; i < n; ++i) y[i] += alpha * x[i];
+}
+
+// row -= a * p + b * v   (the symmetric rank-2 update of one row of the lower triangle)
+SECEDO_SIMD_CLONES void rank2_row(double a, const double *p, double b, const double *v, double *row, int n) {
+    for (int i = 0; i < n; ++i) row[i] -= a * p[i] + b * v[i];
+}
+
 // A (n x n, row-major, symmetric) -> tridiagonal (d, e) with A = Q T Q^T; Q^T overwrites A
 void tridiagonalise(int n, std::vector<double> &a, std::vector<double> &d, std::vector<double> &e) {
     std::vector<double> v(n), p(n), q((size_t)n * n, 0.0);
@@ -162,22 +191,14 @@ void tridiagonalise_keep(int n, std::vector<double> &a, std::vector<double> &d, 
         for (int i = k + 1; i < n; ++i) p[i] = 0.0;
         for (int i = k + 1; i < n; ++i) {
             const double *row = &a[(size_t)i * n];
-            const double vi = v[i];
-            double s = row[i] * vi;
-            for (int j = k + 1; j < i; ++j) {
-                s += row[j] * v[j];
-                p[j] += row[j] * vi;
-            }
-            p[i] += s;
+            const int len = i - (k + 1);
+            p[i] += row[i] * v[i] + dot8(row + k + 1, &v[k + 1], len);
+            axpy(v[i], row + k + 1, &p[k + 1], len);
         }
-        double kappa = 0.0;
-        for (int i = k + 1; i < n; ++i) kappa += v[i] * p[i];
-        for (int i = k + 1; i < n; ++i) p[i] -= kappa * v[i];
-        for (int i = k + 1; i < n; ++i) {
-            double *row = &a[(size_t)i * n];
-            const double vi = 2.0 * v[i], pi = 2.0 * p[i];
-            for (int j = k + 1; j <= i; ++j) row[j] -= vi * p[j] + pi * v[j];
-        }
+        const double kappa = dot8(&v[k + 1], &p[k + 1], n - (k + 1));
+        axpy(-kappa, &v[k + 1], &p[k + 1], n - (k + 1));
+        for (int i = k + 1; i < n; ++i)
+            rank2_row(2.0 * v[i], &p[k + 1], 2.0 * p[i], &v[k + 1], &a[(size_t)i * n + k + 1], i - k);
         a[(size_t)(k + 1) * n + k] = alpha;
         for (int i = k + 2; i < n; ++i) a[(size_t)i * n + k] = 0.0;
         for (int i = k + 1; i < n; ++i) vs[(size_t)k * n + i] = v[i];  // reflector k, stored as a row
@@ -369,10 +390,8 @@ bool sym_eig_top(int n, const std::vector<double> &a_in, int k, std::vector<doub
         for (int r = n - 3; r >= 0; --r) {
             if (!used[r]) continue;
             const double *v = &vs[(size_t)r * n];
-            double dot = 0.0;
-            for (int i = r + 1; i < n; ++i) dot += v[i] * x[i];
-            dot *= 2.0;
-            for (int i = r + 1; i < n; ++i) x[i] -= dot * v[i];
+            const int len = n - (r + 1);
+            axpy(-2.0 * dot8(v + r + 1, x + r + 1, len), v + r + 1, x + r + 1, len);
         }
     }
     // accept only what A itself confirms
@@ -380,9 +399,7 @@ bool sym_eig_top(int n, const std::vector<double> &a_in, int k, std::vector<doub
         const double *x = &tv[(size_t)j * n];
         double res = 0.0;
         for (int i = 0; i < n; ++i) {
-            double s = 0.0;
-            const double *row = &a_sym[(size_t)i * n];
-            for (int c = 0; c < n; ++c) s += row[c] * x[c];
+            const double s = dot8(&a_sym[(size_t)i * n], x, n);
             res = std::max(res, std::fabs(s - lam[j] * x[i]));
         }
         if (!(res <= 1e-11 * (tnorm > 0.0 ? tnorm * n : 1.0))) {
@@ -399,10 +416,6 @@ bool sym_eig_top(int n, const std::vector<double> &a_in, int k, std::vector<doub
         for (int i = 0; i < n; ++i) top_vecs[(size_t)i * k + j] = tv[(size_t)j * n + i];
     return true;
 }
-
-namespace {
-
-}  // namespace
 
 bool sym_eig(int n, const std::vector<double> &a_in, std::vector<double> &evals, std::vector<double> &evecs) {
     if (n <= 0) {
