@@ -72,7 +72,8 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
                           double homozygous_rate, double seq_error_rate, uint32_t num_threads,
                           int normalization, double *out);
 /* secedo_simmat_compute keeps its device buffers between calls (one set per device; the reference calls
- * computeSimilarityMatrix once per sub-cluster of its recursion). This frees them. Never required. */
+ * computeSimilarityMatrix once per sub-cluster of its recursion), and so does secedo_em_refine* with its
+ * scratch (secedo_em.h). This frees both. Never required. */
 void secedo_simmat_release_cache(void);
 
 /* ------------------------------------------------------------------------------------------

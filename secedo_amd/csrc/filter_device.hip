@@ -153,7 +153,9 @@ __global__ __launch_bounds__(TPB) void k_compact(FilterIn in, const IdBase *id_b
 }
 
 __global__ void k_chr_offsets(const uint32_t *chr_locus_off, uint32_t n_chr, const uint32_t *locus_rank,
-                              uint32_t n_loci, uint32_t total_kept, uint32_t *out_chr_locus_off) {
+                              uint32_t n_loci, uint32_t total_kept, uint32_t *out_chr_locus_off,
+                              const unsigned long long *entry_rank, unsigned long long *out_locus_entry_off) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_locus_entry_off[total_kept] = entry_rank[n_loci];
     for (uint32_t c = blockIdx.x * TPB + threadIdx.x; c <= n_chr; c += gridDim.x * TPB) {
         const uint32_t l = chr_locus_off[c];
         out_chr_locus_off[c] = l < n_loci ? locus_rank[l] : total_kept;
@@ -211,10 +213,25 @@ std::string filter_device(const DeviceFlatPileup &in, double theta, uint32_t cel
     HIP_OK(hipMemsetAsync(n_unsure, 0, 4, stream));
     const uint32_t wave_grid = static_cast<uint32_t>(std::min<uint64_t>(((uint64_t)L * 64 + TPB - 1) / TPB, 1u << 15));
     hipLaunchKernelGGL(k_decide, dim3(wave_grid), dim3(TPB), 0, stream, fin, theta, th, decision, in_count, counts4, n_unsure);
-    uint32_t h_unsure = 0;
-    HIP_OK(hipMemcpyAsync(&h_unsure, n_unsure, 4, hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));
-    if (h_unsure) {
+    // Ranks of the kept loci and entries. The verdicts are assumed final (a locus whose statistic touches
+    // its threshold is rare): weights, scans and ONE read-back of {unsure, kept loci, kept entries}; only
+    // if a locus was unsure is it decided on the host and the ranking redone.
+    uint32_t total_loci = 0;
+    unsigned long long total_entries = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        hipLaunchKernelGGL(k_weights, dim3(blocks_for(L)), dim3(TPB), 0, stream, decision, in_count, L, keep, kept_entries);
+        HIP_OK(hipMemsetAsync(keep + L, 0, 4, stream));
+        HIP_OK(hipMemsetAsync(kept_entries + L, 0, 8, stream));
+        size_t cap = ws->b.bytes;
+        HIP_OK(hipcub::DeviceScan::ExclusiveSum(ws->b.p, cap, keep, locus_rank, (int)L + 1, stream));
+        cap = ws->b.bytes;
+        HIP_OK(hipcub::DeviceScan::ExclusiveSum(ws->b.p, cap, kept_entries, entry_rank, (int)L + 1, stream));
+        uint32_t h_unsure = 0;
+        if (attempt == 0) HIP_OK(hipMemcpyAsync(&h_unsure, n_unsure, 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(&total_loci, locus_rank + L, 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(&total_entries, entry_rank + L, 8, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        if (!h_unsure) break;
         // the few loci whose statistic touches its threshold: decided with the C library, like the reference
         std::vector<uint32_t> dec(L);
         std::vector<uint4> cnt(L);
@@ -228,18 +245,6 @@ std::string filter_device(const DeviceFlatPileup &in, double theta, uint32_t cel
         }
         HIP_OK(hipMemcpy(decision, dec.data(), (size_t)L * 4, hipMemcpyHostToDevice));
     }
-    hipLaunchKernelGGL(k_weights, dim3(blocks_for(L)), dim3(TPB), 0, stream, decision, in_count, L, keep, kept_entries);
-    HIP_OK(hipMemsetAsync(keep + L, 0, 4, stream));
-    HIP_OK(hipMemsetAsync(kept_entries + L, 0, 8, stream));
-    size_t cap = ws->b.bytes;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(ws->b.p, cap, keep, locus_rank, (int)L + 1, stream));
-    cap = ws->b.bytes;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(ws->b.p, cap, kept_entries, entry_rank, (int)L + 1, stream));
-    uint32_t total_loci = 0;
-    unsigned long long total_entries = 0;
-    HIP_OK(hipMemcpyAsync(&total_loci, locus_rank + L, 4, hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipMemcpyAsync(&total_entries, entry_rank + L, 8, hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));
     if (in.id_base16) {
         hipLaunchKernelGGL((k_compact<uint16_t>), dim3(wave_grid), dim3(TPB), 0, stream, fin, in.id_base16, keep,
                            locus_rank, entry_rank, out.locus_pos, reinterpret_cast<unsigned long long *>(out.locus_entry_off),
@@ -249,10 +254,10 @@ std::string filter_device(const DeviceFlatPileup &in, double theta, uint32_t cel
                            locus_rank, entry_rank, out.locus_pos, reinterpret_cast<unsigned long long *>(out.locus_entry_off),
                            out.read_ids, static_cast<uint32_t *>(out.id_base));
     }
+    // ... and the closing offset of the last kept locus
     hipLaunchKernelGGL(k_chr_offsets, dim3(1), dim3(TPB), 0, stream, in.chr_locus_off, in.n_chr, locus_rank, L,
-                       total_loci, out.chr_locus_off);
-    // the closing offset of the last kept locus
-    HIP_OK(hipMemcpyAsync(out.locus_entry_off + total_loci, &total_entries, 8, hipMemcpyHostToDevice, stream));
+                       total_loci, out.chr_locus_off, entry_rank,
+                       reinterpret_cast<unsigned long long *>(out.locus_entry_off));
     HIP_OK(hipStreamSynchronize(stream));
     *n_loci_out = total_loci;
     *n_entries_out = total_entries;

@@ -306,15 +306,30 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     uint32_t n_la = 0, n_lb = 0, n_ib = 0, n_ie = 0, n_jb = 0, n_je = 0, n_dsh = 0;
     bool n_staged = false;
 
+    // Range boundaries run ahead of the pairing so that their two dependent reads (locus span -> entry
+    // offsets of the two blocks) are never waited for. One register holds them all, a value per lane:
+    // lanes 0-3 the offsets of the next range (row begin, row end, column begin, column end), lanes 4-5
+    // the locus span of the range after it; it is loaded while the current range is paired.
+    uint32_t q_la = 0, q_lb = 0;  // locus span of the range `ahead` holds the offsets of
+    uint32_t ahead = 0;
+    auto fetch_ahead = [&](uint32_t r) {  // r: the range with span (q_la, q_lb)
+        const uint32_t *src = lane == 0u ? offI + q_la : lane == 1u ? offI + q_lb : lane == 2u ? offJ + q_la
+                            : lane == 3u ? offJ + q_lb : a.range_off + (r + lane - 3u);  // lanes 4, 5: r + 1, r + 2
+        ahead = 0u;
+        if (lane < 4u || (lane < 6u && r + 1u < r_end)) ahead = *src;
+    };
     auto prefetch = [&](uint32_t r) {
-        n_la = __builtin_amdgcn_readfirstlane(a.range_off[r]);  // wave-uniform: keep them in SGPRs
-        n_lb = __builtin_amdgcn_readfirstlane(a.range_off[r + 1]);
-        const uint32_t range_ib = __builtin_amdgcn_readfirstlane(offI[n_la]);
+        n_la = q_la;
+        n_lb = q_lb;
+        const uint32_t range_ib = __builtin_amdgcn_readlane(ahead, 0);
         n_ib = max(range_ib, row_begin);  // this chunk's part of the range's row side
-        n_ie = max(n_ib, min((uint32_t)__builtin_amdgcn_readfirstlane(offI[n_lb]), row_end));
+        n_ie = max(n_ib, min((uint32_t)__builtin_amdgcn_readlane(ahead, 1), row_end));
         n_dsh = n_ib - range_ib;
-        n_jb = __builtin_amdgcn_readfirstlane(offJ[n_la]);
-        n_je = __builtin_amdgcn_readfirstlane(offJ[n_lb]);
+        n_jb = __builtin_amdgcn_readlane(ahead, 2);
+        n_je = __builtin_amdgcn_readlane(ahead, 3);
+        q_la = __builtin_amdgcn_readlane(ahead, 4);
+        q_lb = __builtin_amdgcn_readlane(ahead, 5);
+        if (r + 1u < r_end) fetch_ahead(r + 1u);
         n_staged = (n_je - n_jb) <= (uint32_t)CAPJ && (n_lb - n_la) <= (uint32_t)CAPL;
         if (n_staged) {
 #pragma unroll
@@ -339,7 +354,12 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
         }
     };
 
-    if (r_begin < r_end) prefetch(r_begin);
+    if (r_begin < r_end) {
+        q_la = __builtin_amdgcn_readfirstlane(a.range_off[r_begin]);
+        q_lb = __builtin_amdgcn_readfirstlane(a.range_off[r_begin + 1u]);
+        fetch_ahead(r_begin);
+        prefetch(r_begin);
+    }
     STAMP(t_pro);
     for (uint32_t r = r_begin; r < r_end; ++r) {
         const uint32_t la = n_la, lb = n_lb, ib = n_ib, ie = n_ie, jb = n_jb, je = n_je, dsh = n_dsh;
