@@ -78,6 +78,9 @@ def main():
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 "
                          "flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--tiles", action="store_true",
+                    help="N > 1: deal out the output tiles (replicated packing + all-gather) even when the pileup "
+                         "has chromosomes enough to be split by chromosomes (the default then)")
     ap.add_argument("--packed-resident", action="store_true",
                     help="keep the PACKED pileup resident and leave the packing out of the step "
                          "(steady state of repeated accumulations; default: the step starts from the raw "
@@ -107,19 +110,37 @@ def main():
     mfl, threads, rates, norm = 1000, 8, (0.01, 0.5, 0.01), "ADD_MIN"
     p = synth_config(args.workload, clustered=args.clustered)
 
+    # N > 1, strong scaling of ONE matrix. With chromosomes enough the pileup is split by chromosomes (reads,
+    # flushes and the tail rule never cross one): a rank packs and accumulates only its chromosomes, for all
+    # tiles, and the int64 accumulators are summed by one all-reduce -- the packing is divided too.
+    # Otherwise the tiles are dealt out, every rank packs the whole pileup, one all-gather.
+    by_chromosome = world > 1 and p.n_chr >= world and not args.tiles
+    mine = sd.chromosome_shard(p, rank, world) if by_chromosome else p
+
     plan = secedo_amd.SimilarityMatrixPlan(local_rank)
-    resident = plan.upload(p, None, n_cells)  # the raw flat pileup, in HBM before the clock starts
+    resident = plan.upload(mine, None, n_cells)  # the raw flat pileup, in HBM before the clock starts
     t0 = time.perf_counter()
     plan.prepare_resident(resident, n_cells, mfl, threads)
     torch.cuda.synchronize()
     prepare_s = time.perf_counter() - t0
-    acc = plan.new_acc(pad_tiles_to=world)
+    block_cells = 0  # the library's choice
+    if by_chromosome:
+        # the ranks must agree on the tile edge (it is chosen from the shard's statistics): the smallest
+        b = torch.tensor([plan.block_cells], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(b, op=dist.ReduceOp.MIN)
+        block_cells = int(b.item())
+        plan.prepare_resident(resident, n_cells, mfl, threads, block_cells)
+    acc = plan.new_acc(pad_tiles_to=1 if by_chromosome else world)
     out = torch.empty((n_cells, n_cells), dtype=torch.float64, device="cuda:%d" % local_rank)
+    my_tiles = (0, plan.num_tiles) if by_chromosome else sd.tile_range(plan.num_tiles, rank, world)
 
     def step():
         if not args.packed_resident:
-            plan.prepare_resident(resident, n_cells, mfl, threads)
-        sd.sharded_accumulate(plan, acc, *rates, rank, world)
+            plan.prepare_resident(resident, n_cells, mfl, threads, block_cells)
+        if by_chromosome:
+            sd.chromosome_sharded_accumulate(plan, acc, *rates, world)
+        else:
+            sd.sharded_accumulate(plan, acc, *rates, rank, world)
         plan.finalize(acc, norm, out)
 
     def sync():
@@ -144,17 +165,18 @@ def main():
 
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    cnt = torch.tensor([local_updates, local_pairs], dtype=torch.int64, device=red_dev)
+    cnt = torch.tensor([local_updates, local_pairs, plan.num_entries if by_chromosome or rank == 0 else 0,
+                        plan.num_reads if by_chromosome or rank == 0 else 0], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
-    updates, pairs = int(cnt[0].item()), int(cnt[1].item())
+    updates, pairs, kept_entries, reads = (int(v.item()) for v in cnt)
 
     # phase times of one step, events on the launch stream (torch's current one)
     phase = {}
     def repack():
-        plan.prepare_resident(resident, n_cells, mfl, threads)
+        plan.prepare_resident(resident, n_cells, mfl, threads, block_cells)
 
     def refinalize():
         plan.finalize(acc, norm, out)
@@ -162,7 +184,7 @@ def main():
     for name, fn in (("pack_ms", repack), ("finalize_ms", refinalize)):
         ts = []
         if name == "finalize_ms":
-            plan.accumulate(acc, *rates, *sd.tile_range(plan.num_tiles, rank, world))
+            plan.accumulate(acc, *rates, *my_tiles)
         for _ in range(5):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -172,7 +194,7 @@ def main():
             ts.append(a.elapsed_time(b))
         phase[name] = sorted(ts)[len(ts) // 2]
     # per-launch kernel time over K launches with events on the launch stream
-    lo, hi = sd.tile_range(plan.num_tiles, rank, world)
+    lo, hi = my_tiles
     evs = []
     for _ in range(min(args.steps, 10)):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -194,7 +216,9 @@ def main():
         except (OSError, ValueError, KeyError):
             traffic = None
         E, L, N = plan.num_entries, plan.num_loci, n_cells
-        b_alg = 16 * local_updates + 6 * E / world + 4 * L + 16 * N * N / world  # this rank's launch
+        # this rank's launch: its tiles of the whole pileup, or all tiles of its chromosomes
+        b_alg = (16 * local_updates + 6 * E + 4 * L + 16 * N * N if by_chromosome
+                 else 16 * local_updates + 6 * E / world + 4 * L + 16 * N * N / world)
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "cell-pair x locus updates/sec (similarity matrix)",
@@ -211,14 +235,15 @@ def main():
             "data": "synthetic (SYNTH-v1, seed 42)",
             "config": {"workload": "%s: %d cells x %d loci%s" % (
                 args.workload, n_cells, n_loci, " clustered" if args.clustered else ""),
-                "entries": int(p.n_entries), "kept_entries": E, "reads": plan.num_reads,
+                "entries": int(p.n_entries), "kept_entries": kept_entries, "reads": reads,
                 "updates_per_step": updates, "read_pairs_per_step": pairs,
                 "block_cells": plan.block_cells, "tiles": plan.num_tiles,
                 "normalization": norm, "max_fragment_length": mfl, "num_threads": threads,
-                "parallelism": "tiles/%d + all-gather" % world if world > 1 else "single GPU",
-                # strong scaling of one matrix: every rank packs the whole pileup (the read structure is
-                # global), only the pair accumulation is divided
-                "replicated_ms_per_step": phase.get("pack_ms") if world > 1 else None},
+                "parallelism": ("single GPU" if world == 1 else
+                                "chromosomes/%d (packing + accumulation) + all-reduce of the int64 accumulator" % world
+                                if by_chromosome else "tiles/%d + all-gather" % world),
+                # tiles mode: every rank packs the whole pileup, only the pair accumulation is divided
+                "replicated_ms_per_step": phase.get("pack_ms") if world > 1 and not by_chromosome else None},
             "wall_s_full_matrix": elapsed / args.steps,
             "dense_equivalent_cell_pair_locus_slots_per_s":
                 n_cells * (n_cells - 1) / 2 * n_loci * args.steps / elapsed,

@@ -1,10 +1,21 @@
 """Multi-GPU driver of the similarity-matrix path: one process per GPU, RCCL over xGMI.
 
-The output tiles (upper-triangular cell-block pairs) are independent, so they are dealt to the
-ranks in contiguous ranges; the pileup is small (<= 0.4 GB packed) and is replicated. The only
-exchange is one all-gather of the tile-major int64 accumulator, after which
-every rank normalises and mirrors the full matrix locally -- integer accumulators make the result
-bit-identical for any number of ranks.
+Two ways to share one matrix among the ranks, both exact (integer accumulators make the result
+bit-identical for any number of ranks):
+
+* by output tiles (sharded_accumulate): the upper-triangular cell-block pairs are independent, so they
+  are dealt to the ranks in contiguous ranges; the pileup is replicated and packed by every rank; one
+  all-gather of the tile-major int64 accumulator.
+* by chromosomes (chromosome_shard + chromosome_sharded_accumulate): reads, flushes and the tail rule
+  never cross a chromosome (reference similarity_matrix.cpp:345-408 walks the chromosomes one after the
+  other and empties its read table after each, :407-408; the `completed` counter it carries over, :344,
+  is below the flush threshold there and is overtaken by the real count before it can trigger a flush:
+  completed = max(carried, complete reads), tests/test_distributed_cpu.py checks the sum against the
+  oracle, which carries it), so the sum over loci splits at chromosome boundaries: every rank packs and accumulates ONLY its chromosomes -- the packing, which is two
+  thirds of a 1000-cell step, is divided too -- for all tiles, and one all-reduce (sum) of the
+  accumulator replaces the all-gather. bench.py uses this one when there are chromosomes enough.
+
+Either way every rank then normalises and mirrors the full matrix locally.
 """
 from __future__ import annotations
 
@@ -46,6 +57,56 @@ def sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate
             acc.copy_(gathered)
         else:
             dist.all_gather_into_tensor(acc, mine.clone(), group=group)
+    return acc
+
+
+def chromosome_cuts(chr_locus_off, locus_entry_off, world):
+    """world + 1 chromosome indices: rank r takes chromosomes [cuts[r], cuts[r + 1]). Contiguous, each
+    cut at the chromosome boundary nearest to an equal share of the entries (a rank may get none)."""
+    import numpy as np
+    chr_off = np.asarray(chr_locus_off, dtype=np.int64)
+    ent = np.asarray(locus_entry_off, dtype=np.int64)[chr_off]  # entries before each chromosome boundary
+    total = int(ent[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        c = int(np.argmin(np.abs(ent - target)))
+        cuts.append(max(c, cuts[-1]))
+    cuts.append(len(chr_off) - 1)
+    return cuts
+
+
+def chromosome_shard(p, rank, world):
+    """The chromosomes of `rank` as a FlatPileup of their own (views of the entry arrays, offsets
+    rebased). Position-sorted pileups keep their order; read ids need no change (they are scoped to a
+    chromosome already)."""
+    import numpy as np
+    from .pileup import FlatPileup
+    cuts = chromosome_cuts(p.chr_locus_off, p.locus_entry_off, world)
+    c0, c1 = cuts[rank], cuts[rank + 1]
+    l0, l1 = int(p.chr_locus_off[c0]), int(p.chr_locus_off[c1])
+    e0, e1 = int(p.locus_entry_off[l0]), int(p.locus_entry_off[l1])
+    return FlatPileup((p.chr_locus_off[c0:c1 + 1].astype(np.int64) - l0).astype(np.uint32), p.locus_pos[l0:l1],
+                      (p.locus_entry_off[l0:l1 + 1] - np.uint64(e0)).astype(np.uint64), p.read_ids[e0:e1],
+                      p.id_base[e0:e1])
+
+
+def chromosome_sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate, world, group=None):
+    """`plan` holds this rank's chromosomes (chromosome_shard; the same block_cells on every rank):
+    accumulate all tiles over them into the zeroed `acc`, then sum the accumulators of all ranks."""
+    import torch.distributed as dist
+
+    n = plan.acc_elems
+    acc[:n].zero_()
+    if plan.num_entries:
+        plan.accumulate(acc, mutation_rate, homozygous_rate, seq_error_rate)
+    if world > 1:
+        if acc.is_cuda and dist.get_backend(group) != "nccl":
+            summed = acc[:n].cpu()  # rehearsal backends (gloo) move host memory
+            dist.all_reduce(summed, op=dist.ReduceOp.SUM, group=group)
+            acc[:n].copy_(summed)
+        else:
+            dist.all_reduce(acc[:n], op=dist.ReduceOp.SUM, group=group)
     return acc
 
 

@@ -89,3 +89,73 @@ def test_row_ranges_partition_the_matrix():
             assert aligned[0][0] == 0 and aligned[-1][1] == n
             assert all(aligned[r][1] == aligned[r + 1][0] for r in range(world - 1))
             assert all(lo % 128 == 0 or lo == n for lo, _ in aligned)
+
+
+def test_chromosome_shards_sum_to_the_whole_matrix():
+    """The chromosome split is exact: the raw (pre-normalisation) matrices of the shards, computed by the
+    oracle -- which carries the reference's `completed` counter from chromosome to chromosome -- add up to
+    the raw matrix of the whole pileup (up to the rounding of the oracle's double sums, 1e-13; the device
+    path accumulates integers and is compared bit for bit in tests/test_gpu_distributed.py); shards are
+    contiguous, disjoint and cover everything."""
+    from oracle import bindings as ob
+    from tests.pileup_gen import random_pileup
+    n = 40
+    for seed, n_chr, mfl, threads in ((5, 5, 1000, 1), (6, 7, 150, 2), (7, 3, 1000, 8)):
+        p = random_pileup(seed, n, n_chr, 120, 12, 200, dup_frac=0.05, triple_frac=0.2)
+        _, raw = ob.oracle_compute(p, n, mfl, None, 0.01, 0.5, 0.02, threads, "ADD_MIN", want_raw=True)
+        for world in (2, 3, 4, 9):
+            cuts = sd.chromosome_cuts(p.chr_locus_off, p.locus_entry_off, world)
+            assert cuts[0] == 0 and cuts[-1] == p.n_chr and all(a <= b for a, b in zip(cuts, cuts[1:]))
+            total = np.zeros_like(raw)
+            entries = 0
+            for r in range(world):
+                shard = sd.chromosome_shard(p, r, world)
+                entries += shard.n_entries
+                assert shard.n_chr == cuts[r + 1] - cuts[r]
+                if shard.n_entries:
+                    _, part = ob.oracle_compute(shard, n, mfl, None, 0.01, 0.5, 0.02, threads, "ADD_MIN",
+                                                want_raw=True)
+                    total += part
+            assert entries == p.n_entries
+            assert np.max(np.abs(total - raw)) <= 1e-11 * max(1.0, np.max(np.abs(raw)))
+
+
+class FakeShardPlan:
+    """accumulate() adds rank + 1 to every element: the all-reduce must leave 1 + 2 + ... + world."""
+
+    def __init__(self, rank, n):
+        self.rank, self.acc_elems, self.num_entries = rank, n, 1
+
+    def accumulate(self, acc, eps, h, theta):
+        acc[:self.acc_elems] += self.rank + 1
+
+
+def _shard_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        acc = torch.full((48,), -3, dtype=torch.int64)  # garbage that must disappear; 8 elements of padding
+        sd.chromosome_sharded_accumulate(FakeShardPlan(rank, 40), acc, 0.01, 0.5, 0.01, world)
+        ok = bool(torch.all(acc[:40] == world * (world + 1) // 2))
+        flags = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(flags, torch.tensor([int(ok)], dtype=torch.int64))
+        if rank == 0:
+            out.put([int(f.item()) for f in flags])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chromosome_sharded_accumulate_gloo_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) == [1, 1]

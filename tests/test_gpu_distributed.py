@@ -124,3 +124,54 @@ def test_two_ranks_reproduce_single_process_bitwise(tmp_path):
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / ("rank%d.npy" % r)), single)
     assert np.any(single != 0)
+
+
+def _chromosome_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import secedo_amd
+        from secedo_amd import distributed as sd
+        from tests.pileup_gen import random_pileup
+
+        n = 300
+        p = random_pileup(611, n, 7, 150, 50, 800, dup_frac=0.03, triple_frac=0.2)  # 7 chromosomes
+        torch.cuda.set_device(0)
+        with secedo_amd.SimilarityMatrixPlan(0) as plan:
+            shard = sd.chromosome_shard(p, rank, world)
+            plan.prepare(shard, n, 400, None, 2, block_cells=64)  # reads longer than mfl: flushes cut them
+            acc = plan.new_acc()
+            acc.fill_(-5)  # garbage that the sharded path must overwrite
+            sd.chromosome_sharded_accumulate(plan, acc, 0.01, 0.5, 0.01, world)
+            np.save(os.path.join(out_dir, "acc%d.npy" % rank), acc.cpu().numpy())
+            np.save(os.path.join(out_dir, "rank%d.npy" % rank), plan.finalize(acc, "ADD_MIN").cpu().numpy())
+            if rank == 0:
+                plan.prepare(p, n, 400, None, 2, block_cells=64)
+                full = plan.new_acc()
+                plan.accumulate(full, 0.01, 0.5, 0.01)
+                np.save(os.path.join(out_dir, "acc_single.npy"), full.cpu().numpy())
+                np.save(os.path.join(out_dir, "single.npy"), plan.finalize(full, "ADD_MIN").cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chromosome_shards_reproduce_single_process_bitwise(tmp_path):
+    """Every rank packs and accumulates only its chromosomes (all tiles), the int64 accumulators are summed
+    by an all-reduce: the accumulator and the matrix equal the single-process ones bit for bit."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    world = 3
+    procs = [ctx.Process(target=_chromosome_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    acc_single, single = np.load(tmp_path / "acc_single.npy"), np.load(tmp_path / "single.npy")
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("acc%d.npy" % r)), acc_single)
+        assert np.array_equal(np.load(tmp_path / ("rank%d.npy" % r)), single)
+    assert np.any(single != 0)
