@@ -10,8 +10,8 @@ bit-identical for any number of ranks):
   never cross a chromosome (reference similarity_matrix.cpp:345-408 walks the chromosomes one after the
   other and empties its read table after each, :407-408; the `completed` counter it carries over, :344,
   is below the flush threshold there and is overtaken by the real count before it can trigger a flush:
-  completed = max(carried, complete reads), tests/test_distributed_cpu.py checks the sum against the
-  oracle, which carries it), so the sum over loci splits at chromosome boundaries: every rank packs and accumulates ONLY its chromosomes -- the packing, which is two
+  completed = max(carried, complete reads); tests/test_distributed_cpu.py checks the sum against a CPU
+  restatement of the reference that carries it), so the sum over loci splits at chromosome boundaries: every rank packs and accumulates ONLY its chromosomes -- the packing, which is two
   thirds of a 1000-cell step, is divided too -- for all tiles, and one all-reduce (sum) of the
   accumulator replaces the all-gather. bench.py uses this one when there are chromosomes enough.
 
