@@ -202,13 +202,19 @@ __device__ __forceinline__ uint32_t count_le(const uint32_t *a, uint32_t n, uint
     return lo;
 }
 
-// entry -> locus, one wave per locus (coalesced; empty loci cost nothing)
-__global__ __launch_bounds__(TPB) void k_entry_locus(Raw in, uint32_t *entry_locus) {
+// entry -> locus, one wave per locus (coalesced; empty loci cost nothing); lane 0 also checks that the
+// positions increase strictly inside a chromosome (the reference asserts it, similarity_matrix.cpp:398)
+__global__ __launch_bounds__(TPB) void k_entry_locus(Raw in, uint32_t *entry_locus, Scalars *sc) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
     for (uint32_t l = wave; l < in.n_loci; l += n_waves) {
         const uint32_t b = (uint32_t)in.locus_entry_off[l], e = (uint32_t)in.locus_entry_off[l + 1];
         for (uint32_t i = b + lane; i < e; i += 64u) entry_locus[i] = l;
+        if (lane == 0u && l + 1 < in.n_loci && in.locus_pos[l + 1] <= in.locus_pos[l]) {
+            // allowed only across a chromosome boundary
+            const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
+            if (l + 1 < in.chr_locus_off[c + 1]) sc->error = 3;
+        }
     }
 }
 
@@ -216,15 +222,17 @@ __global__ __launch_bounds__(TPB) void k_entry_locus(Raw in, uint32_t *entry_loc
 // memory is the neutral element). A workgroup owns a contiguous chunk of entries and cuts it at the
 // chromosome boundaries: one pair of atomics per (workgroup, chromosome) -- same-address atomics
 // are slow.
-__global__ __launch_bounds__(TPB) void k_id_range(Raw in, uint32_t *id_max, uint32_t *id_negmin) {
+__global__ __launch_bounds__(TPB) void k_id_range(Raw in, const uint32_t *entry_locus, uint32_t *id_max,
+                                                 uint32_t *id_negmin) {
     __shared__ uint32_t s_hi[TPB / 64], s_neg[TPB / 64];
     const uint32_t E = in.n_entries;
     const uint32_t chunk = (E + gridDim.x - 1) / gridDim.x;
     uint32_t cur = min(E, blockIdx.x * chunk);
     const uint32_t e1 = min(E, cur + chunk);
     if (cur >= e1) return;
-    uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1,
-                                   last_le<uint64_t>(in.locus_entry_off, in.n_loci + 1, (uint64_t)cur));
+    // (the locus of the first entry from k_entry_locus' table: a binary search over the loci here is 16
+    // dependent reads in front of every workgroup's chunk and was most of this kernel's time)
+    uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, entry_locus[cur]);
     while (cur < e1) {
         // entries of chromosome c end where its last locus ends (skip chromosomes without entries)
         uint32_t c_end = (uint32_t)in.locus_entry_off[in.chr_locus_off[c + 1]];
@@ -350,16 +358,6 @@ __global__ void k_id_rank(Raw in, const uint32_t *dense, const uint32_t *id_off,
         skey[b + rank] = d;  // equal keys <=> same read; ascending in (chromosome, read id)
         sval[b + rank] = e;
         sloc[b + rank] = sloc_pack(entry_locus[e], in.id_base(e));  // the one gather by entry index
-    }
-}
-
-__global__ void k_check_positions(Raw in, Scalars *sc) {
-    for (uint32_t l = blockIdx.x * TPB + threadIdx.x; l + 1 < in.n_loci; l += gridDim.x * TPB) {
-        if (in.locus_pos[l + 1] <= in.locus_pos[l]) {
-            // allowed only across a chromosome boundary
-            const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
-            if (l + 1 < in.chr_locus_off[c + 1]) sc->error = 3;
-        }
     }
 }
 
@@ -1043,10 +1041,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     // ---- 1: entries grouped by (chromosome, read id), pileup order inside a read ---------------
     const HostTrace trace;
     trace.mark("begin");
-    hipLaunchKernelGGL(k_check_positions, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, sc);
-    hipLaunchKernelGGL(k_entry_locus, dim3(blocks_for((uint64_t)L * 64)), dim3(TPB), 0, stream, raw, eloc);
+    hipLaunchKernelGGL(k_entry_locus, dim3(blocks_for((uint64_t)L * 64)), dim3(TPB), 0, stream, raw, eloc, sc);
     hipLaunchKernelGGL(k_id_range, dim3(std::min<uint32_t>(1024, (E + 4095) / 4096)), dim3(TPB), 0, stream, raw,
-                       id_max, id_negmin);
+                       eloc, id_max, id_negmin);
     // The size of the id space decides between the counting scheme and the radix sort and sizes the
     // histogram. A handle that has packed before assumes the size of the previous call and does not wait
     // (k_id_bases raises Scalars::id_exceeded if that was too small: the attempt is then void and

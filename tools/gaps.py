@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """gaps.py <rocprofv3 out dir> -- busy time and idle gaps on the GPU per bench step, from the newest
-*kernel_trace.csv under the directory (the steps are delimited by k_check_positions, the first
+*kernel_trace.csv under the directory (the steps are delimited by k_entry_locus, the first
 kernel of the device packing)."""
 import csv, glob, os, sys
 f = sorted(glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))
-starts = [i for i, r in enumerate(rows) if "k_check_positions" in r[2]]
+starts = [i for i, r in enumerate(rows) if "k_entry_locus" in r[2]]
 steps = []
 for a, b in zip(starts[2:-1], starts[3:]):  # skip warm-up
     seg = rows[a:b]
