@@ -317,8 +317,7 @@ inline uint32_t grid_for(size_t total) {
 // orthonormalised block W R^-1 has a zero column there.
 // Right-looking elimination on the matrix scaled to unit diagonal. Thread (r, c) keeps element (r, c) in
 // a register; only the pivot row goes through LDS, one barrier per pivot; who is alive is recomputed by
-// every thread from the same values. The inverse is built row by row from the bottom in registers too:
-// thread (col, t) owns X[t][col], a row's inner products are summed by a shuffle tree over 32 lanes.
+// every thread from the same values. The inverse is built in registers too, a row per thread.
 __global__ __launch_bounds__(1024) void k_cholesky_drop(const double *G, const double *R_prev, double *Rinv_out,
                                                        double *R_out, uint32_t *alive_out) {
     constexpr int N = 32;
@@ -357,18 +356,22 @@ __global__ __launch_bounds__(1024) void k_cholesky_drop(const double *G, const d
     __syncthreads();
     if (tid < N) rdiag_inv[tid] = ((alive >> tid) & 1u) ? 1.0 / R[tid][tid] : 0.0;
     __syncthreads();
-    // R^-1 on the surviving triangle: X[row][col] = (delta - sum_{t > row} R[row][t] X[t][col]) / R[row][row]
-    {
-        const int col = tid / N, t = tid % N;
-        double xt = 0.0;  // X[t][col]
-        const bool col_alive = (alive >> col) & 1u;
-        for (int row = N - 1; row >= 0; --row) {
-            if (!((alive >> row) & 1u)) continue;  // uniform; the row of R^-1 stays zero
-            double v = t > row ? R[row][t] * xt : 0.0;
-            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if (t == row && col >= row && col_alive) xt = ((row == col ? 1.0 : 0.0) - v) * rdiag_inv[row];
+    // R^-1 on the surviving triangle from X R = I: thread `row` (32 threads) builds row `row` of X left to
+    // right, X[row][c] = (delta - sum_{t < c} X[row][t] R[t][c]) / R[c][c], in registers (the loops are
+    // unrolled; every thread reads the same R[t][c]: an LDS broadcast) -- no cross-lane sums
+    if (tid < N) {
+        const int row = tid;
+        const bool row_alive = (alive >> row) & 1u;
+        double xr[N];
+#pragma unroll
+        for (int col = 0; col < N; ++col) {
+            double v = col == row ? 1.0 : 0.0;
+#pragma unroll
+            for (int t = 0; t < col; ++t) v -= xr[t] * R[t][col];
+            xr[col] = (col >= row && row_alive && ((alive >> col) & 1u)) ? v * rdiag_inv[col] : 0.0;
         }
-        Rinv_out[t * N + col] = xt;
+#pragma unroll
+        for (int col = 0; col < N; ++col) Rinv_out[row * N + col] = xr[col];
     }
     double v = R[r][c];
     if (R_prev) {  // R of the two passes together: this pass's factor times the first one's
