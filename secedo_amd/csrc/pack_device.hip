@@ -34,6 +34,7 @@ DevicePacked::~DevicePacked() {
     if (side) (void)hipStreamDestroy(side);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_offsets) (void)hipEventDestroy(ev_offsets);
     if (mailbox) (void)hipHostFree(mailbox);
 }
 
@@ -800,12 +801,17 @@ struct CapChoice {
     }
 };
 
+// The pair bound that decides between the two sets of limits comes out of the grouping that is still
+// running when the offsets are ready, so the ranges are cut for BOTH sets (blockIdx.y: 0 plain, 1 count
+// tile) on the side stream meanwhile, and k_ranges_compact picks one.
 __global__ __launch_bounds__(TPB) void k_ranges_segment(const uint32_t *blk_off, uint32_t nb, uint32_t L,
-                                                       CapChoice caps, const Scalars *sc,
-                                                       uint32_t *seg_ends, uint32_t *seg_count) {
-    const bool use_counts = caps.counts(sc);
+                                                       CapChoice caps, uint32_t *seg_ends_both,
+                                                       uint32_t *seg_count_both, size_t variant_stride) {
+    const bool use_counts = blockIdx.y == 1u;
     const uint32_t cap_entries = use_counts ? caps.entries_counts : caps.entries_plain;
     const uint32_t cap_loci = use_counts ? caps.loci_counts : caps.loci_plain;
+    uint32_t *seg_ends = seg_ends_both + blockIdx.y * variant_stride;
+    uint32_t *seg_count = seg_count_both + blockIdx.y * variant_stride;
     const size_t stride = (size_t)L + 1;
     const uint32_t seg = blockIdx.x;
     if ((unsigned long long)seg * cap_loci >= L) {  // the grid is sized for the smaller of the two limits
@@ -866,10 +872,13 @@ __global__ __launch_bounds__(TPB) void k_ranges_segment(const uint32_t *blk_off,
     if (threadIdx.x == 0) seg_count[seg] = nr;
 }
 
-__global__ __launch_bounds__(TPB) void k_ranges_compact(const uint32_t *seg_ends, const uint32_t *seg_count,
-                                                       uint32_t n_seg, CapChoice caps, uint32_t *range_off,
-                                                       Scalars *sc) {
-    const uint32_t cap_loci = caps.counts(sc) ? caps.loci_counts : caps.loci_plain;
+__global__ __launch_bounds__(TPB) void k_ranges_compact(const uint32_t *seg_ends_both, const uint32_t *seg_count_both,
+                                                       size_t variant_stride, uint32_t n_seg, CapChoice caps,
+                                                       uint32_t *range_off, Scalars *sc) {
+    const bool use_counts = caps.counts(sc);
+    const uint32_t cap_loci = use_counts ? caps.loci_counts : caps.loci_plain;
+    const uint32_t *seg_ends = seg_ends_both + (use_counts ? variant_stride : 0);
+    const uint32_t *seg_count = seg_count_both + (use_counts ? variant_stride : 0);
     __shared__ uint32_t s_base;
     if (threadIdx.x == 0) {
         s_base = 0;
@@ -1113,6 +1122,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         HIP_OK(hipStreamCreateWithFlags(&pk.side, hipStreamNonBlocking));
         HIP_OK(hipEventCreateWithFlags(&pk.ev_fork, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&pk.ev_join, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&pk.ev_offsets, hipEventDisableTiming));
     }
     // reads from the current `split` flags, then completed counts and the flush chain. The chain is
     // sequential (one lane per chromosome) and only the final gather needs its result: it runs on a
@@ -1229,6 +1239,31 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *blk_cnt = S[KEY_A].as<uint32_t>();  // mark / arank are dead after k_ranks
     // counting path: per pileup entry its k and cell (entry -> locus and the per-read scratch are dead)
     unsigned long long *entry_kc = force_radix ? nullptr : S[ENTRY_KC].as<unsigned long long>();
+    // The pair bound decides the tile variant, and the tile variant the staging limits of the locus ranges;
+    // the bound comes out of the grouping below, the ranges need only the offsets: they are cut for both
+    // sets of limits on the side stream while the grouping runs (k_ranges_segment), and picked afterwards.
+    CapChoice caps;
+    caps.entries_plain = pk.stage_masks ? geo.cap_entries_masks : geo.cap_entries_plain;
+    caps.loci_plain = pk.stage_masks ? geo.cap_loci_masks : geo.cap_loci_plain;
+    caps.entries_counts = geo.cap_entries_counts;
+    caps.loci_counts = geo.cap_loci_counts;
+    caps.count_limit = kCountTileLimit;
+    caps.allow_counts = (allow_count_tile && !pk.stage_masks) ? 1u : 0u;
+    const uint32_t lo_loci = caps.allow_counts ? std::min(caps.loci_plain, caps.loci_counts) : caps.loci_plain;
+    const uint32_t hi_loci = caps.allow_counts ? std::max(caps.loci_plain, caps.loci_counts) : caps.loci_plain;
+    const uint32_t n_seg = (L + lo_loci - 1) / lo_loci;
+    const size_t variant_stride = (size_t)n_seg * hi_loci + n_seg + 2;
+    HIP_OK(S[ELOC].ensure(std::max<size_t>((size_t)E * 4, 2 * variant_stride * 4)));
+    uint32_t *seg_count = S[ELOC].as<uint32_t>();  // entry -> locus is dead after k_csr
+    uint32_t *seg_ends = seg_count + n_seg;
+    auto cut_ranges_on_side = [&]() -> std::string {  // call when blk_off is complete on `stream`
+        HIP_OK(hipEventRecord(pk.ev_offsets, stream));
+        HIP_OK(hipStreamWaitEvent(pk.side, pk.ev_offsets, 0));
+        hipLaunchKernelGGL(k_ranges_segment, dim3(n_seg, caps.allow_counts ? 2u : 1u), dim3(TPB), 0, pk.side, blk_off, nb,
+                           L, caps, seg_ends, seg_count, variant_stride);
+        HIP_OK(hipEventRecord(pk.ev_join, pk.side));
+        return std::string();
+    };
     if (force_radix) HIP_OK(hipMemsetAsync(blk_cnt, 0, (n_off + 1) * 4, stream));
     HIP_OK(hipMemsetAsync(per_cell_sq, 0, ((size_t)nb * B + 1) * 8, stream));
     hipLaunchKernelGGL(k_keys2, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, incl, read_locus, num_cells, B,
@@ -1245,6 +1280,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         }
         cub_cap = S[CUB].bytes;
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
+        const std::string err = cut_ranges_on_side();
+        if (!err.empty()) return err;
     } else {
         const uint32_t locus_grid = std::min<uint32_t>(blocks_for((uint64_t)L * 64), 8192);
         const size_t lds = (size_t)(TPB / 64) * nb * 4;
@@ -1253,6 +1290,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         cub_cap = S[CUB].bytes;
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
         trace.mark("offset scan launched");
+        const std::string err = cut_ranges_on_side();
+        if (!err.empty()) return err;
         if (n_kept) {
             unsigned long long *grouped = key_b;  // the sorted entry keys are dead after k_dup_rule
             hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_kc, blk_off,
@@ -1263,28 +1302,11 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     }
     if (n_kept)
         hipLaunchKernelGGL(k_max_u64, dim3(blocks_for((size_t)nb * B)), dim3(TPB), 0, stream, per_cell_sq, nb * B, sc);
-    // the pair bound decides the tile variant, and the tile variant the staging limits of the ranges
-    CapChoice caps;
-    caps.entries_plain = pk.stage_masks ? geo.cap_entries_masks : geo.cap_entries_plain;
-    caps.loci_plain = pk.stage_masks ? geo.cap_loci_masks : geo.cap_loci_plain;
-    caps.entries_counts = geo.cap_entries_counts;
-    caps.loci_counts = geo.cap_loci_counts;
-    caps.count_limit = kCountTileLimit;
-    caps.allow_counts = (allow_count_tile && !pk.stage_masks) ? 1u : 0u;
-    {
-        const uint32_t lo_loci = caps.allow_counts ? std::min(caps.loci_plain, caps.loci_counts) : caps.loci_plain;
-        const uint32_t hi_loci = caps.allow_counts ? std::max(caps.loci_plain, caps.loci_counts) : caps.loci_plain;
-        const uint32_t n_seg = (L + lo_loci - 1) / lo_loci;
-        HIP_OK(S[ELOC].ensure(std::max<size_t>((size_t)E * 4, ((size_t)n_seg * hi_loci + n_seg + 2) * 4)));
-        uint32_t *seg_count = S[ELOC].as<uint32_t>();  // entry -> locus is dead after k_csr
-        uint32_t *seg_ends = seg_count + n_seg;
-        hipLaunchKernelGGL(k_ranges_segment, dim3(n_seg), dim3(TPB), 0, stream, blk_off, nb, L, caps, sc, seg_ends,
-                           seg_count);
-        hipLaunchKernelGGL(k_ranges_compact, dim3(1), dim3(TPB), 0, stream, seg_ends, seg_count, n_seg, caps,
-                           pk.range_off.as<uint32_t>(), sc);
-    }
+    // the locus ranges were cut for both sets of limits on the side stream (after the flush chain): pick
     HIP_OK(hipStreamWaitEvent(stream, pk.ev_join, 0));
     side_join.joined = true;
+    hipLaunchKernelGGL(k_ranges_compact, dim3(1), dim3(TPB), 0, stream, seg_ends, seg_count, variant_stride, n_seg, caps,
+                       pk.range_off.as<uint32_t>(), sc);
     if (n_kept) {
         hipLaunchKernelGGL(k_locus_info, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, pk.range_off.as<uint32_t>(), sc,
                            locus_chr, locus_rel);
