@@ -953,8 +953,9 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
         }
         entry32[d] = cib | (base << kC_BaseShift) | (tail ? kC_Tail : 0u) | (hi - lo > 1 ? kC_Multi : 0u)
                 | (wide ? kC_Wide : 0u) | (locus_rel[l] << 16);
-        mask32[d] = (masks & 0xFFu) | (((masks >> 16) & 0xFFu) << 8) | ((bases & 0xFFu) << 16)
-                | (((bases >> 16) & 0xFFu) << 24);
+        if (mask32)  // staged by the clustered-loci tile variant only
+            mask32[d] = (masks & 0xFFu) | (((masks >> 16) & 0xFFu) << 8) | ((bases & 0xFFu) << 16)
+                    | (((bases >> 16) & 0xFFu) << 24);
     }
 }
 
@@ -1313,7 +1314,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         hipLaunchKernelGGL(k_records, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, raw, key2_b, val2_b, n_kept,
                            t_read, read_off, read_locus, read_base, run_rank, rbeg, flushed, locus_chr, locus_rel, B,
                            lbits, pk.entry.as<uint4>(),
-                           pk.entry32.as<uint32_t>(), pk.mask32.as<uint32_t>(), pk.entry_read.as<uint32_t>());
+                           pk.entry32.as<uint32_t>(), pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr,
+                           pk.entry_read.as<uint32_t>());
     }
     // read-back 3: errors of the group mapping, pair bound (-> tile variant), number of ranges
     trace.mark("records launched");
