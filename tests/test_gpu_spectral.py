@@ -81,6 +81,16 @@ def test_eigenpairs_match_lapack(n, k, seed):
     check_against_lapack(a, 20, 7)
 
 
+@pytest.mark.parametrize("n,k,seed", [(230, 2, 41), (700, 3, 42), (1500, 5, 43)])
+def test_thick_restart_matches_lapack(n, k, seed, monkeypatch):
+    """The restart that keeps 64 Ritz vectors and the last Krylov block (the default from 12000 rows on),
+    forced on small matrices; 230 rows: barely more than the 7 blocks of the basis."""
+    monkeypatch.setenv("SECEDO_SPECTRAL_KEEP", "2")
+    a, _ = planted(n, k, seed, isolated=(3,) if n > 500 else ())
+    vals, vecs, info = check_against_lapack(a, 20, 7)
+    assert info["max_residual_vectors"] <= 1e-9
+
+
 def test_isolated_cells_disconnected_components_and_all_zero():
     # isolated cells: rows of zeros give eigenvalue exactly 1 (the Laplacian row is the unit vector)
     a, _ = planted(150, 2, 11, isolated=(0, 17, 149))
