@@ -239,7 +239,7 @@ int solve(int device_id, const double *d_rows, uint32_t row_begin, uint32_t n_ro
         for (uint32_t r = 0; r < m; ++r)
             if (!basis_alive[r]) H[(size_t)r * m + r] = -1.0;
         const auto t_rr = std::chrono::steady_clock::now();
-        if (!secedo::sym_eig_top((int)m, H, (int)ucols, theta, U))  // U: m x ucols, column k = k-th largest
+        if (!secedo::sym_eig_top((int)m, H, (int)ucols, theta, U, true))  // U: m x ucols, column k = k-th largest; only those values
             return secedo::api_fail(SECEDO_E_LIMIT, "the projected eigenproblem did not converge");
         rr_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rr).count();
         // the largest tau first; residual of a Ritz pair = || R_last u_last || (T V_j = sum_blk V_blk H_blk,j

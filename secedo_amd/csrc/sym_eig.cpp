@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <numeric>
 
 namespace secedo {
@@ -212,6 +213,61 @@ void tridiagonalise_keep(int n, std::vector<double> &a, std::vector<double> &d, 
     }
 }
 
+// One row of the Sturm recurrence for k shifts at once: q <- d_i - shift - e_{i-1}^2 / q, negative pivots
+// counted (a vanishing pivot is pushed to -pivmin, as in LAPACK's dstebz). Counts kept as doubles so that
+// the loop over the shifts is one vector loop.
+SECEDO_SIMD_CLONES void sturm_row(int k, double di, double e2, double pivmin, const double *shift, double *q,
+                                  double *negatives) {
+    for (int j = 0; j < k; ++j) {
+        double t = q[j];
+        t = std::fabs(t) < pivmin ? -pivmin : t;
+        const double v = di - shift[j] - e2 / t;
+        q[j] = v;
+        negatives[j] += v < 0.0 ? 1.0 : 0.0;
+    }
+}
+
+// The k largest eigenvalues of the tridiagonal (d, e), descending, by bisection on the Sturm count --
+// all k intervals advance together. Each halving costs one pass over the matrix for all k values,
+// against the O(n^2) rotations QL spends on the n - k values nobody reads.
+void top_values_bisect(int n, const std::vector<double> &d, const std::vector<double> &e, int k, double *out) {
+    double gl = d[0], gu = d[0], emax2 = 0.0;
+    std::vector<double> e2(n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        const double r = (i ? std::fabs(e[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(e[i]) : 0.0);
+        gl = std::min(gl, d[i] - r);
+        gu = std::max(gu, d[i] + r);
+        if (i + 1 < n) {
+            e2[i] = e[i] * e[i];
+            emax2 = std::max(emax2, e2[i]);
+        }
+    }
+    const double eps = 2.220446049250313e-16, pivmin = 2.2250738585072014e-308 * std::max(1.0, emax2);
+    const double tn = std::max(std::fabs(gl), std::fabs(gu));
+    gl -= 2.0 * tn * eps * n + 2.0 * pivmin;
+    gu += 2.0 * tn * eps * n + 2.0 * pivmin;
+    std::vector<double> lo(k, gl), hi(k, gu), mid(k), q(k), neg(k);
+    for (int iter = 0; iter < 80; ++iter) {
+        bool open = false;
+        for (int j = 0; j < k; ++j) {
+            mid[j] = 0.5 * (lo[j] + hi[j]);
+            open = open || hi[j] - lo[j] > 2.0 * eps * std::max(std::fabs(lo[j]), std::fabs(hi[j])) + 2.0 * pivmin;
+        }
+        if (!open) break;
+        for (int j = 0; j < k; ++j) {
+            q[j] = d[0] - mid[j];
+            neg[j] = q[j] < 0.0 ? 1.0 : 0.0;
+        }
+        for (int i = 1; i < n; ++i) sturm_row(k, d[i], e2[i - 1], pivmin, mid.data(), q.data(), neg.data());
+        // the j-th largest eigenvalue lies below x exactly when at least n - j eigenvalues do
+        for (int j = 0; j < k; ++j) {
+            if (neg[j] >= (double)(n - j)) hi[j] = mid[j];
+            else lo[j] = mid[j];
+        }
+    }
+    for (int j = 0; j < k; ++j) out[j] = 0.5 * (lo[j] + hi[j]);
+}
+
 // eigenvalues of the tridiagonal (d, e) by the implicit QL iteration, no vectors
 bool ql_values(int n, std::vector<double> d, std::vector<double> e, std::vector<double> &out) {
     for (int l = 0; l < n; ++l) {
@@ -339,7 +395,7 @@ bool inverse_iteration(int n, const std::vector<double> &d, const std::vector<do
 }  // namespace
 
 bool sym_eig_top(int n, const std::vector<double> &a_in, int k, std::vector<double> &evals,
-                 std::vector<double> &top_vecs) {
+                 std::vector<double> &top_vecs, bool top_values_only) {
     if (k > n) k = n;
     if (n <= 2 || k <= 0) {  // nothing to gain: the full decomposition
         std::vector<double> z;
@@ -360,7 +416,14 @@ bool sym_eig_top(int n, const std::vector<double> &a_in, int k, std::vector<doub
     std::vector<double> d, e, vs;
     std::vector<char> used;
     tridiagonalise_keep(n, a, d, e, vs, used);
-    if (!ql_values(n, d, e, evals)) return false;
+    if (top_values_only) {
+        evals.assign(n, std::numeric_limits<double>::quiet_NaN());
+        std::vector<double> topv(k);
+        top_values_bisect(n, d, e, k, topv.data());
+        for (int j = 0; j < k; ++j) evals[n - 1 - j] = topv[j];
+    } else if (!ql_values(n, d, e, evals)) {
+        return false;
+    }
     double t1 = 0.0;  // 1-norm of the tridiagonal: the scale of its rounding errors
     for (int i = 0; i < n; ++i) t1 = std::max(t1, std::fabs(d[i]) + (i ? std::fabs(e[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(e[i]) : 0.0));
     std::vector<double> tv((size_t)k * n);  // eigenvectors of the tridiagonal, one per row

@@ -14,6 +14,8 @@ bool sym_eig(int n, const std::vector<double> &a, std::vector<double> &evals, st
 // QL without accumulation, vectors by inverse iteration on the tridiagonal and back-transformation:
 // about a fifth of the work of sym_eig for k = 32 of 192. Falls back to sym_eig if a vector does not
 // verify against the matrix.
-bool sym_eig_top(int n, const std::vector<double> &a, int k, std::vector<double> &evals, std::vector<double> &top_vecs);
+// top_values_only: only evals[n - k .. n - 1] are computed (bisection instead of QL; the rest is NaN).
+bool sym_eig_top(int n, const std::vector<double> &a, int k, std::vector<double> &evals, std::vector<double> &top_vecs,
+                 bool top_values_only = false);
 
 }  // namespace secedo

@@ -65,6 +65,22 @@ static int check(int n, int mode) {
             for (int c = 0; c < n; ++c) s += a[i * n + c] * z[c * n + j];
             res2 = std::fmax(res2, std::fabs(s - ev2[j] * z[i * n + j]));
         }
+    // the variant that finds only the k largest values (bisection): same values, same quality of vectors
+    std::vector<double> ev3, tv3;
+    if (!secedo::sym_eig_top(n, a, k, ev3, tv3, true)) return 1;
+    for (int j = 0; j < k; ++j) {
+        dv = std::fmax(dv, std::fabs(ev3[n - 1 - j] - ev2[n - 1 - j]));
+        for (int i = 0; i < n; ++i) {
+            double s = 0;
+            for (int c = 0; c < n; ++c) s += a[i * n + c] * tv3[c * k + j];
+            res = std::fmax(res, std::fabs(s - ev3[n - 1 - j] * tv3[i * k + j]));
+        }
+        for (int l = 0; l < k; ++l) {
+            double s = 0;
+            for (int i = 0; i < n; ++i) s += tv3[i * k + j] * tv3[i * k + l];
+            orth = std::fmax(orth, std::fabs(s - (j == l)));
+        }
+    }
     const double tol = 1e-12 * n;
     if (dv > tol || res > tol || orth > tol || res2 > tol) {
         std::printf("n=%d mode=%d: values %.2e residual %.2e orthogonality %.2e full residual %.2e\n", n, mode, dv, res,
