@@ -383,8 +383,11 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
             v.locus_pos = hp.data();
             v.locus_entry_off = ho.data();
             v.read_ids = hr.data();
-            v.id_base16 = d.id_base16 ? hi16.data() : nullptr;
-            v.id_base32 = d.id_base16 ? nullptr : hi32.data();
+            // (an empty vector's data() may be null, and "which of the two" is told by the pointers)
+            static const uint16_t none16 = 0;
+            static const uint32_t none32 = 0;
+            v.id_base16 = d.id_base16 ? (hi16.empty() ? &none16 : hi16.data()) : nullptr;
+            v.id_base32 = d.id_base16 ? nullptr : (hi32.empty() ? &none32 : hi32.data());
             v.group_id_to_pos = hg.data();
             v.n_groups = d.n_groups;
         }

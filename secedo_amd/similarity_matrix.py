@@ -137,7 +137,10 @@ class SimilarityMatrixPlan:
         id16, id32 = _id_arrays(p)
 
         def dev_tensor(a, view):
-            return t.from_numpy(np.ascontiguousarray(a).view(view)).to(dev)
+            a = np.ascontiguousarray(a)
+            if a.size == 0:  # an empty pileup (e.g. a rank without chromosomes) still needs real pointers
+                a = np.zeros(1, dtype=a.dtype)
+            return t.from_numpy(a.view(view)).to(dev)
 
         res = dict(
             chr=dev_tensor(p.chr_locus_off, np.int32), pos=dev_tensor(p.locus_pos, np.int32),

@@ -175,3 +175,33 @@ def test_chromosome_shards_reproduce_single_process_bitwise(tmp_path):
         assert np.array_equal(np.load(tmp_path / ("acc%d.npy" % r)), acc_single)
         assert np.array_equal(np.load(tmp_path / ("rank%d.npy" % r)), single)
     assert np.any(single != 0)
+
+
+def test_more_ranks_than_chromosomes_leave_empty_shards():
+    """Three chromosomes over eight ranks: five ranks hold an empty pileup (prepared from HBM like the
+    others); the per-rank accumulators still add up to the whole one bit for bit."""
+    import secedo_amd
+    from secedo_amd import distributed as sd
+    from tests.pileup_gen import random_pileup
+
+    n, world = 200, 8
+    p = random_pileup(77, n, 3, 200, 40, 900, dup_frac=0.03)
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        plan.prepare(p, n, 1000, None, 8, block_cells=64)
+        full = plan.new_acc()
+        plan.accumulate(full, 0.01, 0.5, 0.01)
+        total = torch.zeros_like(full)
+        empty = 0
+        for r in range(world):
+            shard = sd.chromosome_shard(p, r, world)
+            plan.prepare_resident(plan.upload(shard, None, n), n, 1000, 8, 64)
+            assert plan.num_tiles * 64 * 64 == full.numel()
+            part = plan.new_acc()
+            if plan.num_entries:
+                plan.accumulate(part, 0.01, 0.5, 0.01)
+            else:
+                empty += 1
+            total += part
+        torch.cuda.synchronize()
+        assert empty == 5
+        assert torch.equal(total, full)
