@@ -48,3 +48,51 @@ def test_u32_ids_and_errors():
         secedo_amd.expectation_maximization(p, np.arange(n, dtype=np.uint32), 1, 1e-3, prob[:100])
     with pytest.raises(secedo_amd.SecedoError):  # groups outside id_to_pos
         secedo_amd.expectation_maximization(p, np.arange(50, dtype=np.uint32), 1, 1e-3, prob)
+
+
+def test_many_iterations_and_the_iteration_limit():
+    """Iterations are launched four at a time: a refinement that needs 16 of them, limits that fall inside
+    and at the end of a batch, and the error when the limit is too small."""
+    from tests.pileup_gen import random_pileup
+    n = 60
+    p = random_pileup(3, n, 1, 300, 6, 400, err=0.2)
+    rng = np.random.default_rng(3)
+    prob = np.clip(0.5 + 0.05 * rng.standard_normal(n), 0.05, 0.95)
+    i2p = np.arange(n, dtype=np.uint32)
+    ref, it_ref = ob.oracle_em(p, i2p, 0.2, prob)
+    assert it_ref == 16
+    for limit in (0, 16, 17, 18):
+        got, it = secedo_amd.expectation_maximization(p, i2p, 1, 0.2, prob.copy(), max_iterations=limit)
+        assert it == it_ref and np.max(np.abs(got - ref)) <= TOL
+    for limit in (15, 14, 3):
+        with pytest.raises(secedo_amd.SecedoError):
+            secedo_amd.expectation_maximization(p, i2p, 1, 0.2, prob.copy(), max_iterations=limit)
+
+
+def test_scratch_pool_release_and_concurrent_callers():
+    """The scratch is kept per device between calls; releasing it and two threads refining at once (the
+    second gets an allocation of its own) give the same results."""
+    import threading
+    from secedo_amd import _lib
+    from tests.pileup_gen import random_pileup
+    n = 80
+    p = random_pileup(5, n, 2, 200, 10, 400)
+    rng = np.random.default_rng(5)
+    prob = np.clip(rng.random(n), 0.05, 0.95)
+    i2p = np.arange(n, dtype=np.uint32)
+    ref, it_ref = ob.oracle_em(p, i2p, 1e-3, prob)
+    _lib.lib().secedo_simmat_release_cache()
+    results = [None, None]
+
+    def run(k):
+        for _ in range(5):
+            results[k] = secedo_amd.expectation_maximization(p, i2p, 1, 1e-3, prob.copy())
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    _lib.lib().secedo_simmat_release_cache()
+    for got, it in results + [secedo_amd.expectation_maximization(p, i2p, 1, 1e-3, prob.copy())]:
+        assert it == it_ref and np.max(np.abs(got - ref)) <= TOL

@@ -4,6 +4,8 @@ Tolerance: norm-wise max|got-ref| <= 1e-9 * max|ref| (BASELINE.json north_star, 
 symmetry and the zero diagonal must be exact. The integer work counters (updates, read pairs) must
 match the oracle's exactly.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -558,3 +560,29 @@ def test_randomised_differential_sweep():
         if np.all(np.isfinite(ref)) and not (norm == "EXPONENTIATE" and np.max(np.abs(raw)) > 30):
             assert gu.normwise_err(got, ref) <= tol_ref, ctx
         assert np.array_equal(got, got.T, equal_nan=True), ctx
+
+
+def test_plain_copy_readbacks_give_the_same_matrix(tmp_path):
+    """SECEDO_PACK_READBACK=memcpy: the packing reads its scalars back with hipMemcpy + synchronise instead
+    of the polled mailbox in pinned host memory (the switch is read once per process: a child process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = "\n".join([
+        "import numpy as np, sys",
+        "sys.path.insert(0, %r)" % root,
+        "import secedo_amd",
+        "from tests.pileup_gen import random_pileup",
+        "p = random_pileup(91, 150, 2, 400, 25, 300, dup_frac=0.03)",
+        "m = secedo_amd.compute_similarity_matrix(p, 150, 200, None, 0.01, 0.5, 0.01, 2, '', 'ADD_MIN')",
+        "np.save(sys.argv[1], m)"])
+    outs = []
+    for mode in ("memcpy", "mailbox"):
+        env = dict(os.environ, SECEDO_PACK_READBACK=mode)
+        out = str(tmp_path / (mode + ".npy"))
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=600)
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0], outs[1]) and np.any(outs[0] != 0)
+    p = random_pileup(91, 150, 2, 400, 25, 300, dup_frac=0.03)
+    ref = ob.oracle_compute(p, 150, 200, None, 0.01, 0.5, 0.01, 2, "ADD_MIN")
+    assert gu.normwise_err(outs[0], ref) <= TOL
