@@ -775,13 +775,6 @@ __global__ __launch_bounds__(TPB) void k_group_counts(const unsigned long long *
     }
 }
 
-__global__ void k_max_u64(const unsigned long long *a, uint32_t n, Scalars *sc) {
-    unsigned long long best = 0;
-    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) best = max(best, a[i]);
-    for (int off = 32; off > 0; off >>= 1) best = max(best, (unsigned long long)__shfl_down(best, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(&sc->pair_bound, best);
-}
-
 // Locus ranges (one partition shared by all cell blocks). The loci are cut into segments of
 // cap_loci loci, one workgroup per segment; inside its segment a workgroup cuts greedily: the
 // longest range from `s` in which no block has more than cap_entries entries (feasibility is
@@ -874,7 +867,22 @@ __global__ __launch_bounds__(TPB) void k_ranges_segment(const uint32_t *blk_off,
 
 __global__ __launch_bounds__(TPB) void k_ranges_compact(const uint32_t *seg_ends_both, const uint32_t *seg_count_both,
                                                        size_t variant_stride, uint32_t n_seg, CapChoice caps,
-                                                       uint32_t *range_off, Scalars *sc) {
+                                                       uint32_t *range_off, const unsigned long long *per_cell_sq,
+                                                       uint32_t n_cells_padded, Scalars *sc) {
+    // the pair bound first: the largest per-cell sum of squares (it used to be a launch of its own)
+    __shared__ unsigned long long s_best[TPB / 64];
+    {
+        unsigned long long best = 0;
+        for (uint32_t i = threadIdx.x; i < n_cells_padded; i += TPB) best = max(best, per_cell_sq[i]);
+        for (int off = 32; off > 0; off >>= 1) best = max(best, (unsigned long long)__shfl_down(best, off));
+        if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < TPB / 64; ++w) best = max(best, s_best[w]);
+            sc->pair_bound = max(sc->pair_bound, best);
+        }
+        __syncthreads();
+    }
     const bool use_counts = caps.counts(sc);
     const uint32_t cap_loci = use_counts ? caps.loci_counts : caps.loci_plain;
     const uint32_t *seg_ends = seg_ends_both + (use_counts ? variant_stride : 0);
@@ -1301,13 +1309,11 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
                                stream, key2_a, grouped, n_kept, B, L, lbits, blk_off, key2_b, val2_b, per_cell_sq, sc);
         }
     }
-    if (n_kept)
-        hipLaunchKernelGGL(k_max_u64, dim3(blocks_for((size_t)nb * B)), dim3(TPB), 0, stream, per_cell_sq, nb * B, sc);
     // the locus ranges were cut for both sets of limits on the side stream (after the flush chain): pick
     HIP_OK(hipStreamWaitEvent(stream, pk.ev_join, 0));
     side_join.joined = true;
     hipLaunchKernelGGL(k_ranges_compact, dim3(1), dim3(TPB), 0, stream, seg_ends, seg_count, variant_stride, n_seg, caps,
-                       pk.range_off.as<uint32_t>(), sc);
+                       pk.range_off.as<uint32_t>(), per_cell_sq, n_kept ? nb * B : 0u, sc);
     if (n_kept) {
         hipLaunchKernelGGL(k_locus_info, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, pk.range_off.as<uint32_t>(), sc,
                            locus_chr, locus_rel);
