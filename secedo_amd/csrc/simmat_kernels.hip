@@ -624,9 +624,21 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
     STAMP(t_sl);
 #ifdef SECEDO_STAMPS
     if (threadIdx.x == 0u && blockIdx.x < 2048u) {
+        // per workgroup (wave 0 stands for it), read by secedo_simmat_last_counts under SECEDO_STAMPS_PRINT:
+        // where it ran (HW_REG_XCC_ID | HW_REG_HW_ID), the cycles of its phases, its real-time start and
+        // end (s_memrealtime, 100 MHz), and -- in counters[16 + workgroup] -- lifetime | first range | end
         unsigned long long *w = a.counters + 16 + 2048 + (size_t)blockIdx.x * 8;
-        w[0] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); w[1] = t_le - t_pro; w[2] = t_fl - t_le; w[3] = t_eb - t_fl; w[4] = t_sl - t_eb; w[5] = st_real_begin; w[6] = stamp_real(); w[7] = st_loop;
-        a.counters[16 + blockIdx.x] = ((t_sl - st_begin) & 0xFFFFFFFFull) | ((unsigned long long)r_begin << 32) | ((unsigned long long)r_end << 44);
+        w[0] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32)
+                | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        w[1] = t_le - t_pro;
+        w[2] = t_fl - t_le;
+        w[3] = t_eb - t_fl;
+        w[4] = t_sl - t_eb;
+        w[5] = st_real_begin;
+        w[6] = stamp_real();
+        w[7] = st_loop;
+        a.counters[16 + blockIdx.x] = ((t_sl - st_begin) & 0xFFFFFFFFull) | ((unsigned long long)r_begin << 32)
+                | ((unsigned long long)r_end << 44);
     }
 #endif
     // work counters: wave reduction, one atomic per wave
