@@ -73,7 +73,8 @@ struct Scalars {
 
 // Scalar read-backs. hipMemcpyAsync + hipStreamSynchronize leaves the GPU idle for 30-40 us per
 // read-back (interrupt, wake-up, the first launches after it); instead a one-lane kernel publishes the
-// scalars into pinned host memory and the host polls the sequence word next to them.
+// scalars into pinned, coherent (fine-grained: visible to the host while the stream is still running,
+// whatever HIP_HOST_COHERENT says) host memory and the host polls the sequence word next to them.
 struct Mailbox {
     Scalars sc;
     unsigned long long totals;
@@ -96,7 +97,7 @@ hipError_t read_scalars(DevicePacked &pk, hipStream_t stream, const Scalars *sc,
     }();
     hipError_t e;
     if (!plain && !pk.mailbox && !pk.mailbox_failed) {
-        if (hipHostMalloc(&pk.mailbox, sizeof(Mailbox), hipHostMallocDefault) == hipSuccess) {
+        if (hipHostMalloc(&pk.mailbox, sizeof(Mailbox), hipHostMallocCoherent) == hipSuccess) {
             std::memset(pk.mailbox, 0, sizeof(Mailbox));
         } else {  // no pinned memory to be had: the plain copies below
             (void)hipGetLastError();
