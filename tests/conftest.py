@@ -27,3 +27,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The product library is a build artefact (git-ignored): if a checkout has not been built yet, build it
+    once (hipcc cross-compiles without a GPU; __graft_entry__.build() does the same and more)."""
+    lib = os.path.join(ROOT, "secedo_amd", "libsecedo_simmat.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "secedo_amd", "csrc"), "-j4"], check=True,
+                       capture_output=True)
+    yield
