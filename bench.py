@@ -1,18 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the similarity-matrix hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C1] [--clustered]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2|C5|C1] [--clustered]
 
-One step = one pass of the hot path over the synthetic pileup already resident in HBM:
-zero the accumulator, accumulate every tile (this rank's tile range when N > 1), all-gather the
-accumulator over RCCL (N > 1), normalise + mirror into the dense N x N fp64 matrix.
+One step = one pass of the hot path over the synthetic pileup already resident in HBM: device packing
+of the raw flat pileup (read assembly, flush schedule, tiles), zero the accumulator, accumulate the
+tiles, (N > 1: RCCL exchange), normalise + mirror into the dense N x N fp64 matrix.
 The metric is (read pair, shared locus) updates per second (BASELINE.json "cell-pair x locus
 updates/sec"; one update = one x_s++/x_d++ of reference similarity_matrix.cpp:225).
+The default workload is C3 = BASELINE.json configs[2] (8000 cells x 100K loci), the configuration the
+north-star target is stated on; it fits one GPU.
+
+`python bench.py --gpus N` with N > 1 starts its own N ranks (one process per GPU, torch.distributed.run,
+rendezvous on 127.0.0.1) when it was not itself started by a launcher; started under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it uses the ranks it was given.
+With N > 1 both ways of sharing the matrix are timed, K steps each:
+  * tiles: the output tiles are dealt to the ranks, every rank packs the whole (replicated) pileup, one
+    all-gather of the int64 tile-major accumulator (the north-star's block partition + all-gather);
+  * chromosomes: every rank packs and accumulates only its chromosomes, for all tiles, one all-reduce
+    (sum) of the accumulator.
+`value` is the faster of the two (named in config.parallelism); both are in `partitionings`.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -66,26 +80,81 @@ def cpu_baseline(p, n_cells, mfl, rates, threads, budget_updates):
             "host_cpus": os.cpu_count()}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
+    ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--clustered", action="store_true", help="gap_max=300 variant (~2.8 loci/read)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 "
                          "flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--tiles", action="store_true",
-                    help="N > 1: deal out the output tiles (replicated packing + all-gather) even when the pileup "
-                         "has chromosomes enough to be split by chromosomes (the default then)")
+    ap.add_argument("--only", default="both", choices=["both", "tiles", "chromosomes"],
+                    help="N > 1: time only one of the two partitionings")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal without a GPU: start the ranks, rendezvous (gloo), shard the "
+                         "pileup both ways, exchange the shard sizes, print them -- no HIP call anywhere")
     ap.add_argument("--packed-resident", action="store_true",
                     help="keep the PACKED pileup resident and leave the packing out of the step "
                          "(steady state of repeated accumulations; default: the step starts from the raw "
                          "flat pileup in HBM and includes the device-side packing)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """The parent of `python bench.py --gpus N`: it has not touched the GPU (no HIP call, no torch.cuda
+    call), starts N fresh rank processes through torch.distributed.run and passes their output on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this host
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """What the ranks do before any GPU work, on the CPU: rendezvous, shard, exchange. Used by the tests to
+    check that `python bench.py --gpus N` starts N ranks that find each other and cover the work once."""
+    import torch
+    import torch.distributed as dist
+    from secedo_amd import distributed as sd
+    from secedo_amd.synth import CONFIGS, synth_config
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    p = synth_config(args.workload, clustered=args.clustered)
+    shard = sd.chromosome_shard(p, rank, world) if world > 1 else p
+    n_blocks = -(-CONFIGS[args.workload][0] // 128)
+    lo, hi = sd.tile_range(n_blocks * (n_blocks + 1) // 2, rank, world)
+    mine = torch.tensor([shard.n_entries, shard.n_chr, hi - lo], dtype=torch.int64)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(parts, mine)
+    else:
+        parts = [mine]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "world_size": world,
+                          "backend": "gloo" if world > 1 else "none",
+                          "entries": int(p.n_entries), "chromosomes": int(p.n_chr),
+                          "tiles": n_blocks * (n_blocks + 1) // 2,
+                          "shard_entries": [int(t[0]) for t in parts],
+                          "shard_chromosomes": [int(t[1]) for t in parts],
+                          "shard_tiles": [int(t[2]) for t in parts]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     import numpy as np
     import torch
@@ -98,83 +167,95 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local_rank)
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     n_cells, n_loci, n_chr, gap, prob = CONFIGS[args.workload]
     mfl, threads, rates, norm = 1000, 8, (0.01, 0.5, 0.01), "ADD_MIN"
     p = synth_config(args.workload, clustered=args.clustered)
-
-    # N > 1, strong scaling of ONE matrix. With chromosomes enough the pileup is split by chromosomes (reads,
-    # flushes and the tail rule never cross one): a rank packs and accumulates only its chromosomes, for all
-    # tiles, and the int64 accumulators are summed by one all-reduce -- the packing is divided too.
-    # Otherwise the tiles are dealt out, every rank packs the whole pileup, one all-gather.
-    by_chromosome = world > 1 and p.n_chr >= world and not args.tiles
-    mine = sd.chromosome_shard(p, rank, world) if by_chromosome else p
-
-    plan = secedo_amd.SimilarityMatrixPlan(local_rank)
-    resident = plan.upload(mine, None, n_cells)  # the raw flat pileup, in HBM before the clock starts
-    t0 = time.perf_counter()
-    plan.prepare_resident(resident, n_cells, mfl, threads)
-    torch.cuda.synchronize()
-    prepare_s = time.perf_counter() - t0
-    block_cells = 0  # the library's choice
-    if by_chromosome:
-        # the ranks must agree on the tile edge (it is chosen from the shard's statistics): the smallest
-        b = torch.tensor([plan.block_cells], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(b, op=dist.ReduceOp.MIN)
-        block_cells = int(b.item())
-        plan.prepare_resident(resident, n_cells, mfl, threads, block_cells)
-    acc = plan.new_acc(pad_tiles_to=1 if by_chromosome else world)
     out = torch.empty((n_cells, n_cells), dtype=torch.float64, device="cuda:%d" % local_rank)
-    my_tiles = (0, plan.num_tiles) if by_chromosome else sd.tile_range(plan.num_tiles, rank, world)
-
-    def step():
-        if not args.packed_resident:
-            plan.prepare_resident(resident, n_cells, mfl, threads, block_cells)
-        if by_chromosome:
-            sd.chromosome_sharded_accumulate(plan, acc, *rates, world)
-        else:
-            sd.sharded_accumulate(plan, acc, *rates, rank, world)
-        plan.finalize(acc, norm, out)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    # exact work counters of one pass (integer, identical every step)
-    local_updates, local_pairs = plan.last_counts()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    # the accumulate kernel's own duration: HIP events recorded by the library on the launch stream
-    # around the last launch of the timed region, plus torch events over a few more launches below
-    last_ms = plan.last_accumulate_ms()
+    def run_mode(by_chromosome):
+        """W warm-up steps, then K timed steps of one partitioning. Returns its record and live objects."""
+        mine = sd.chromosome_shard(p, rank, world) if by_chromosome else p
+        plan = secedo_amd.SimilarityMatrixPlan(local_rank)
+        resident = plan.upload(mine, None, n_cells)  # the raw flat pileup, in HBM before the clock starts
+        t0 = time.perf_counter()
+        plan.prepare_resident(resident, n_cells, mfl, threads)
+        torch.cuda.synchronize()
+        prepare_s = time.perf_counter() - t0
+        block_cells = 0  # the library's choice
+        if by_chromosome:
+            # shards are summed into one accumulator: same tile edge, same fixed-point scale on every rank
+            block_cells, _ = sd.agree_on_shard_geometry(
+                plan, lambda b: plan.prepare_resident(resident, n_cells, mfl, threads, b), world, red_dev)
+        acc = plan.new_acc(pad_tiles_to=1 if by_chromosome else world)
+        my_tiles = (0, plan.num_tiles) if by_chromosome else sd.tile_range(plan.num_tiles, rank, world)
 
-    red_dev = "cuda" if args.backend == "nccl" else "cpu"
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    cnt = torch.tensor([local_updates, local_pairs, plan.num_entries if by_chromosome or rank == 0 else 0,
-                        plan.num_reads if by_chromosome or rank == 0 else 0], dtype=torch.int64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    updates, pairs, kept_entries, reads = (int(v.item()) for v in cnt)
+        def step():
+            if not args.packed_resident:
+                plan.prepare_resident(resident, n_cells, mfl, threads, block_cells)
+            if by_chromosome:
+                sd.chromosome_sharded_accumulate(plan, acc, *rates, world)
+            else:
+                sd.sharded_accumulate(plan, acc, *rates, rank, world)
+            plan.finalize(acc, norm, out)
 
-    # phase times of one step, events on the launch stream (torch's current one)
+        for _ in range(args.warmup):
+            step()
+        sync()
+        local_updates, local_pairs = plan.last_counts()  # exact integer work counters of one pass
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        last_ms = plan.last_accumulate_ms()  # HIP events recorded by the library on the launch stream
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        own = by_chromosome or rank == 0
+        cnt = torch.tensor([local_updates, local_pairs, plan.num_entries if own else 0,
+                            plan.num_reads if own else 0], dtype=torch.int64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        updates, pairs, kept_entries, reads = (int(v.item()) for v in cnt)
+        return dict(by_chromosome=by_chromosome, plan=plan, resident=resident, acc=acc, my_tiles=my_tiles,
+                    block_cells=block_cells, elapsed=float(t.item()), updates=updates, pairs=pairs,
+                    kept_entries=kept_entries, reads=reads, local_updates=local_updates, last_ms=last_ms,
+                    prepare_s=prepare_s)
+
+    modes = []
+    if world == 1:
+        modes.append(run_mode(False))
+    else:
+        if args.only in ("both", "tiles"):
+            modes.append(run_mode(False))
+        if args.only in ("both", "chromosomes") and p.n_chr >= 2:
+            modes.append(run_mode(True))
+    best = min(modes, key=lambda m: m["elapsed"])
+    plan, acc, resident = best["plan"], best["acc"], best["resident"]
+    by_chromosome, block_cells, my_tiles = best["by_chromosome"], best["block_cells"], best["my_tiles"]
+    elapsed, updates = best["elapsed"], best["updates"]
+
+    # phase times of one step of the reported partitioning, events on the launch stream (torch's current one)
     phase = {}
+
     def repack():
         plan.prepare_resident(resident, n_cells, mfl, threads, block_cells)
 
@@ -207,19 +288,26 @@ def main():
     kern_ms = ev_ms[len(ev_ms) // 2]
 
     if rank == 0:
-        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_traffic.json)
+        # HBM bytes per accumulate launch from separate rocprofv3 --pmc passes over this same command
+        # (tools/collect_traffic.sh -> profiles/r02_traffic.json; FETCH_SIZE doubled as the microarch guide
+        # prescribes for gfx950); null when no pass was taken for this workload
+        traffic = traffic_src = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
                 t = json.load(fh).get(args.workload if not args.clustered and world == 1 else "")
             if t:
-                traffic = (t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024
+                traffic = t["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r02_traffic.json (%s)" % t.get("source", "rocprofv3 --pmc")
         except (OSError, ValueError, KeyError):
             traffic = None
         E, L, N = plan.num_entries, plan.num_loci, n_cells
+        local_updates = best["local_updates"]
         # this rank's launch: its tiles of the whole pileup, or all tiles of its chromosomes
         b_alg = (16 * local_updates + 6 * E + 4 * L + 16 * N * N if by_chromosome
                  else 16 * local_updates + 6 * E / world + 4 * L + 16 * N * N / world)
+        b_alg_step = 16 * updates + 6 * best["kept_entries"] + 4 * n_loci + 16 * N * N  # the whole job
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
+        step_s = elapsed / args.steps
         line = {
             "metric": "cell-pair x locus updates/sec (similarity matrix)",
             "value": updates * args.steps / elapsed,
@@ -227,7 +315,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": step_s * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -235,31 +323,45 @@ def main():
             "data": "synthetic (SYNTH-v1, seed 42)",
             "config": {"workload": "%s: %d cells x %d loci%s" % (
                 args.workload, n_cells, n_loci, " clustered" if args.clustered else ""),
-                "entries": int(p.n_entries), "kept_entries": kept_entries, "reads": reads,
-                "updates_per_step": updates, "read_pairs_per_step": pairs,
+                "entries": int(p.n_entries), "kept_entries": best["kept_entries"], "reads": best["reads"],
+                "updates_per_step": updates, "read_pairs_per_step": best["pairs"],
                 "block_cells": plan.block_cells, "tiles": plan.num_tiles,
                 "normalization": norm, "max_fragment_length": mfl, "num_threads": threads,
                 "parallelism": ("single GPU" if world == 1 else
                                 "chromosomes/%d (packing + accumulation) + all-reduce of the int64 accumulator" % world
-                                if by_chromosome else "tiles/%d + all-gather" % world),
+                                if by_chromosome else "tiles/%d (replicated packing) + all-gather of the int64 "
+                                                      "accumulator" % world),
+                "backend": "none" if world == 1 else ("RCCL (nccl)" if args.backend == "nccl" else args.backend),
+                "world_size": world,
                 # tiles mode: every rank packs the whole pileup, only the pair accumulation is divided
                 "replicated_ms_per_step": phase.get("pack_ms") if world > 1 and not by_chromosome else None},
-            "wall_s_full_matrix": elapsed / args.steps,
-            "dense_equivalent_cell_pair_locus_slots_per_s":
-                n_cells * (n_cells - 1) / 2 * n_loci * args.steps / elapsed,
+            "partitionings": {("chromosomes+all-reduce" if m["by_chromosome"] else "tiles+all-gather"):
+                              {"ms_per_step": m["elapsed"] / args.steps * 1e3,
+                               "updates_per_s": m["updates"] * args.steps / m["elapsed"]} for m in modes},
+            "wall_s_full_matrix": step_s,
+            "dense_equivalent_cell_pair_locus_slots_per_s": n_cells * (n_cells - 1) / 2 * n_loci / step_s,
             "step_includes_packing": not args.packed_resident,
             "packing": "device" if plan.used_device_packing else "host",
             "phase_ms": {"pack": phase["pack_ms"], "accumulate": kern_ms, "finalize": phase["finalize_ms"]},
-            "first_prepare_s": prepare_s,
+            "first_prepare_s": best["prepare_s"],
+            "scale_log2": plan.scale_log2,
+            # SURVEY 8d accounting: achieved = ALGORITHMIC bytes of one accumulate launch / its duration.
+            # The updates land in LDS, so this is not HBM use: `traffic` is; the kernel's real limiter is
+            # vector-instruction issue (profiles/r02_pmc_C3.txt).
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "accumulate_tiles", "kernel_ms": kern_ms,
-                         "kernel_ms_last_timed_step": last_ms,
-                         "algorithmic_bytes": b_alg},
+                         "kernel_ms_last_timed_step": best["last_ms"],
+                         "algorithmic_bytes": b_alg,
+                         "hbm_frac_measured": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         "limiter": "VALU issue + LDS latency (see profiles/)",
+                         "whole_step": {"algorithmic_bytes": b_alg_step,
+                                        "achieved": b_alg_step / step_s / 1e9,
+                                        "frac": b_alg_step / step_s / 1e9 / HBM_PEAK_GBPS / world}},
         }
-        if not args.no_cpu_baseline:
-            # the drop-in call itself: host buffers in, host matrix out (create, H2D, pack, accumulate,
-            # normalise, D2H, destroy) -- PCIe-inclusive, never `value`
+        if not args.no_cpu_baseline and world == 1:
+            # the drop-in call itself: host buffers in, host matrix out (H2D, pack, accumulate, normalise,
+            # D2H) -- PCIe-inclusive, never `value`
             # (the library keeps the call's device buffers for the next call: first and repeated call)
             t0 = time.perf_counter()
             secedo_amd.compute_similarity_matrix(p, n_cells, mfl, None, *rates, threads, "", norm)
@@ -267,8 +369,21 @@ def main():
             t0 = time.perf_counter()
             secedo_amd.compute_similarity_matrix(p, n_cells, mfl, None, *rates, threads, "", norm)
             line["one_shot_host_call_s"] = time.perf_counter() - t0
-            line["cpu_baseline"] = cpu_baseline(p, n_cells, mfl, rates, threads, 2.5e8)
-        print(json.dumps(line))
+            # ... and through the C++ shim with the reference's signature (include/secedo_simmat.hpp) from a
+            # vector<vector<PosData>>, as the reference's caller holds the pileup: flatten + H2D + step +
+            # D2H straight into the returned matrix. A child process (tests/cpp/shim_test.cpp, built by make).
+            shim = os.path.join(ROOT, "secedo_amd", "csrc", "build", "shim_test")
+            if os.path.exists(shim) and n_cells <= 16383:
+                try:
+                    r = subprocess.run([shim, "--synth", str(n_cells), str(n_loci), str(n_chr),
+                                        str(300 if args.clustered else gap), repr(prob), "2"],
+                                       capture_output=True, text=True, timeout=600)
+                    line["cpp_dropin_call"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 \
+                        else {"error": r.stderr[-300:]}
+                except (subprocess.SubprocessError, ValueError, IndexError) as e:
+                    line["cpp_dropin_call"] = {"error": str(e)[:300]}
+            line["cpu_baseline"] = cpu_baseline(p, n_cells, mfl, rates, threads, 5e8)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

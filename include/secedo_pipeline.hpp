@@ -68,11 +68,15 @@ void expectation_maximization(const std::vector<std::vector<PosDataT>> &pos_data
     if (rc != SECEDO_OK) throw std::runtime_error(std::string("secedo_em: ") + secedo_simmat_last_error());
 }
 
-// MatdT: rows(), and either contiguous row-major storage reachable through `data()` (the reference's
+// MatdT: rows(), and contiguous row-major storage reachable through `data()` (the reference's
 // Mat<double>) -- the matrix is symmetric, so row-major and column-major coincide.
+// The iteration stops at residuals <= 1e-9 or after its cycle limit; pairs that did not get there are not
+// handed out silently: without `info_out` an unconverged solve throws, with it the caller decides
+// (info_out->converged, max_residual_vectors / _values).
 template <class MatdT>
 void smallest_eigenpairs(const MatdT &similarity, uint32_t n_values, uint32_t n_vectors,
-                         std::vector<double> *eigenvalues, std::vector<double> *eigenvectors) {
+                         std::vector<double> *eigenvalues, std::vector<double> *eigenvectors,
+                         secedo_spectral_info *info_out = nullptr) {
     const uint32_t n = similarity.rows();
     n_values = n_values < n ? n_values : n;
     n_vectors = n_vectors < n_values ? n_vectors : n_values;
@@ -82,6 +86,11 @@ void smallest_eigenpairs(const MatdT &similarity, uint32_t n_values, uint32_t n_
     const int rc = secedo_spectral_eigs(0, similarity.data(), n, n_values, n_vectors, 0.0, 0, eigenvalues->data(),
                                         eigenvectors->data(), &info);
     if (rc != SECEDO_OK) throw std::runtime_error(std::string("secedo_spectral: ") + secedo_simmat_last_error());
+    if (info_out) *info_out = info;
+    else if (!info.converged)
+        throw std::runtime_error("secedo_spectral: the eigensolver did not converge (residual "
+                                 + std::to_string(info.max_residual_vectors) + " after "
+                                 + std::to_string(info.cycles) + " cycles)");
 }
 
 }  // namespace secedo_amd

@@ -137,6 +137,17 @@ uint64_t secedo_simmat_num_entries(const secedo_simmat_t *handle);
 uint64_t secedo_simmat_num_reads(const secedo_simmat_t *handle);
 uint64_t secedo_simmat_num_loci(const secedo_simmat_t *handle);
 
+/* Fixed-point scale of the accumulator. The int64 accumulators hold D * 2^scale_log2; the scale is 44 unless
+ * the pileup's pair bound (an upper bound on the (read pair, shared locus) incidences one cell pair can
+ * collect) says an int64 could overflow. Accumulators that are ADDED UP across handles -- chromosome shards
+ * on several GPUs -- must share one scale: every rank reads its shard's bound after prepare(), the ranks
+ * sum the bounds (the bound of the union is at most the sum), and every rank sets the sum before
+ * accumulate(), ranks with an empty shard included. 0 restores the handle's own bound. scale_log2() is the
+ * scale of the last accumulate(). */
+uint64_t secedo_simmat_pair_bound(const secedo_simmat_t *handle);
+int secedo_simmat_set_pair_bound(secedo_simmat_t *handle, uint64_t pair_bound);
+int secedo_simmat_scale_log2(const secedo_simmat_t *handle);
+
 int secedo_simmat_zero_acc(secedo_simmat_t *handle, int64_t *d_acc, void *stream);
 int secedo_simmat_accumulate(secedo_simmat_t *handle, double mutation_rate, double homozygous_rate,
                              double seq_error_rate, uint32_t tile_begin, uint32_t tile_end,
@@ -182,9 +193,14 @@ int secedo_simmat_last_counts(secedo_simmat_t *handle, uint64_t *updates, uint64
 int secedo_simmat_last_accumulate_ms(secedo_simmat_t *handle, float *ms);
 
 /* log-likelihood ratio D(x_s, x_d) = log P(x_s,x_d | different) - log P(x_s,x_d | same) as the
- * device tables hold it (closed form of similarity_matrix.cpp:117-170; host-only, no device). */
+ * device tables hold it (host-only, no device): for x_s + x_d <= 64 what the reference's nested sums
+ * return (similarity_matrix.cpp:117-170), including the wrap-around of its uint64_t binomial products
+ * from x_s + x_d ~ 48 on; beyond 64 -- and everywhere under SECEDO_LLR_EXACT=1 -- the closed form of
+ * the same sums, i.e. the reference's formula in exact arithmetic (secedo_simmat_llr_closed_form). */
 double secedo_simmat_llr(uint32_t x_s, uint32_t x_d, double mutation_rate, double homozygous_rate,
                          double seq_error_rate);
+double secedo_simmat_llr_closed_form(uint32_t x_s, uint32_t x_d, double mutation_rate, double homozygous_rate,
+                                     double seq_error_rate);
 
 /* ------------------------------------------------------------------------------------------
  * Locus filter, the step immediately upstream of the similarity matrix.
@@ -243,26 +259,6 @@ int secedo_pileup_read(const char *path, const uint16_t *id_to_group, uint32_t n
                        int write_bin, secedo_pileup_info *info, uint32_t *locus_pos,
                        uint64_t *locus_entry_off, uint32_t *read_ids, uint16_t *id_base16);
 const char *secedo_pileup_last_error(void);
-
-/* ------------------------------------------------------------------------------------------
- * SYNTH-v1 synthetic pileup generator: bench and test utility, host only.
- * Call with all output pointers NULL to obtain the sizes, then again with buffers.
- * ---------------------------------------------------------------------------------------- */
-typedef struct secedo_synth_spec {
-    uint32_t num_cells;
-    uint32_t num_loci;
-    uint32_t num_chromosomes;
-    uint32_t gap_max;      /* locus gaps are 1 + rng % gap_max */
-    double new_frag_prob;  /* per cell and locus probability of a new fragment (p) */
-    uint32_t frag_min, frag_max;
-    double base_error;     /* i.i.d. sequencing error */
-    double mate_frac;      /* fraction of fragments with a second mate entry */
-    uint64_t seed;
-} secedo_synth_spec;
-
-int secedo_synth_generate(const secedo_synth_spec *spec, uint64_t *n_loci, uint64_t *n_entries,
-                          uint32_t *chr_locus_off, uint32_t *locus_pos, uint64_t *locus_entry_off,
-                          uint32_t *read_ids, uint32_t *id_base32);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,9 @@
 //   PosDataT: members `uint32_t position`, `std::vector<uint32_t> read_ids`,
 //             `std::vector<uint16_t> group_ids_bases`           (sequenced_data.hpp:26-37)
 //   MatdT:    constructor MatdT(rows, cols) owning its elements, `double &operator()(r, c)`
-//             row-major contiguous storage is NOT assumed       (util/mat.hpp:86, :117)
+//             (util/mat.hpp:86, :117). When MatdT also has `double *data()` over contiguous row-major
+//             storage -- the reference's Mat<double> does, util/mat.hpp:238 with :117 -- the library
+//             writes the result straight into it; otherwise it goes through a buffer and operator().
 //
 // Error behaviour of the reference is kept: an unknown normalisation throws std::logic_error
 // ("Invalid normalization: ..."), here before any work is done (the reference throws after the
@@ -30,9 +32,20 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace secedo_amd {
+
+namespace detail {
+// does `m.data()` give a double* (contiguous storage the library may write the matrix into)?
+template <class M, class = void>
+struct has_double_data : std::false_type {};
+template <class M>
+struct has_double_data<M, std::void_t<decltype(std::declval<M &>().data())>>
+    : std::is_convertible<decltype(std::declval<M &>().data()), double *> {};
+}  // namespace detail
 
 template <class MatdT, class PosDataT>
 MatdT computeSimilarityMatrix(const std::vector<std::vector<PosDataT>> &pos_data, uint32_t num_cells,
@@ -67,18 +80,26 @@ MatdT computeSimilarityMatrix(const std::vector<std::vector<PosDataT>> &pos_data
         chr_locus_off.push_back(static_cast<uint32_t>(locus_pos.size()));
     }
 
-    std::vector<double> flat(static_cast<size_t>(num_cells) * num_cells);
+    MatdT result(num_cells, num_cells);
+    std::vector<double> staging;  // only for matrix types without contiguous data()
+    double *out;
+    if constexpr (detail::has_double_data<MatdT>::value) {
+        out = result.data();
+    } else {
+        staging.resize(static_cast<size_t>(num_cells) * num_cells);
+        out = staging.data();
+    }
     const int rc = secedo_simmat_compute(
             chr_locus_off.data(), static_cast<uint32_t>(pos_data.size()), locus_pos.data(),
             locus_entry_off.data(), read_ids.data(), id_base.data(), nullptr, group_id_to_pos.data(),
             static_cast<uint32_t>(group_id_to_pos.size()), num_cells, max_fragment_length,
-            mutation_rate, homozygous_rate, seq_error_rate, num_threads, norm, flat.data());
+            mutation_rate, homozygous_rate, seq_error_rate, num_threads, norm, out);
     if (rc == SECEDO_E_INVALID_NORMALIZATION) throw std::logic_error("Invalid normalization: " + normalization);
     if (rc != SECEDO_OK) throw std::runtime_error(std::string("secedo_simmat: ") + secedo_simmat_last_error());
-
-    MatdT result(num_cells, num_cells);
-    for (uint32_t i = 0; i < num_cells; ++i) {
-        for (uint32_t j = 0; j < num_cells; ++j) result(i, j) = flat[static_cast<size_t>(i) * num_cells + j];
+    if constexpr (!detail::has_double_data<MatdT>::value) {
+        for (uint32_t i = 0; i < num_cells; ++i) {
+            for (uint32_t j = 0; j < num_cells; ++j) result(i, j) = staging[static_cast<size_t>(i) * num_cells + j];
+        }
     }
     return result;
 }

@@ -138,9 +138,11 @@ def oracle_compute(p, num_cells, max_fragment_length, group_id_to_pos=None, muta
     return (out, raw) if want_raw else out
 
 
-def set_exact_binomials(on: bool) -> None:
-    """See simmat_oracle.h: reference formula without the u64 binomial wrap (x_s + x_d > ~48)."""
-    _load_oracle().oracle_set_exact_binomials(1 if on else 0)
+def set_exact_binomials(on) -> None:
+    """See simmat_oracle.c: False/0 the reference bit for bit (default); True/1 the reference's formula
+    without the u64 binomial wrap (x_s + x_d > ~48); 2 exact only beyond x_s + x_d = 64 (what the MI355X
+    path documents for read pairs sharing more than 64 loci)."""
+    _load_oracle().oracle_set_exact_binomials(int(on))
 
 
 def set_direct_llr_sum(on: bool) -> None:

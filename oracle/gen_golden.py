@@ -158,6 +158,36 @@ def reference_pileup_files():
         save("ref_three_rows", p, [case(n, 1000, 1, norm) for norm in NORMS])
 
 
+def files_pipeline():
+    """SURVEY.md 8f-3 end to end, from the compiled reference: the reference's own tests/data pileup
+    FILES through its reader (util/pileup_reader.cpp), its locus filter (Filter::filter, all cells inside
+    the cluster) and computeSimilarityMatrix -- what divide_cluster does with a file
+    (spectral_clustering.cpp:336-356). ten_rows keeps 4 of its 10 loci; six_cells keeps none (the empty
+    pileup is a case of its own: every matrix entry is the constant of its normalisation)."""
+    data = os.path.join(GOLDEN, "data")
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for f in os.listdir(data):
+            if not f.endswith(".bin"):
+                shutil.copy(os.path.join(data, f), tmp)
+        for name in ("ten_rows", "six_cells"):
+            pos, off, rid, idb, ncell, mlen = ob.ref_read_pileup(os.path.join(tmp, name + ".pileup"), 1, "")
+            p = FlatPileup(np.asarray([0, len(pos)], dtype=np.uint32), pos, off, rid, idb)
+            n = int((p.id_base >> 2).max()) + 1
+            i2p = np.arange(n, dtype=np.uint32)
+            o_chr, o_pos, o_off, o_rid, o_idb, cov = ob.ref_filter(p, i2p, 0.01, 4)
+            fp = FlatPileup(o_chr, o_pos, o_off, o_rid, o_idb)
+            mfl = max(int(mlen), 2)
+            for k, v in dict(n_cells=np.uint32(n), mfl=np.uint32(mfl), kept_pos=o_pos, kept_off=o_off,
+                             kept_rid=o_rid, kept_idb=o_idb, avg_coverage=np.float64(cov)).items():
+                out[name + "__" + k] = v
+            for norm in NORMS:
+                out[name + "__" + norm] = ob.ref_compute(fp, n, mfl, i2p, 0.01, 0.5, 0.01, 1, norm)
+            print("files_pipeline %-10s cells %5d loci %3d -> %3d  mfl %d" % (name, n, p.n_loci, len(o_pos), mfl))
+    np.savez_compressed(os.path.join(GOLDEN, "ref_files_pipeline.npz"), theta=np.float64(0.01),
+                        cell_proportion=np.uint32(4), **out)
+
+
 def divide_clusters_shaped():
     """Input shaped like the reference's only test that reaches the path
     (tests/test_spectral_clustering.cpp:210-259): 100 cells, 5000 consecutive positions, all
@@ -208,6 +238,58 @@ def random_cases():
     p = random_pileup(103, 12, 1, 400, 6, 12, frag_min=120, frag_max=260, dup_frac=0.01)
     save("dense_12cells", p, [case(12, 1000, 1, norm) for norm in NORMS]
          + [case(12, 1000, 3, "ADD_MIN", theta=0.001)])
+
+
+def wrap_cases():
+    """Read pairs sharing 48-64 loci: there the reference's uint64_t binomial PRODUCTS wrap
+    (similarity_matrix.cpp:125, :159; single binomials up to row 64 still fit), and what it returns is
+    the wrapped sum -- D(60,4) = 0.464 where its own formula gives 0.578. The product reproduces exactly
+    that (llr_table.cpp: reference_llr), so these vectors come straight from the compiled reference.
+    `wrap_beyond64` goes further (reads of 70-100 loci): from 65 shared loci on the product returns the
+    closed form instead; the fixture records what the reference does there so that the test can state
+    the difference."""
+    # (a) known answers D(x_s, x_d) up to x_s + x_d = 64, as in kat_llr_table
+    params = [(0.01, 0.5, 0.01), (0.01, 0.15, 0.001)]
+    combos = [(48, 0), (50, 3), (60, 4), (32, 32), (64, 0), (0, 64), (40, 24), (24, 40), (63, 1), (47, 1),
+              (45, 10), (30, 30)]
+    table = np.zeros((len(params), len(combos)), dtype=np.float64)
+    for pi, (eps, h, theta) in enumerate(params):
+        for ci, (xs, xd) in enumerate(combos):
+            rows = [(1000 + 3 * k, [(1, 0, 0), (2, 1, 0 if k < xs else 1)]) for k in range(xs + xd)]
+            rows += far_dummies(100, 1000 + 3 * (xs + xd), 4, group=0)
+            m = ob.ref_compute(from_rows([rows]), 3, 1000, None, eps, h, theta, 1, "ADD_MIN")
+            table[pi, ci] = m[0, 2] - m[0, 1]
+    np.savez_compressed(os.path.join(GOLDEN, "kat_llr_wrap.npz"), params=np.asarray(params),
+                        combos=np.asarray(combos, dtype=np.uint32), table=table)
+    print("kat_llr_wrap: D(60,4)=%.15g D(64,0)=%.15g (eps,h,theta)=(0.01,0.5,0.01)" % (table[0, 2], table[0, 4]))
+    # (b) random dense pileups: fragments of 200-250 bp over loci 4 bp apart on average
+    p = random_pileup(104, 10, 1, 420, 5, 7, frag_min=200, frag_max=250, dup_frac=0.01)
+    save("wrap_dense_10cells", p, [case(10, 1000, 1, norm) for norm in NORMS]
+         + [case(10, 1000, 2, "ADD_MIN", h=0.15, theta=0.001)])
+    p = random_pileup(105, 8, 1, 500, 4, 7, frag_min=300, frag_max=400, dup_frac=0.0)
+    save("wrap_beyond64", p, [case(8, 1000, 1, "ADD_MIN")])
+
+
+def c2_reference_run():
+    """one 1000-cell run of the compiled reference (BASELINE config 2,
+    SYNTH-v1 seed 42: 1000 cells x 50000 loci, T = 8, ADD_MIN), kept as a digest: sha256 of the 8 MB
+    output, its maximum, its sum, and 1000 sampled entries (i, j, value). The input is regenerated by the
+    product's deterministic generator (secedo_amd.synth), whose entry/locus counts are stored too."""
+    import hashlib
+    from secedo_amd.synth import CONFIGS, synth_config
+    n_cells = CONFIGS["C2"][0]
+    p = synth_config("C2")
+    out = ob.ref_compute(p, n_cells, 1000, None, 0.01, 0.5, 0.01, 8, "ADD_MIN")
+    rng = np.random.default_rng(2024)
+    ii = rng.integers(0, n_cells, size=1000)
+    jj = rng.integers(0, n_cells, size=1000)
+    np.savez_compressed(os.path.join(GOLDEN, "c2_reference_digest.npz"),
+                        sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest(), dtype=np.uint8),
+                        max_abs=np.float64(np.max(np.abs(out))), total=np.float64(np.sum(out)),
+                        sample_i=ii.astype(np.uint32), sample_j=jj.astype(np.uint32), sample_v=out[ii, jj],
+                        n_entries=np.uint64(p.n_entries), n_loci=np.uint64(p.n_loci),
+                        params=np.asarray([n_cells, 1000, 0.01, 0.5, 0.01, 8, 0], dtype=np.float64))
+    print("c2_reference_digest: max %.6f sum %.6f" % (np.max(np.abs(out)), np.sum(out)))
 
 
 def filter_cases():
@@ -353,7 +435,7 @@ def main():
         sys.exit("oracle/_ref/libsecedo_ref.so missing: run `make -C oracle ref` in the container")
     os.makedirs(GOLDEN, exist_ok=True)
     for fn in (semantic_probes, kat_llr_table, reference_pileup_files, divide_clusters_shaped,
-               random_cases, filter_cases, reader_cases, laplacian_kat, em_cases):
+               random_cases, wrap_cases, c2_reference_run, files_pipeline, filter_cases, reader_cases, laplacian_kat, em_cases):
         if not only or fn.__name__ in only:
             fn()
 

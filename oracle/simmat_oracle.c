@@ -35,9 +35,12 @@ typedef struct {
  * (e.g. D(50,3) is off by 3e-6, D(60,4) by 0.11): its output there is an artefact of the wrap, not
  * the value of its own formula. oracle_set_exact_binomials(1) evaluates the SAME nested sums with a
  * long-double Pascal triangle, i.e. the reference formula in exact arithmetic; the default (0)
- * reproduces the reference bit for bit. Tests that push x_s + x_d beyond the wrap use mode 1. */
-static _Thread_local int g_exact_binomials = 0;
-void oracle_set_exact_binomials(int on) { g_exact_binomials = on; }
+ * reproduces the reference bit for bit. */
+static _Thread_local int g_exact_mode = 0;
+void oracle_set_exact_binomials(int on) { g_exact_mode = on; }
+/* Mode 2: exact binomials only for x_s + x_d > 64 -- what the MI355X path documents for read pairs that
+ * share more loci than its table of reference-identical terms covers. */
+#define g_exact_binomials (g_exact_mode == 1 || (g_exact_mode == 2 && x_s + x_d > 64))
 
 static double *pow_table(double base, uint32_t size) {
     /* similarity_matrix.cpp:53-65 start each table as {1, x}; :85-94 extend by

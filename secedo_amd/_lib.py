@@ -91,6 +91,10 @@ SIGNATURES = {
     "secedo_simmat_last_counts": (C.c_int, [_vp, _u64p, _u64p]),
     "secedo_simmat_last_accumulate_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "secedo_simmat_llr": (C.c_double, [C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double]),
+    "secedo_simmat_llr_closed_form": (C.c_double, [C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double]),
+    "secedo_simmat_pair_bound": (C.c_uint64, [_vp]),
+    "secedo_simmat_set_pair_bound": (C.c_int, [_vp, C.c_uint64]),
+    "secedo_simmat_scale_log2": (C.c_int, [_vp]),
     "secedo_is_significant": (C.c_int, [_vp, C.c_double, C.c_uint32]),
     "secedo_filter": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_double,
                                 C.c_uint32, _vp, _vp, _vp, _vp, _vp, _u64p, _u64p, _f64p]),
@@ -100,7 +104,6 @@ SIGNATURES = {
     "secedo_pileup_read": (C.c_int, [C.c_char_p, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint64, C.c_int, C.c_int,
                                      C.POINTER(PileupInfo), _vp, _vp, _vp, _vp]),
     "secedo_pileup_last_error": (C.c_char_p, []),
-    "secedo_synth_generate": (C.c_int, [C.POINTER(SynthSpec), _u64p, _u64p, _vp, _vp, _vp, _vp, _vp]),
     "secedo_em_refine_device": (C.c_int, [C.c_int, _vp, C.c_uint32, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_double,
                                           _vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), _vp]),
     "secedo_em_refine": (C.c_int, [C.c_int, _vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.c_double, _vp, C.c_uint32,

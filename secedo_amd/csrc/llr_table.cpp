@@ -1,7 +1,10 @@
 #include "llr_table.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
+#include <thread>
 
 namespace secedo {
 
@@ -57,8 +60,157 @@ double llr(const LlrModel &m, uint32_t x_s, uint32_t x_d) {
     return static_cast<double>(diff - same);
 }
 
+// ---- the reference's own evaluation --------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kRows = kLlrRefMax + 1;
+
+// Powers as the reference builds them (each entry = previous * base, similarity_matrix.cpp:85-94) and
+// Pascal's triangle in uint64_t (:95-101). Up to row 64 no single binomial wraps; the PRODUCTS do.
+struct RefTables {
+    double pss[kRows], psd[kRows], pds[kRows], pdd[kRows];
+    double a1[kRows], a2[kRows], b2[kRows], hh[kRows], ehalf[kRows];  // (1-e-h)^k (1-e/2-h)^k (h+e/2)^k h^k (e^k * .5^k)
+    double sum_s[kRows], sum_d[kRows];                                // (pss+pds)^k, (psd+pdd)^k
+    uint64_t comb[kRows][kRows];
+
+    RefTables(double eps, double h, double theta) {
+        const double t2 = theta * theta;
+        const double p_sd = 2 * theta * (1 - theta) + 2 * t2 / 3;  // :45
+        const double p_ss = 1 - p_sd;                              // :47
+        const double p_ds = 2 * (1 - theta) * theta / 3 + 2 * t2 / 9;  // :49
+        const double p_dd = 1 - p_ds;                              // :51
+        auto powers = [](double *out, double base) {
+            out[0] = 1;
+            out[1] = base;
+            for (uint32_t k = 2; k < kRows; ++k) out[k] = out[k - 1] * base;
+        };
+        powers(pss, p_ss);
+        powers(psd, p_sd);
+        powers(pds, p_ds);
+        powers(pdd, p_dd);
+        powers(a1, 1 - eps - h);
+        powers(a2, 1 - eps * 0.5 - h);
+        powers(b2, h + eps * 0.5);
+        powers(hh, h);
+        powers(sum_s, p_ss + p_ds);
+        powers(sum_d, p_sd + p_dd);
+        double e[kRows], half[kRows];
+        powers(e, eps);
+        powers(half, 0.5);
+        for (uint32_t k = 0; k < kRows; ++k) ehalf[k] = e[k] * half[k];  // the reference multiplies the two (:131-132)
+        for (uint32_t n = 0; n < kRows; ++n) {
+            comb[n][0] = comb[n][n] = 1;
+            for (uint32_t i = 1; i < n; ++i) comb[n][i] = comb[n - 1][i - 1] + comb[n - 1][i];
+        }
+    }
+
+    // :153-170. Terms are positive, so the order of the floating-point factors moves the sum by a few
+    // ulp only; the integer product is what must be reproduced exactly.
+    double log_same(uint32_t xs, uint32_t xd) const {
+        double p = 0;
+        for (uint32_t k = 0; k <= xs; ++k) {
+            for (uint32_t l = 0; l <= xd; ++l) {
+                const uint64_t c = comb[xs][k] * comb[xd][l];
+                p += static_cast<double>(c) * a2[k + l] * 0.5 * (pss[k] * psd[l] + pds[k] * pdd[l])
+                        * b2[xs + xd - k - l] * pss[xs - k] * psd[xd - l];
+            }
+        }
+        p *= static_cast<double>(comb[xs + xd][xs]);
+        return std::log(p);
+    }
+
+    // :117-141: k, l = loci where the genotypes truly differ ...; the four binomials are one uint64_t
+    // product, evaluated left to right as in the reference expression.
+    double log_diff(uint32_t xs, uint32_t xd) const {
+        double prob = 0;
+        for (uint32_t k = 0; k <= xs; ++k) {
+            for (uint32_t l = 0; l <= xd; ++l) {
+                const uint64_t ckl = comb[xs][k] * comb[xd][l];
+                const double f = a1[k + l] * 0.5 * (pss[k] * psd[l] + pds[k] * pdd[l]);
+                double inner = 0;
+                for (uint32_t p = 0; p <= xs - k; ++p) {
+                    const uint64_t cp = ckl * comb[xs - k][p];
+                    const double g = sum_s[xs - k - p] * pss[p];
+                    const uint64_t *row = comb[xd - l];
+                    for (uint32_t q = 0; q <= xd - l; ++q) {
+                        const uint64_t c = cp * row[q];
+                        inner += static_cast<double>(c) * ehalf[xs + xd - k - l - p - q] * g
+                                * sum_d[xd - l - q] * hh[p + q] * psd[q];
+                    }
+                }
+                prob += f * inner;
+            }
+        }
+        prob *= static_cast<double>(comb[xs + xd][xs]);
+        return std::log(prob);
+    }
+};
+
+}  // namespace
+
+double reference_llr(double eps, double h, double theta, uint32_t x_s, uint32_t x_d) {
+    if (x_s + x_d > kLlrRefMax) return std::nan("");
+    const RefTables rt(eps, h, theta);
+    return rt.log_diff(x_s, x_d) - rt.log_same(x_s, x_d);
+}
+
+bool llr_exact_mode() {
+    const char *env = std::getenv("SECEDO_LLR_EXACT");
+    return env && std::atoi(env) != 0;
+}
+
+bool extend_reference(LlrTable *t, uint32_t max_shared) {
+    const uint32_t want = std::min(max_shared, kLlrRefMax);
+    bool finite = true;
+    auto check = [&](uint32_t upto) {
+        for (uint32_t s = 0; s <= upto; ++s)
+            for (uint32_t d = 0; s + d <= upto; ++d)
+                if (s + d > 0 && !std::isfinite(t->value[s * kLlrTableDim + d])) finite = false;
+    };
+    if (llr_exact_mode() || want <= t->ref_upto) {
+        check(want);
+        return finite;
+    }
+    // the entries (ref_upto, want], heaviest first, shared among a few threads (O(x_s^2 x_d^2) each:
+    // about 1e8 terms for the whole triangle up to 64)
+    std::vector<std::pair<uint32_t, uint32_t>> todo;
+    for (uint32_t n = want; n > t->ref_upto; --n)
+        for (uint32_t s = 0; s <= n; ++s) todo.push_back({s, n - s});
+    auto cost = [](const std::pair<uint32_t, uint32_t> &e) {
+        return (uint64_t)(e.first + 1) * (e.first + 1) * (e.second + 1) * (e.second + 1);
+    };
+    std::sort(todo.begin(), todo.end(), [&](const auto &a, const auto &b) { return cost(a) > cost(b); });
+    const RefTables rt(t->eps, t->h, t->theta);
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t i; (i = next.fetch_add(1)) < todo.size();) {
+            const uint32_t s = todo[i].first, d = todo[i].second;
+            t->value[s * kLlrTableDim + d] = rt.log_diff(s, d) - rt.log_same(s, d);
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_threads = want >= 32 ? std::max(1u, std::min(hw ? hw : 1u, 16u)) : 1u;
+    std::vector<std::thread> pool;
+    for (unsigned i = 1; i < n_threads; ++i) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    t->ref_upto = want;
+    double per_locus = 0;
+    for (uint32_t s = 0; s < kLlrTableDim; ++s)
+        for (uint32_t d = 0; d < kLlrTableDim; ++d) {
+            const double v = t->value[s * kLlrTableDim + d];
+            if (s + d && std::isfinite(v)) per_locus = std::max(per_locus, std::fabs(v) / (s + d));
+        }
+    t->max_abs_per_locus = per_locus;
+    check(want);
+    return finite;
+}
+
 LlrTable make_llr_table(double eps, double h, double theta, uint64_t pair_bound) {
     LlrTable t;
+    t.eps = eps;
+    t.h = h;
+    t.theta = theta;
     t.model = make_llr_model(eps, h, theta);
     t.value.assign(kLlrTableDim * kLlrTableDim, 0.0);
     t.fixed.assign(kLlrTableDim * kLlrTableDim, 0);

@@ -10,6 +10,14 @@
 //
 // so D = log P_diff - log P_same needs no binomial at all. Only D leaves the reference function
 // (similarity_matrix.cpp:428), hence only D is tabulated here.
+//
+// The closed form is the value of the reference's formula in exact arithmetic. The reference itself
+// multiplies its binomials as uint64_t before the product becomes a double (:125, :159), and those
+// products wrap from about x_s + x_d = 48 on: what it returns there is the wrapped sum, not the formula
+// (D(60,4) differs by 0.11). A drop-in must return what the reference returns, so the table entries a
+// pileup can reach (x_s + x_d <= longest read, up to 64) are evaluated by reference_llr(), which
+// restates the reference's nested sums with the same wrapping integer arithmetic; the closed form
+// serves beyond the table (read pairs sharing more than 64 loci) and under SECEDO_LLR_EXACT=1.
 #pragma once
 
 #include <cstdint>
@@ -30,9 +38,17 @@ LlrModel make_llr_model(double mutation_rate, double homozygous_rate, double seq
 double llr(const LlrModel &m, uint32_t x_s, uint32_t x_d);
 
 constexpr uint32_t kLlrTableDim = 65;  // x_s, x_d in [0, 64]: one 32-locus window either side + 1
+constexpr uint32_t kLlrRefMax = 64;    // entries with x_s + x_d <= this can be made reference-identical
+
+// D(x_s, x_d) as the reference computes it: log of the four-fold sum of :117-141 minus log of the
+// two-fold sum of :153-170, binomials multiplied in uint64_t (wrap-around kept). x_s + x_d <= kLlrRefMax.
+double reference_llr(double mutation_rate, double homozygous_rate, double seq_error_rate, uint32_t x_s,
+                     uint32_t x_d);
 
 struct LlrTable {
     LlrModel model;
+    double eps = 0, h = 0, theta = 0;
+    uint32_t ref_upto = 0;         // entries with 1 <= x_s + x_d <= ref_upto hold reference_llr()
     int scale_log2;                // fixed point: value = round(D * 2^scale_log2)
     double max_abs_per_locus;      // max over the table of |D| / (x_s + x_d)
     std::vector<int64_t> fixed;    // kLlrTableDim^2, row = x_s
@@ -48,5 +64,11 @@ LlrTable make_llr_table(double mutation_rate, double homozygous_rate, double seq
 int llr_scale_for(const LlrTable &t, uint64_t pair_bound);
 // re-derive t->fixed from t->value for another scale
 void requantize(LlrTable *t, int scale_log2);
+// Make the entries with x_s + x_d <= max_shared (capped at kLlrRefMax) reference-identical (no-op for
+// those that already are, and under SECEDO_LLR_EXACT=1). t->fixed is stale afterwards: requantize.
+// Returns false when one of those entries is not finite (rates for which the reference itself
+// produces inf / NaN, e.g. a sequencing error rate of 0).
+bool extend_reference(LlrTable *t, uint32_t max_shared);
+bool llr_exact_mode();  // SECEDO_LLR_EXACT=1: the closed form everywhere
 
 }  // namespace secedo

@@ -66,6 +66,7 @@ struct Scalars {
     uint32_t long_reads;  // some id's entries span >= max_fragment_length: flushes may split it (k_split_update)
     uint32_t split_changed;
     uint32_t id_exceeded;  // the id space is larger than the caller assumed (the size of the previous call)
+    uint32_t max_read_entries;  // kept entries of the longest read id run
     unsigned long long id_space;  // sum over chromosomes of (largest - smallest read id + 1)
     unsigned long long multi_entries;
     unsigned long long pair_bound;
@@ -431,9 +432,11 @@ __global__ __launch_bounds__(TPB) void k_read_info(Raw in, const unsigned long l
                                                   uint32_t *starts_by_rank, uint32_t *rbeg, uint32_t *read_off,
                                                   Scalars *sc) {
     __shared__ unsigned long long part[TPB / 64];
+    __shared__ uint32_t part_len[TPB / 64];
     const uint32_t n = in.n_entries;
     const uint32_t n_runs = incl_reads(incl[n - 1]);
     unsigned long long multi = 0;
+    uint32_t longest = 0;
     for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r < n_runs; r += gridDim.x * TPB) {
         const uint32_t s0 = run_start[r], s1 = run_start[r + 1];
         const uint32_t e0 = sval[s0];
@@ -449,18 +452,30 @@ __global__ __launch_bounds__(TPB) void k_read_info(Raw in, const unsigned long l
         read_off[r] = k0;
         if (r == n_runs - 1) read_off[n_runs] = k1;
         if (k1 - k0 > 1) multi += k1 - k0;
+        longest = max(longest, k1 - k0);
     }
     for (uint32_t c = blockIdx.x * TPB + threadIdx.x; c <= in.n_chr; c += gridDim.x * TPB) {
         rbeg[c] = arank[(uint32_t)in.locus_entry_off[in.chr_locus_off[c]]];
     }
     // one atomic per workgroup: same-address atomics are slow
-    for (int off = 32; off > 0; off >>= 1) multi += __shfl_down(multi, off);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = multi;
+    for (int off = 32; off > 0; off >>= 1) {
+        multi += __shfl_down(multi, off);
+        longest = max(longest, (uint32_t)__shfl_down(longest, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6] = multi;
+        part_len[threadIdx.x >> 6] = longest;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long sum = 0;
-        for (int w = 0; w < TPB / 64; ++w) sum += part[w];
+        uint32_t len = 0;
+        for (int w = 0; w < TPB / 64; ++w) {
+            sum += part[w];
+            len = max(len, part_len[w]);
+        }
         if (sum) atomicAdd(&sc->multi_entries, sum);
+        if (len > 1) atomicMax(&sc->max_read_entries, len);  // reads of one entry are the rule: no atomic for them
     }
 }
 
@@ -1221,6 +1236,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     const uint32_t R = (uint32_t)totals, n_kept = (uint32_t)(totals >> 32);
     const size_t nk = std::max<uint32_t>(n_kept, 1);
     pk.multi_entries = hsc.multi_entries;
+    pk.max_read_entries = std::max(hsc.max_read_entries, n_kept ? 1u : 0u);
     if (block_cells == 0) {
         const StageGeometry g64 = geometry(64);
         const bool clustered = n_kept && (double)pk.multi_entries > g64.masks_threshold * (double)n_kept;

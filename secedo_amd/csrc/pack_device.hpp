@@ -47,6 +47,7 @@ struct DevicePacked {
     DeviceArena scratch[13];  // temporaries, kept between calls to avoid re-allocation
     uint32_t num_cells = 0, block_cells = 0, num_blocks = 0, num_loci = 0, num_ranges = 0;
     uint64_t num_entries = 0, num_reads = 0, pair_bound = 0, multi_entries = 0;
+    uint32_t max_read_entries = 0;  // kept entries of the longest read (before flush splits: an upper bound)
     bool stage_masks = false;
     bool count_tile = false;
     uint32_t cap_entries = 0, cap_loci = 0;

@@ -167,6 +167,7 @@ std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t m
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t n = pk.read_off[r + 1] - pk.read_off[r];
         if (n > 1) pk.multi_entries += n;
+        pk.max_read_entries = std::max(pk.max_read_entries, n);
     }
     if (block_cells == 0) {
         const StageGeometry g64 = geometry(64);

@@ -83,6 +83,7 @@ struct PackedPileup {
     uint64_t raw_entries = 0;   // entries of the input pileup
     uint64_t pair_bound = 0;    // max over cells of sum_l n_cell(l)^2 (Cauchy-Schwarz bound)
     uint64_t multi_entries = 0; // entries of reads with more than one kept entry
+    uint32_t max_read_entries = 0; // kept entries of the longest read: no read pair shares more loci
     bool any_window_overflow = false;
     bool stage_masks = false;
     bool count_tile = false;    // the accumulate kernel may use the 2 x 16-bit count tile

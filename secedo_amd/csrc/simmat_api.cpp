@@ -100,6 +100,7 @@ struct secedo_simmat {
     bool have_model = false, have_lut = false, have_slow = false;
     double lut_eps = 0, lut_h = 0, lut_theta = 0;
     int scale_log2 = 44;
+    uint64_t pair_bound_override = 0;  // secedo_simmat_set_pair_bound
     secedo::LlrModel model;
     secedo::LlrTable table;
     secedo::SlowPathArgs slow_host;
@@ -197,6 +198,12 @@ int secedo_simmat_normalization_from_string(const char *name) {
 }
 
 double secedo_simmat_llr(uint32_t x_s, uint32_t x_d, double eps, double h, double theta) {
+    if (x_s + x_d >= 1 && x_s + x_d <= secedo::kLlrRefMax && !secedo::llr_exact_mode())
+        return secedo::reference_llr(eps, h, theta, x_s, x_d);
+    return secedo::llr(secedo::make_llr_model(eps, h, theta), x_s, x_d);
+}
+
+double secedo_simmat_llr_closed_form(uint32_t x_s, uint32_t x_d, double eps, double h, double theta) {
     return secedo::llr(secedo::make_llr_model(eps, h, theta), x_s, x_d);
 }
 
@@ -416,6 +423,7 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
         pk.num_reads = hp_pk.num_reads;
         pk.pair_bound = hp_pk.pair_bound;
         pk.multi_entries = hp_pk.multi_entries;
+        pk.max_read_entries = hp_pk.max_read_entries;
         pk.stage_masks = hp_pk.stage_masks;
         pk.count_tile = hp_pk.count_tile;
         pk.cap_entries = hp_pk.cap_entries;
@@ -458,6 +466,14 @@ uint64_t secedo_simmat_num_entries(const secedo_simmat_t *h) { return h ? h->pk.
 uint64_t secedo_simmat_num_reads(const secedo_simmat_t *h) { return h ? h->pk.num_reads : 0; }
 uint64_t secedo_simmat_num_loci(const secedo_simmat_t *h) { return h ? h->pk.num_loci : 0; }
 
+uint64_t secedo_simmat_pair_bound(const secedo_simmat_t *h) { return h ? h->pk.pair_bound : 0; }
+int secedo_simmat_scale_log2(const secedo_simmat_t *h) { return h ? h->scale_log2 : 0; }
+int secedo_simmat_set_pair_bound(secedo_simmat_t *h, uint64_t pair_bound) {
+    if (!h) return fail(SECEDO_E_INVALID_ARG, "handle is null");
+    h->pair_bound_override = pair_bound;
+    return SECEDO_OK;
+}
+
 int secedo_simmat_zero_acc(secedo_simmat_t *h, int64_t *d_acc, void *stream) {
     if (!h || !d_acc) return fail(SECEDO_E_INVALID_ARG, "null argument");
     if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
@@ -498,8 +514,18 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         h->have_model = true;
         h->have_lut = false;
     }
+    // the entries this pileup can reach (no read pair shares more loci than its shorter read has) as the
+    // reference evaluates them, wrapping binomial products included (llr_table.hpp)
+    if (h->table.ref_upto < std::min(h->pk.max_read_entries, secedo::kLlrRefMax) && !secedo::llr_exact_mode())
+        h->have_lut = false;
+    if (!secedo::extend_reference(&h->table, h->pk.max_read_entries))
+        return fail(SECEDO_E_INVALID_ARG, "these rates give a non-finite log-likelihood ratio (log of 0: the reference "
+                                          "would write inf / NaN into the matrix)");
     {
-        const int want_scale = secedo::llr_scale_for(h->table, h->pk.pair_bound);
+        // the fixed-point scale follows the pair bound of everything that is summed into one accumulator:
+        // this pileup's own bound, or the one the caller set for all the shards that will be added up
+        const uint64_t bound = h->pair_bound_override ? std::max(h->pair_bound_override, h->pk.pair_bound) : h->pk.pair_bound;
+        const int want_scale = secedo::llr_scale_for(h->table, bound);
         if (!h->have_lut || want_scale != h->scale_log2) {
             secedo::requantize(&h->table, want_scale);
             HIP_TRY(h->lut.ensure(h->table.fixed.size() * sizeof(int64_t)));
@@ -528,6 +554,14 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         }
     }
 
+    if (h->pk.num_entries == 0) {
+        // nothing to add (a rank whose shard is empty): the table and the scale above are all finalize needs
+        HIP_TRY(hipMemsetAsync(h->counters.p, 0, 16 * sizeof(unsigned long long), s));
+        HIP_TRY(hipEventRecord(h->ev_begin, s));
+        HIP_TRY(hipEventRecord(h->ev_end, s));
+        h->timed = true;
+        return SECEDO_OK;
+    }
     const uint32_t n_tiles = tile_end - tile_begin;
     secedo::AccumulateArgs a;
     a.blk_off = h->pk.blk_off.as<uint32_t>();
@@ -868,7 +902,11 @@ int secedo_filter_device(const uint32_t *d_chr_locus_off, uint32_t n_chr, const 
     in.n_loci = n_loci;
     in.n_entries = n_entries;
     secedo::FilterOut out{d_out_chr_locus_off, d_out_locus_pos, d_out_locus_entry_off, d_out_read_ids, d_out_id_base};
-    static thread_local secedo::FilterWorkspace ws;
+    // scratch kept between calls, one set per device (allocations belong to the device they were made on)
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    static thread_local std::map<int, secedo::FilterWorkspace> workspaces;
+    secedo::FilterWorkspace &ws = workspaces[device];
     const std::string err = secedo::filter_device(in, seq_error_rate, cell_proportion,
                                                   static_cast<hipStream_t>(stream), &ws, out, out_n_loci,
                                                   out_n_entries, avg_coverage);

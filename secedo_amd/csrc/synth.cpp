@@ -10,7 +10,7 @@
 // fragments gets a second (mate) entry at one of their first three loci, half of them with a
 // conflicting base (exercises reference: similarity_matrix.cpp:387-395). Read ids are consecutive
 // and restart at 0 in every chromosome (a read is identified by its id within a chromosome, :407).
-#include "secedo_simmat.h"
+#include "synth.h"
 
 #include <cstring>
 #include <vector>
@@ -119,10 +119,10 @@ extern "C" int secedo_synth_generate(const secedo_synth_spec *spec, uint64_t *n_
                                      uint64_t *n_entries, uint32_t *chr_locus_off,
                                      uint32_t *locus_pos, uint64_t *locus_entry_off,
                                      uint32_t *read_ids, uint32_t *id_base32) {
-    if (!spec || !n_loci || !n_entries) return SECEDO_E_INVALID_ARG;
+    if (!spec || !n_loci || !n_entries) return -1;
     if (spec->num_cells == 0 || spec->num_cells > 65535 || spec->gap_max == 0
         || spec->frag_max < spec->frag_min || spec->frag_min == 0)
-        return SECEDO_E_INVALID_ARG;
+        return -1;
     const bool sizing = !chr_locus_off && !locus_pos && !locus_entry_off && !read_ids && !id_base32;
     if (sizing || !g_have) {
         generate(*spec, g_result);
@@ -130,9 +130,9 @@ extern "C" int secedo_synth_generate(const secedo_synth_spec *spec, uint64_t *n_
     }
     *n_loci = g_result.pos.size();
     *n_entries = g_result.rid.size();
-    if (sizing) return SECEDO_OK;
+    if (sizing) return 0;
     if (!chr_locus_off || !locus_pos || !locus_entry_off || !read_ids || !id_base32)
-        return SECEDO_E_INVALID_ARG;
+        return -1;
     std::memcpy(chr_locus_off, g_result.chr_off.data(), g_result.chr_off.size() * sizeof(uint32_t));
     std::memcpy(locus_pos, g_result.pos.data(), g_result.pos.size() * sizeof(uint32_t));
     std::memcpy(locus_entry_off, g_result.off.data(), g_result.off.size() * sizeof(uint64_t));
@@ -140,5 +140,5 @@ extern "C" int secedo_synth_generate(const secedo_synth_spec *spec, uint64_t *n_
     std::memcpy(id_base32, g_result.idb.data(), g_result.idb.size() * sizeof(uint32_t));
     g_result = Result();
     g_have = false;
-    return SECEDO_OK;
+    return 0;
 }

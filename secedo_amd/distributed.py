@@ -91,15 +91,39 @@ def chromosome_shard(p, rank, world):
                       p.id_base[e0:e1])
 
 
+def agree_on_shard_geometry(plan, prepare, world, device="cpu", group=None):
+    """Chromosome shards are summed into ONE accumulator, so the ranks must use the same tile edge and the
+    same fixed-point scale, and both are chosen from a shard's own statistics: the tile edge becomes the
+    smallest any rank chose (`prepare(block_cells)` packs again when it differs), the pair bound that
+    decides the scale becomes the SUM of the shards' bounds (the bound of the whole pileup is at most
+    that; a rank whose shard is empty takes part with 0 and gets the common scale all the same).
+    `device`: where the two-word exchange lives ("cuda" under RCCL, "cpu" under gloo).
+    Returns (block_cells, pair_bound)."""
+    import torch
+    import torch.distributed as dist
+    if world <= 1:
+        return plan.block_cells, plan.pair_bound
+    b = torch.tensor([plan.block_cells], dtype=torch.int64, device=device)
+    dist.all_reduce(b, op=dist.ReduceOp.MIN, group=group)
+    block_cells = int(b.item())
+    if block_cells != plan.block_cells:
+        prepare(block_cells)
+    s = torch.tensor([plan.pair_bound], dtype=torch.int64, device=device)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    plan.set_pair_bound(max(int(s.item()), 1))
+    return block_cells, int(s.item())
+
+
 def chromosome_sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate, world, group=None):
-    """`plan` holds this rank's chromosomes (chromosome_shard; the same block_cells on every rank):
-    accumulate all tiles over them into the zeroed `acc`, then sum the accumulators of all ranks."""
+    """`plan` holds this rank's chromosomes (chromosome_shard; the same block_cells and pair bound on every
+    rank: agree_on_shard_geometry): accumulate all tiles over them into the zeroed `acc`, then sum the
+    accumulators of all ranks. A rank with an empty shard still calls accumulate (it sets up the table and
+    the scale that finalize needs)."""
     import torch.distributed as dist
 
     n = plan.acc_elems
     acc[:n].zero_()
-    if plan.num_entries:
-        plan.accumulate(acc, mutation_rate, homozygous_rate, seq_error_rate)
+    plan.accumulate(acc, mutation_rate, homozygous_rate, seq_error_rate)
     if world > 1:
         if acc.is_cuda and dist.get_backend(group) != "nccl":
             summed = acc[:n].cpu()  # rehearsal backends (gloo) move host memory

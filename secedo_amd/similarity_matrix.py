@@ -78,8 +78,17 @@ def compute_similarity_matrix(pos_data: Union[FlatPileup, Sequence[Sequence[PosD
 
 def llr(x_s: int, x_d: int, mutation_rate: float, homozygous_rate: float,
         seq_error_rate: float) -> float:
-    """D(x_s, x_d) = log P_diff - log P_same as the device tables hold it (host-only)."""
+    """D(x_s, x_d) = log P_diff - log P_same as the device tables hold it (host-only): what the
+    reference's nested sums return for x_s + x_d <= 64 (uint64 wrap of its binomial products included),
+    the closed form of those sums beyond."""
     return float(_lib.lib().secedo_simmat_llr(x_s, x_d, mutation_rate, homozygous_rate, seq_error_rate))
+
+
+def llr_closed_form(x_s: int, x_d: int, mutation_rate: float, homozygous_rate: float,
+                    seq_error_rate: float) -> float:
+    """The reference's formula (similarity_matrix.cpp:117-170) in exact arithmetic, any x_s, x_d."""
+    return float(_lib.lib().secedo_simmat_llr_closed_form(x_s, x_d, mutation_rate, homozygous_rate,
+                                                          seq_error_rate))
 
 
 class SimilarityMatrixPlan:
@@ -204,6 +213,23 @@ class SimilarityMatrixPlan:
     @property
     def num_loci(self) -> int:
         return int(_lib.lib().secedo_simmat_num_loci(self._h))
+
+    @property
+    def pair_bound(self) -> int:
+        """Upper bound on the (read pair, shared locus) incidences one cell pair can collect from the
+        prepared pileup; decides the fixed-point scale of the accumulator (secedo_simmat.h)."""
+        return int(_lib.lib().secedo_simmat_pair_bound(self._h))
+
+    def set_pair_bound(self, pair_bound: int):
+        """The bound of everything that will be summed into one accumulator (chromosome shards on several
+        ranks: the sum of the shards' bounds), so that all of them quantise with the same scale."""
+        _lib.check(_lib.lib().secedo_simmat_set_pair_bound(self._h, int(pair_bound)))
+        return self
+
+    @property
+    def scale_log2(self) -> int:
+        """log2 of the fixed-point scale of the last accumulate()."""
+        return int(_lib.lib().secedo_simmat_scale_log2(self._h))
 
     # -- device work -----------------------------------------------------------------------
     def _stream(self):

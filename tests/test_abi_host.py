@@ -34,6 +34,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     # and the Python binding table covers exactly the header
     assert declared == set(_lib.SIGNATURES)
+    # the product library exports the declared interfaces and nothing else of its own (the synthetic
+    # pileup generator of the bench lives in libsecedo_synth.so)
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (secedo_[a-z0-9_]+)$", nm, flags=re.M))
+    assert exported == declared, exported ^ declared
 
 
 def test_version_and_device_count():
@@ -86,19 +91,49 @@ def test_llr_closed_form_equals_reference_sums(eps, h, theta):
             if xs + xd == 0 or xs + xd > 44:
                 continue
             ref = ob.oracle_log_prob_diff(xs, xd, eps, h, theta) - ob.oracle_log_prob_same(xs, xd, eps, h, theta)
-            got = secedo_amd.llr(xs, xd, eps, h, theta)
+            got = secedo_amd.llr_closed_form(xs, xd, eps, h, theta)
             worst = max(worst, abs(got - ref) / max(1.0, abs(ref)))
     assert worst < 2e-12
 
 
-def test_llr_beyond_reference_range_matches_exact_binomials():
+def test_llr_closed_form_matches_exact_binomials_anywhere():
     ob.set_exact_binomials(True)
     try:
         for xs, xd in [(50, 3), (60, 4), (64, 64), (70, 10), (3, 64)]:
             ref = ob.oracle_log_prob_diff(xs, xd, 0.01, 0.5, 0.01) - ob.oracle_log_prob_same(xs, xd, 0.01, 0.5, 0.01)
-            assert abs(secedo_amd.llr(xs, xd, 0.01, 0.5, 0.01) - ref) < 1e-12 * max(1.0, abs(ref))
+            assert abs(secedo_amd.llr_closed_form(xs, xd, 0.01, 0.5, 0.01) - ref) < 1e-12 * max(1.0, abs(ref))
+            if xs + xd > 64:  # beyond the table of reference-identical terms the device uses the closed form
+                assert secedo_amd.llr(xs, xd, 0.01, 0.5, 0.01) == secedo_amd.llr_closed_form(xs, xd, 0.01, 0.5, 0.01)
     finally:
         ob.set_exact_binomials(False)
+
+
+@pytest.mark.parametrize("eps,h,theta", LLR_PARAMS[:3])
+def test_llr_table_is_reference_identical_up_to_64_shared_loci(eps, h, theta):
+    """The terms the device tables hold (x_s + x_d <= 64) are the reference's, wrap-around of its uint64
+    binomial products included (similarity_matrix.cpp:95-101, :125, :159): D(60,4) is 0.464 in the
+    reference and 0.578 by its formula. Checked against the restated sums of the oracle (default mode =
+    the reference bit for bit) on a grid that covers the wrapping region."""
+    grid = [(xs, xd) for xs in range(0, 65, 4) for xd in range(0, 65 - xs, 5) if xs + xd] \
+        + [(50, 3), (60, 4), (64, 0), (0, 64), (32, 32), (47, 1), (1, 63)]
+    wrapped = 0
+    for xs, xd in grid:
+        ref = ob.oracle_log_prob_diff(xs, xd, eps, h, theta) - ob.oracle_log_prob_same(xs, xd, eps, h, theta)
+        got = secedo_amd.llr(xs, xd, eps, h, theta)
+        assert abs(got - ref) <= 1e-11 * max(1.0, abs(ref)), (xs, xd, got, ref)
+        wrapped += abs(got - secedo_amd.llr_closed_form(xs, xd, eps, h, theta)) > 1e-9
+    assert wrapped >= 5  # the grid does reach the region where the reference departs from its formula
+
+
+def test_llr_wrap_kat_from_reference_matrices():
+    """Known answers read off matrices of the compiled reference for read pairs sharing 48-64 loci
+    (tests/golden/kat_llr_wrap.npz, oracle/gen_golden.py: wrap_cases)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "kat_llr_wrap.npz"))
+    for pi, (eps, h, theta) in enumerate(z["params"]):
+        for ci, (xs, xd) in enumerate(z["combos"]):
+            d = secedo_amd.llr(int(xs), int(xd), eps, h, theta)
+            # (the matrix entries are sums of two ~50-term logs minus each other: 1e-12 absolute)
+            assert abs(d - z["table"][pi, ci]) <= 2e-12 * max(1.0, abs(d)), (xs, xd, d, z["table"][pi, ci])
 
 
 def test_llr_kat_from_reference_matrices():
@@ -141,8 +176,9 @@ def test_flatten_round_trip():
 def test_cpp_shim_compiles_and_keeps_the_error_contract(tmp_path):
     exe = str(tmp_path / "shim_test")
     subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    "-I" + os.path.join(ROOT, "secedo_amd", "csrc"),
                     os.path.join(ROOT, "tests", "cpp", "shim_test.cpp"), "-o", exe,
-                    "-L" + os.path.join(ROOT, "secedo_amd"), "-lsecedo_simmat",
+                    "-L" + os.path.join(ROOT, "secedo_amd"), "-lsecedo_simmat", "-lsecedo_synth",
                     "-Wl,-rpath," + os.path.join(ROOT, "secedo_amd")], check=True)
     empty = str(tmp_path / "empty.bin")
     open(empty, "wb").close()

@@ -146,6 +146,57 @@ def _shard_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+class FakeGeometryPlan:
+    """What agree_on_shard_geometry needs of a plan: a tile edge and a pair bound chosen from the shard."""
+
+    def __init__(self, block_cells, pair_bound):
+        self.block_cells, self.pair_bound, self.bound_set, self.repacked = block_cells, pair_bound, None, []
+
+    def set_pair_bound(self, b):
+        self.bound_set = b
+
+
+def _geometry_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 0: a deep shard (bound beyond 2^18, where the scale drops below 44); rank 1: an EMPTY shard
+        plan = FakeGeometryPlan([128, 64][rank], [300000, 0][rank])
+
+        def prepare(b):
+            plan.repacked.append(b)
+            plan.block_cells = b
+
+        got = sd.agree_on_shard_geometry(plan, prepare, world)
+        res = torch.tensor([got[0], got[1], plan.bound_set, len(plan.repacked)], dtype=torch.int64)
+        parts = [torch.zeros_like(res) for _ in range(world)]
+        dist.all_gather(parts, res)
+        if rank == 0:
+            out.put([p.tolist() for p in parts])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shards_agree_on_tile_edge_and_fixed_point_scale_gloo_world2():
+    """Chromosome shards are added into one accumulator: every rank must quantise with the same scale (the
+    SUM of the shards' pair bounds decides it -- ADVICE r01, high) and use the same tile edge (the smallest),
+    a rank with an empty shard included."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_geometry_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    # (tile edge, summed bound, bound handed to the plan, re-packs): rank 0 re-packed with 64, rank 1 did not
+    assert q.get(timeout=10) == [[64, 300000, 300000, 1], [64, 300000, 300000, 0]]
+
+
 def test_chromosome_sharded_accumulate_gloo_world2():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

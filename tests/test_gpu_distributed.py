@@ -141,6 +141,7 @@ def _chromosome_worker(rank, world, port, out_dir):
         with secedo_amd.SimilarityMatrixPlan(0) as plan:
             shard = sd.chromosome_shard(p, rank, world)
             plan.prepare(shard, n, 400, None, 2, block_cells=64)  # reads longer than mfl: flushes cut them
+            sd.agree_on_shard_geometry(plan, lambda b: plan.prepare(shard, n, 400, None, 2, block_cells=b), world)
             acc = plan.new_acc()
             acc.fill_(-5)  # garbage that the sharded path must overwrite
             sd.chromosome_sharded_accumulate(plan, acc, 0.01, 0.5, 0.01, world)
@@ -175,6 +176,58 @@ def test_chromosome_shards_reproduce_single_process_bitwise(tmp_path):
         assert np.array_equal(np.load(tmp_path / ("acc%d.npy" % r)), acc_single)
         assert np.array_equal(np.load(tmp_path / ("rank%d.npy" % r)), single)
     assert np.any(single != 0)
+
+
+def test_shards_with_pair_bounds_across_2_18_share_one_scale():
+    """the fixed-point scale drops below 44 once a shard's pair bound reaches 2^18, and
+    shards that are summed must use ONE scale. Chromosome 0 gives cell 0 sixteen reads at each of 1200 loci
+    (bound 16^2 x 1200 > 2^18 -> scale 43), the other chromosomes are shallow (scale 44 on their own).
+    With the bounds summed and set on every shard (what agree_on_shard_geometry does over RCCL), the
+    shards' accumulators add up to the single-process accumulator bit for bit; left to their own scales
+    they do not."""
+    import secedo_amd
+    from secedo_amd import distributed as sd
+    from tests.pileup_gen import from_rows
+
+    n, world = 20, 3
+    rng = np.random.default_rng(99)
+    rid = iter(range(1, 10 ** 7))
+    deep = []
+    for l in range(1200):
+        ents = [(next(rid), 0, int(rng.integers(0, 4))) for _ in range(16)]
+        ents += [(next(rid), int(c), int(rng.integers(0, 4))) for c in rng.choice(np.arange(1, n), 6, replace=False)]
+        deep.append((1000 + 2000 * l, ents))
+    shallow = [[(1000 + 2000 * l, [(next(rid), int(c), int(rng.integers(0, 4)))
+                                   for c in rng.choice(n, 8, replace=False)]) for l in range(300)]
+               for _ in range(2)]
+    p = from_rows([deep] + shallow)
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        plan.prepare(p, n, 1000, None, 1, block_cells=64)
+        full = plan.new_acc()
+        plan.accumulate(full, 0.01, 0.5, 0.01)
+        assert plan.pair_bound >= 1 << 18 and plan.scale_log2 == 43
+        want = plan.finalize(full, "ADD_MIN").clone()
+        shards = [sd.chromosome_shard(p, r, world) for r in range(world)]
+        assert [s.n_chr for s in shards] == [1, 1, 1]
+        bounds, own_scales = [], []
+        for s in shards:
+            plan.prepare(s, n, 1000, None, 1, block_cells=64)
+            bounds.append(plan.pair_bound)
+            part = plan.new_acc()
+            plan.accumulate(part, 0.01, 0.5, 0.01)
+            own_scales.append(plan.scale_log2)
+        assert own_scales == [43, 44, 44]  # the hole: each shard on its own picks another scale
+        total = torch.zeros_like(full)
+        for s in shards:
+            plan.prepare(s, n, 1000, None, 1, block_cells=64)
+            plan.set_pair_bound(sum(bounds))
+            part = plan.new_acc()
+            plan.accumulate(part, 0.01, 0.5, 0.01)
+            assert plan.scale_log2 == 43
+            total += part
+        assert torch.equal(total, full)
+        assert torch.equal(plan.finalize(total, "ADD_MIN"), want)  # finalize of the last shard: same scale
+        plan.set_pair_bound(0)
 
 
 def test_more_ranks_than_chromosomes_leave_empty_shards():

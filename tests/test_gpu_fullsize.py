@@ -24,6 +24,11 @@ def test_c2_full_size_against_the_oracle():
         ref = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 8, norm)
         assert gu.normwise_err(got, ref) <= 1e-9
         assert np.array_equal(got, got.T) and not np.any(np.diag(got))
+        # the element-wise report over entries with |ref| > 1e-6 max|ref|
+        big = np.abs(ref) > 1e-6 * np.max(np.abs(ref))
+        rel = np.abs(got - ref)[big] / np.abs(ref)[big]
+        print("\nC2 %s vs oracle, %d entries: norm-wise %.2e, element-wise relative max %.2e, 99.9-percentile %.2e"
+              % (norm, rel.size, gu.normwise_err(got, ref), rel.max(), np.percentile(rel, 99.9)))
     u_ref, pairs_ref = ob.oracle_last_updates(), ob.oracle_last_read_pairs()
     with secedo_amd.SimilarityMatrixPlan(0) as plan:
         plan.prepare(p, n, 1000, None, 8)

@@ -35,16 +35,59 @@ def test_hip_matches_reference_vectors(name):
         assert np.all(np.diag(got) == 0)
 
 
+def test_read_pairs_sharing_more_than_64_loci_documented_difference():
+    """Up to 64 shared loci the HIP path returns the reference's own terms (its wrapped uint64 binomial
+    products included: wrap_dense_10cells above is a vector of the compiled reference). Beyond 64 it
+    returns the reference's FORMULA in exact arithmetic, where the reference returns the wrapped sums
+    (DESIGN.md section 4). wrap_beyond64 holds the compiled reference's output for reads of 70-100 loci:
+    the HIP matrix equals the oracle in its "exact beyond 64" mode to 1e-9 and differs from the
+    reference's by what the wrap is worth there."""
+    p, cases = gu.load("wrap_beyond64")
+    c = cases[0]
+    got = hip(p, c)
+    ob.set_exact_binomials(2)
+    try:
+        want = ob.oracle_compute(p, c["num_cells"], c["mfl"], c["g2p"], c["eps"], c["h"], c["theta"], c["T"], c["norm"])
+    finally:
+        ob.set_exact_binomials(0)
+    assert gu.normwise_err(got, want) <= TOL
+    # the reference itself (bit-identical to the oracle's default mode) is somewhere else entirely
+    assert gu.normwise_err(got, c["out"]) > 1e-3
+
+
+def test_c2_reference_digest():
+    """one 1000-cell x 50K-locus run of the COMPILED REFERENCE (BASELINE
+    config 2, T = 8, ADD_MIN), kept as 1000 sampled entries + maximum + sum
+    (tests/golden/c2_reference_digest.npz). Norm-wise 1e-9, and the element-wise report."""
+    from secedo_amd.synth import synth_config
+    z = np.load(gu.GOLDEN + "/c2_reference_digest.npz")
+    n, mfl, eps, h, theta, T, _ = z["params"]
+    p = synth_config("C2")
+    assert p.n_entries == int(z["n_entries"]) and p.n_loci == int(z["n_loci"])
+    got = secedo_amd.compute_similarity_matrix(p, int(n), int(mfl), None, eps, h, theta, int(T), "", "ADD_MIN")
+    ref_max = float(z["max_abs"])
+    sv = got[z["sample_i"], z["sample_j"]]
+    err = np.abs(sv - z["sample_v"])
+    assert np.max(err) <= TOL * ref_max
+    assert abs(float(np.max(np.abs(got))) - ref_max) <= TOL * ref_max
+    assert abs(float(np.sum(got)) - float(z["total"])) <= TOL * abs(float(z["total"]))
+    big = np.abs(z["sample_v"]) > 1e-6 * ref_max
+    rel = err[big] / np.abs(z["sample_v"][big])
+    print("\nC2 vs compiled reference, %d sampled entries: norm-wise %.2e, element-wise relative max %.2e, "
+          "99.9-percentile %.2e" % (len(sv), np.max(err) / ref_max, np.max(rel), np.percentile(rel, 99.9)))
+    assert np.max(rel) <= 1e-8  # elements near 0 carry the reference's own cancellation error (SURVEY 7.2)
+
+
 RANDOM = [
     # seed, cells, chr, loci, cov, gap_max, mfl, T, frag_max, exact binomials in the oracle
     (21, 24, 2, 300, 8, 250, 1000, 1, 600, False),
     (22, 24, 2, 300, 8, 250, 200, 2, 600, False),      # reads longer than mfl: split at flush
     (23, 100, 1, 800, 20, 3000, 1000, 8, 600, False),  # two cell blocks of 64
     (24, 200, 3, 400, 30, 120, 1000, 4, 600, False),   # four blocks, clustered loci
-    # beyond the reference's own numeric range (its u64 binomial products wrap at x_s+x_d ~ 48):
-    # the oracle evaluates the reference formula with exact binomials there (simmat_oracle.h)
-    (25, 16, 1, 300, 6, 9, 1000, 1, 500, True),        # > 32 loci per read: window overflow path
-    (26, 70, 2, 700, 4, 5, 1000, 2, 700, True),        # > 64 shared loci: beyond the LLR table
+    # where the reference's u64 binomial products wrap (x_s + x_d from ~48 on) the HIP path returns the
+    # reference's wrapped terms up to 64 shared loci and the exact formula beyond (oracle mode 2)
+    (25, 16, 1, 300, 6, 9, 1000, 1, 500, 2),           # > 32 loci per read: window overflow path
+    (26, 70, 2, 700, 4, 5, 1000, 2, 700, 2),           # > 64 shared loci: beyond the LLR table
 ]
 
 
@@ -289,8 +332,9 @@ def test_cpp_host_without_torch(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "shim_test")
     subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"),
+                    "-I" + os.path.join(root, "secedo_amd", "csrc"),
                     os.path.join(root, "tests", "cpp", "shim_test.cpp"), "-o", exe,
-                    "-L" + os.path.join(root, "secedo_amd"), "-lsecedo_simmat",
+                    "-L" + os.path.join(root, "secedo_amd"), "-lsecedo_simmat", "-lsecedo_synth",
                     "-Wl,-rpath," + os.path.join(root, "secedo_amd")], check=True)
     n = 90
     p = random_pileup(41, n, 1, 600, 12, 400, dup_frac=0.03)
@@ -309,6 +353,9 @@ def test_cpp_host_without_torch(tmp_path):
         ref = ob.oracle_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 4, norm)
         assert gu.normwise_err(got, ref) <= TOL
         assert np.array_equal(got, secedo_amd.compute_similarity_matrix(p, n, 1000, None, 0.01, 0.5, 0.01, 4, "", norm))
+        # a matrix type without data(): the shim goes through a staging buffer and operator(), same bits
+        subprocess.run([exe, path, str(n), "1000", "4", norm, out + ".nodata", "nodata"], check=True)
+        assert np.array_equal(np.fromfile(out + ".nodata", dtype=np.float64).reshape(n, n), got)
     # the consumers through include/secedo_pipeline.hpp: eigenpairs and EM refinement, C++ vs the Python mirror
     out = str(tmp_path / "consumers.f64")
     subprocess.run([exe, path, str(n), "1000", "4", "ADD_MIN", out, "consumers"], check=True)
@@ -531,7 +578,7 @@ def test_randomised_differential_sweep():
         norm = secedo_amd.NORMALIZATIONS[it % 3]
         block = int(rng.choice([0, 64, 128]))
         mode = str(rng.choice(["auto", "host"]))
-        exact = gap <= 6 or (gap <= 40 and fmax >= 400)  # pairs may share > 48 loci: see simmat_oracle.h
+        exact = 2  # reference-identical up to 64 shared loci, the exact formula beyond (simmat_oracle.c)
         ob.set_exact_binomials(exact)
         try:
             ref, raw = ob.oracle_compute(p, n, mfl, g2p, 0.01, 0.5, 0.02, T, norm, want_raw=True)

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""traffic_json.py <dir> -- profiles/r02_traffic.json from the FETCH_SIZE / WRITE_SIZE passes that
+tools/refresh_profiles_r02.sh left under <dir>: per accumulate_tiles launch, with the counters calibrated
+on a known 1 GiB stream in the same run (tools/fetch_calib.hip) as MI355X_MICROARCH.md (HBM) prescribes."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+R = sys.argv[1]
+
+
+def per_kernel(sub, counter):
+    f = glob.glob(os.path.join(R, sub, "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        if row["Counter_Name"] == counter:
+            acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return acc
+
+
+GIB_KIB = float(1 << 20)
+cal_f = per_kernel("calib_FETCH_SIZE", "FETCH_SIZE")
+cal_w = per_kernel("calib_WRITE_SIZE", "WRITE_SIZE")
+pick = lambda d, name: next(sum(v) / len(v) for k, v in d.items() if name in k)
+f4, f16, w16 = pick(cal_f, "read4") / GIB_KIB, pick(cal_f, "read16") / GIB_KIB, pick(cal_w, "write16") / GIB_KIB
+fetch = per_kernel("pmc_FETCH_SIZE", "FETCH_SIZE")
+write = per_kernel("pmc_WRITE_SIZE", "WRITE_SIZE")
+name = next(k for k in fetch if "accumulate_tiles" in k)
+fk, wk = sum(fetch[name]) / len(fetch[name]), sum(write[name]) / len(write[name])
+# the kernel's loads are 4 bytes per lane (entry32 / offsets), its stores 16 bytes per lane (slab flush)
+hbm = (fk / f4 + wk / w16) * 1024.0
+print(json.dumps({
+    "_comment": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes over `python bench.py --steps 3 "
+                "--warmup 1 --no-cpu-baseline`), per accumulate_tiles launch, KiB as the counters report them; "
+                "calibration = counter / true KiB on a 1 GiB stream (tools/fetch_calib.hip, same run). "
+                "hbm_bytes_per_launch = (FETCH_SIZE / calib_read4 + WRITE_SIZE / calib_write16) * 1024.",
+    "calibration": {"FETCH_SIZE_per_true_KiB_read_4B_per_lane": f4, "FETCH_SIZE_per_true_KiB_read_16B_per_lane": f16,
+                    "WRITE_SIZE_per_true_KiB_write_16B_per_lane": w16},
+    "C3": {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "hbm_bytes_per_launch": hbm,
+           "hbm_bytes_uncorrected": (fk + wk) * 1024.0, "launches": len(fetch[name]), "kernel": name[:80],
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated"}}, indent=1))
