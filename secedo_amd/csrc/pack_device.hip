@@ -970,8 +970,9 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
             bases |= (uint32_t)(read_base[j] & 1u) << (dist - 1);
             bases |= (uint32_t)((read_base[j] >> 1) & 1u) << (16 + dist - 1);
         }
-        // the 16-byte record and the read index serve pairs of two multi-locus reads only
-        if (hi - lo > 1) {
+        // the 16-byte record and the read index serve the flagged entries only: pairs of two multi-locus
+        // reads, and (correct_flagged) pairs of two reads that were never flushed
+        if (hi - lo > 1 || tail) {
             entry[d] = make_uint4(meta, masks, bases, l);
             entry_read[d] = r;
         }

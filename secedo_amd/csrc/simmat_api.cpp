@@ -91,6 +91,9 @@ struct secedo_simmat {
     uint32_t num_tiles = 0;
     DevBuf tile_row, tile_col, lut, counters, max_bits, slow_args, slab, plan_wg_tile, plan_wg_begin;
     uint32_t plan_tile_begin = 0xFFFFFFFFu, plan_tile_end = 0, plan_ranges = 0, plan_blocks = 0, plan_workgroups = 0;
+    DevBuf flag_cnt, flag_cur, flag_off, flag_idx, unit_off, unit_locus, tile_sel;  // sparse-loci path: flagged entries
+    bool flags_ready = false;                                 // ... of the current packed pileup
+    uint64_t tile_sel_hash = 0;
     DevBuf own_acc, own_out;  // used by the one-shot entry point only
     DevBuf tile_ids;          // tile list of accumulate_list / max_of_tiles
     std::vector<uint16_t> host_tile_row, host_tile_col;
@@ -107,6 +110,7 @@ struct secedo_simmat {
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timed = false;
+    secedo::SideStream side;  // correct_flagged beside accumulate_counts (created on first use)
 };
 
 namespace {
@@ -232,6 +236,9 @@ void secedo_simmat_destroy(secedo_simmat_t *h) {
     (void)hipSetDevice(h->device);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    if (h->side.fork) (void)hipEventDestroy(h->side.fork);
+    if (h->side.join) (void)hipEventDestroy(h->side.join);
+    if (h->side.stream) (void)hipStreamDestroy(h->side.stream);
     delete h;
 }
 
@@ -454,6 +461,8 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, 16 * sizeof(unsigned long long), s));
     h->prepared = true;
     h->timed = false;
+    h->flags_ready = false;
+    h->tile_sel_hash = 0;
     return SECEDO_OK;
 }
 
@@ -482,6 +491,8 @@ int secedo_simmat_zero_acc(secedo_simmat_t *h, int64_t *d_acc, void *stream) {
                            static_cast<hipStream_t>(stream)));
     return SECEDO_OK;
 }
+
+static uint64_t nl_units(const secedo_simmat_t *h) { return (uint64_t)h->pk.num_loci + 1; }
 
 // tiles [tile_begin, tile_end) when list == nullptr, else the n_list tiles of `list` (global indices)
 static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double theta, uint32_t tile_begin,
@@ -589,7 +600,8 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         || h->plan_blocks != h->pk.num_blocks || h->plan_list_hash != list_hash) {
         // workgroups resident per CU (LDS-limited): 1 (128-cell tiles), 2 (64-cell tiles with staged masks,
         // 512 threads), 4 (the other 64-cell variants)
-        const uint32_t wgs_per_round = h->pk.block_cells == 128 ? 256u : h->pk.stage_masks ? 512u : 1024u;
+        // (the 64-cell count tile runs accumulate_counts with 512 threads and 59 KiB of LDS: two per CU)
+        const uint32_t wgs_per_round = h->pk.block_cells == 128 ? 256u : (h->pk.stage_masks || h->pk.count_tile) ? 512u : 1024u;
         uint32_t rounds = 1;
         if (const char *env = std::getenv("SECEDO_ROUNDS")) rounds = std::max(1, std::atoi(env));
         // weight of a tile = the time it takes: per row-side entry a fixed part (the batch set-up) and a
@@ -650,13 +662,61 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
     a.acc = d_acc;
     a.counters = h->counters.as<unsigned long long>();
 
-    HIP_TRY(hipMemsetAsync(h->counters.p, 0, 16 * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(h->counters.p, 0, 96 * sizeof(unsigned long long), s));
+    if (h->pk.count_tile && !h->pk.stage_masks && secedo::counts_path_enabled()) {
+        // accumulate_counts + correct_flagged: the per-locus lists of flagged entries, once per prepare
+        if (!h->flags_ready) {
+            const size_t nl = (size_t)h->pk.num_loci + 1;
+            HIP_TRY(h->flag_cnt.ensure(nl * 4));
+            HIP_TRY(h->flag_cur.ensure(nl * 4));
+            HIP_TRY(h->flag_off.ensure(nl * 4));
+            HIP_TRY(h->flag_idx.ensure(std::max<size_t>(h->pk.num_entries, 1) * 4));
+            HIP_TRY(h->unit_off.ensure(nl * 4));
+            HIP_TRY(h->unit_locus.ensure((h->pk.num_entries / 64 + nl) * 4));
+            HIP_TRY(secedo::build_flagged_lists(a.entry32, a.entry, (uint32_t)h->pk.num_entries, h->pk.num_loci,
+                                                h->flag_cnt.as<uint32_t>(), h->flag_cur.as<uint32_t>(),
+                                                h->flag_off.as<uint32_t>(), h->flag_idx.as<uint32_t>(),
+                                                h->unit_off.as<uint32_t>(), h->unit_locus.as<uint32_t>(), s));
+            h->flags_ready = true;
+        }
+        a.flag_off = h->flag_off.as<uint32_t>();
+        a.flag_idx = h->flag_idx.as<uint32_t>();
+        a.unit_off = h->unit_off.as<uint32_t>();
+        a.unit_locus = h->unit_locus.as<uint32_t>();
+        a.unit_bound = (uint32_t)std::min<uint64_t>(h->pk.num_entries / 64 + nl_units(h), 0xFFFFFFFFull);
+        a.num_blocks = h->pk.num_blocks;
+        a.tile_end = tile_end;
+        if (list) {  // a launch over a tile list: one flag per tile
+            if (h->tile_sel_hash != list_hash || !h->tile_sel.p) {
+                std::vector<uint8_t> sel(std::max<uint32_t>(h->num_tiles, 1), 0);
+                for (uint32_t k = 0; k < n_list; ++k) sel[list[k]] = 1;
+                HIP_TRY(h->tile_sel.upload(sel));
+                h->tile_sel_hash = list_hash;
+            }
+            a.tile_selected = h->tile_sel.as<uint8_t>();
+        }
+    }
     HIP_TRY(hipEventRecord(h->ev_begin, s));
     // 16-bit pair counters per cell pair are safe when no cell pair can collect 65536 pairs
     const bool count_tile = h->pk.count_tile;
     HIP_TRY(h->slab.ensure(secedo::accumulate_slab_bytes(h->pk.block_cells, count_tile, a.n_workgroups)));
     a.slab = h->slab.p;
-    HIP_TRY(secedo::launch_accumulate(a, h->pk.block_cells, h->pk.stage_masks, count_tile, n_tiles, s));
+    const secedo::SideStream *side = nullptr;
+    if (a.flag_off) {  // the sparse-loci path: its correction kernel runs beside the pair kernel
+        static const bool serial = [] {
+            const char *e = std::getenv("SECEDO_CORRECT_SERIAL");
+            return e && std::atoi(e) != 0;
+        }();
+        if (!serial) {
+            if (!h->side.stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&h->side.stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&h->side.fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&h->side.join, hipEventDisableTiming));
+            }
+            side = &h->side;
+        }
+    }
+    HIP_TRY(secedo::launch_accumulate(a, h->pk.block_cells, h->pk.stage_masks, count_tile, n_tiles, s, side));
     HIP_TRY(hipEventRecord(h->ev_end, s));
     h->timed = true;
     return SECEDO_OK;
@@ -781,7 +841,21 @@ int secedo_simmat_last_counts(secedo_simmat_t *h, uint64_t *updates, uint64_t *r
     if (std::getenv("SECEDO_STAMPS_PRINT")) {  // diagnostic builds (-DSECEDO_STAMPS) only
         unsigned long long st[16] = {0};
         HIP_TRY(hipMemcpy(st, h->counters.p, sizeof(st), hipMemcpyDeviceToHost));
-        if (st[8]) {
+        if (st[8] && std::getenv("SECEDO_STAMPS_COUNTS")) {  // accumulate_counts (-DSECEDO_STAMPS)
+            const double w = (double)st[8];
+            std::fprintf(stderr, "[stamps-counts] sampled waves %llu | per wave cycles: total %.0f barrier-A %.0f stage+barrier-B %.0f "
+                                 "items(+col prefetch issue) %.0f primary groups %.0f drain %.0f | per primary batch %.0f, per drain batch %.0f "
+                                 "(%.2f drain batches per primary batch)\n",
+                         st[8], st[7] / w, st[2] / w, st[3] / w, st[4] / w, st[5] / w, st[6] / w,
+                         (double)st[5] / std::max<double>(1, (double)st[9]), (double)st[6] / std::max<double>(1, (double)st[10]),
+                         (double)st[10] / std::max<double>(1, (double)st[9]));
+            unsigned long long pw[64] = {0};
+            HIP_TRY(hipMemcpy(pw, h->counters.as<unsigned long long>() + 16, sizeof(pw), hipMemcpyDeviceToHost));
+            const double wgs = w / 16.0;
+            for (int k = 0; k < 16; ++k)
+                std::fprintf(stderr, "[stamps-counts] wave %2d: barrier-A %8.0f  pairs %8.0f  items %8.0f  stage+B %8.0f\n", k,
+                             pw[k * 4] / wgs, pw[k * 4 + 1] / wgs, pw[k * 4 + 2] / wgs, pw[k * 4 + 3] / wgs);
+        } else if (st[8]) {
             std::fprintf(stderr, "[stamps] waves %llu batches %llu trips %llu | per wave: lifetime %.0f cyc, setup %.0f, "
                                  "fill %.0f, trips %.0f | per batch: setup %.0f fill %.0f trips %.0f (%.2f trips)\n",
                          st[8], st[5], st[6], (double)st[7] / st[8], (double)st[2] / st[8], (double)st[3] / st[8],

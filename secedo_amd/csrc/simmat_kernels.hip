@@ -13,6 +13,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace secedo {
@@ -685,9 +687,542 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// accumulate_counts + correct_flagged: the sparse-loci path (count tile; what C2, C3 and C5 run).
+//
+// accumulate_counts has the decomposition of accumulate_tiles -- a workgroup owns one B x B tile for a share
+// of its row-side entries and walks the locus ranges that share touches, the column side of a range staged
+// in LDS, the next range's loads in flight in registers -- but it counts EVERY (row entry, column entry)
+// incidence of two different cells as a single-locus pair, whatever the reads' flags:
+//
+//   * ITEMS. A thread keeps its JPT row-side entries of the range in registers, each packed with what its
+//     pairs need: {cell | base (9 bits), first column entry j (13), column entries c (8)}.
+//   * GROUPS OF FOUR. A wave takes 64 items and pairs each with its first four column entries: four LDS
+//     reads in flight at once, straight-line code, no loop, no flag test, no branch. 79 % of the slots
+//     hold a pair when loci are sparse (c ~ Poisson(3.8)).
+//   * CONTINUATIONS. Items with more than four column entries are pushed (ballot + mbcnt) to a per-wave
+//     ring in LDS with j += 4, c -= 4, and come back as wave batches of their own -- the long tail never
+//     holds up the short majority.
+//   * WIDE ITEMS (c >= 32, deep loci) are paired by the whole wave, 64 column entries at a time.
+//
+// What the flags mean is settled afterwards by correct_flagged, per locus, over the (few) flagged entries
+// only: a pair of two never-flushed reads is taken out again (:407-408), and a pair of two multi-locus
+// reads that share n >= 2 loci gets D(x_s, x_d) - x_s D(1,0) - x_d D(0,1) added once, at its first shared
+// locus -- all in the integer fixed point of the accumulator, so the sum is bit for bit what the joint
+// evaluation in the pair loop gave. The pair loop used to append such pairs to a list and work the list
+// off with dependent HBM reads: in-kernel stamps showed every range barrier waiting for whichever wave
+// was flushing its list (26 % of a wave's life on C3).
+// ------------------------------------------------------------------------------------------------
+constexpr int COUNTS_RING = 256;     // continuation items per wave
+constexpr uint32_t IT_J_SHIFT = 9, IT_C_SHIFT = 24, IT_J_MASK = 0x1FFFu, IT_WIDE = 32;
+constexpr uint32_t IT_REC_MASK = 0x1FFu;  // cell (7 bits) | base (2 bits)
+
+template <int B, int THREADS, int CAPJ, int CAPL>
+__global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArgs a) {
+    static_assert(CAPJ <= 8192, "13 bits of column index in an item");
+    constexpr size_t TILE_BYTES = (size_t)B * B * 4;
+    constexpr int WAVES = THREADS / 64;
+    constexpr int JPT = (CAPJ + THREADS - 1) / THREADS;      // staged / held entries per thread
+    constexpr int OPT = (CAPL + 1 + THREADS - 1) / THREADS;  // staged offsets per thread
+    constexpr int RING = COUNTS_RING;
+
+    // LDS: [ tile | sJ CAPJ u16 | sOff CAPL+2 u16 | per wave: ring RING items ]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint32_t *tile32 = reinterpret_cast<uint32_t *>(lds_raw);
+    uint16_t *sJ = reinterpret_cast<uint16_t *>(lds_raw + TILE_BYTES);
+    uint16_t *sOff = sJ + CAPJ;
+    uint32_t *ring = reinterpret_cast<uint32_t *>(sOff + CAPL + 2) + (threadIdx.x >> 6) * RING;
+
+    const uint32_t t_local = a.wg_tile[blockIdx.x];
+    const uint32_t t = a.tile_ids ? a.tile_ids[t_local] : a.tile_begin + t_local;
+    const uint32_t chunk = blockIdx.x - a.tile_wg_begin[t_local];
+    const uint32_t n_chunks_t = a.tile_wg_begin[t_local + 1] - a.tile_wg_begin[t_local];
+    const uint32_t I = a.tile_row[t], J = a.tile_col[t];
+    const bool diag = (I == J);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t *offI = a.blk_off + (size_t)I * a.stride;
+    const uint32_t *offJ = a.blk_off + (size_t)J * a.stride;
+    // chunks: equal shares of the tile's row-side entries (see accumulate_tiles)
+    uint32_t r_begin = 0, r_end = a.num_ranges;
+    uint32_t row_begin = 0u, row_end = 0xFFFFFFFFu;
+    if (n_chunks_t > 1u) {
+        const uint32_t L = a.stride - 1u;
+        const uint32_t e0 = offI[0];
+        const unsigned long long n_row = offI[L] - e0;
+        row_begin = e0 + (uint32_t)(n_row * chunk / n_chunks_t);
+        row_end = e0 + (uint32_t)(n_row * (chunk + 1u) / n_chunks_t);
+        uint32_t before = 0, upto = 0;
+        for (uint32_t base = 0; base < a.num_ranges; base += THREADS) {
+            const uint32_t k = base + tid;
+            bool ends_before = false, begins_inside = false;
+            if (k < a.num_ranges) {
+                ends_before = offI[a.range_off[k + 1u]] <= row_begin;
+                begins_inside = offI[a.range_off[k]] < row_end;
+            }
+            before += (uint32_t)__syncthreads_count(ends_before);
+            upto += (uint32_t)__syncthreads_count(begins_inside);
+        }
+        r_begin = __builtin_amdgcn_readfirstlane(before);
+        r_end = __builtin_amdgcn_readfirstlane(upto);
+        row_begin = __builtin_amdgcn_readfirstlane(row_begin);
+        row_end = __builtin_amdgcn_readfirstlane(row_end);
+    }
+    for (uint32_t i = tid; i < B * B; i += THREADS) tile32[i] = 0u;
+
+    const long long d10 = a.lut[1 * LUT_DIM + 0], d01 = a.lut[0 * LUT_DIM + 1];
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B;
+    unsigned long long n_updates = 0;  // lane 0 of each wave carries the wave's count
+    uint32_t upd_w = 0;                // this wave's pairs in the current range (wave-uniform)
+    uint32_t ring_head = 0, ring_tail = 0;  // wave-uniform, free-running
+    const unsigned char *sJb = reinterpret_cast<const unsigned char *>(sJ);
+
+    // one (row entry, column entry) incidence per lane of `in`
+    auto pair_slot = [&](uint32_t rec9, uint32_t row_byte, uint32_t w, unsigned long long in) {
+        const uint32_t x = rec9 ^ w;
+        if (diag) in &= __ballot((x & C_CELL) != 0u);  // same cell (:215)
+        upd_w += (uint32_t)__popcll(in);
+        const uint32_t addr = row_byte + ((w & C_CELL) << 2);
+        if (__builtin_amdgcn_inverse_ballot_w64(in))
+            atomicAdd(reinterpret_cast<uint32_t *>(lds_raw + addr), (x & (3u << C_BASE_SHIFT)) ? 0x10000u : 1u);
+    };
+
+    // 64 items, each against its first four column entries; items with more go to the ring
+    auto group4 = [&](uint32_t item) {
+        const uint32_t c = item >> IT_C_SHIFT;
+        const uint32_t rec9 = item & IT_REC_MASK;
+        const uint32_t row_byte = (item & C_CELL) * (B * 4u);
+        const unsigned char *p = sJb + ((item >> IT_J_SHIFT) & IT_J_MASK) * 2u;
+        // lanes with fewer than four read on inside the staging area: harmless, masked by `in`
+        const uint32_t w0 = *reinterpret_cast<const uint16_t *>(p);
+        const uint32_t w1 = *reinterpret_cast<const uint16_t *>(p + 2);
+        const uint32_t w2 = *reinterpret_cast<const uint16_t *>(p + 4);
+        const uint32_t w3 = *reinterpret_cast<const uint16_t *>(p + 6);
+        const unsigned long long in0 = __ballot(c > 0u), in1 = __ballot(c > 1u), in2 = __ballot(c > 2u),
+                                 in3 = __ballot(c > 3u), more = __ballot(c > 4u);
+        pair_slot(rec9, row_byte, w0, in0);
+        pair_slot(rec9, row_byte, w1, in1);
+        pair_slot(rec9, row_byte, w2, in2);
+        pair_slot(rec9, row_byte, w3, in3);
+        if (more) {
+            if (__builtin_amdgcn_inverse_ballot_w64(more)) {
+                const uint32_t slot = ring_tail + __builtin_amdgcn_mbcnt_hi(
+                        (uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                ring[slot & (RING - 1)] = item + (4u << IT_J_SHIFT) - (4u << IT_C_SHIFT);
+            }
+            ring_tail += (uint32_t)__popcll(more);
+        }
+    };
+    // one batch from the ring (up to 64 items)
+    auto drain_one = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n = min(64u, ring_tail - ring_head);
+        uint32_t it = 0u;
+        if (lane < n) it = ring[(ring_head + lane) & (RING - 1)];
+        __builtin_amdgcn_wave_barrier();
+        ring_head += n;
+        group4(it);
+    };
+
+    // the next range, in flight in registers while the current one is paired
+    uint32_t pJ[JPT], pI[JPT], pO[OPT];
+    uint32_t n_la = 0, n_lb = 0, n_ib = 0, n_ie = 0, n_jb = 0, n_je = 0, n_dsh = 0;
+    bool n_staged = false;
+    uint32_t q_la = 0, q_lb = 0;  // locus span of the range `ahead` holds the offsets of
+    uint32_t ahead = 0;           // lanes 0-3: offsets of the next range; lanes 4-5: span of the one after
+    auto fetch_ahead = [&](uint32_t r) {
+        const uint32_t *src = lane == 0u ? offI + q_la : lane == 1u ? offI + q_lb : lane == 2u ? offJ + q_la
+                            : lane == 3u ? offJ + q_lb : a.range_off + (r + lane - 3u);
+        ahead = 0u;
+        if (lane < 4u || (lane < 6u && r + 1u < r_end)) ahead = *src;
+    };
+    auto prefetch = [&](uint32_t r) {
+        n_la = q_la;
+        n_lb = q_lb;
+        const uint32_t range_ib = __builtin_amdgcn_readlane(ahead, 0);
+        n_ib = max(range_ib, row_begin);  // this chunk's part of the range's row side
+        n_ie = max(n_ib, min((uint32_t)__builtin_amdgcn_readlane(ahead, 1), row_end));
+        n_dsh = n_ib - range_ib;
+        n_jb = __builtin_amdgcn_readlane(ahead, 2);
+        n_je = __builtin_amdgcn_readlane(ahead, 3);
+        q_la = __builtin_amdgcn_readlane(ahead, 4);
+        q_lb = __builtin_amdgcn_readlane(ahead, 5);
+        if (r + 1u < r_end) fetch_ahead(r + 1u);
+        n_staged = (n_je - n_jb) <= (uint32_t)CAPJ && (n_ie - n_ib) <= (uint32_t)CAPJ
+                && (n_lb - n_la) <= (uint32_t)CAPL;
+        if (n_staged) {
+#pragma unroll
+            for (int k = 0; k < JPT; ++k) {
+                const uint32_t i = tid + k * THREADS;
+                pJ[k] = i < n_je - n_jb ? a.entry32[n_jb + i] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) {
+                const uint32_t i = tid + k * THREADS;
+                pO[k] = i <= n_lb - n_la ? offJ[n_la + i] : 0u;
+            }
+        }
+    };
+    // the row side of the range prefetch() described; issued later, when the registers of the current
+    // range's items are free (the loads still have the ring drain and two barriers to land)
+    auto prefetch_rows = [&]() {
+        if (n_staged) {
+#pragma unroll
+            for (int k = 0; k < JPT; ++k) {
+                const uint32_t i = tid + k * THREADS;
+                pI[k] = i < n_ie - n_ib ? a.entry32[n_ib + i] : 0u;
+            }
+        }
+    };
+
+    if (r_begin < r_end) {
+        q_la = __builtin_amdgcn_readfirstlane(a.range_off[r_begin]);
+        q_lb = __builtin_amdgcn_readfirstlane(a.range_off[r_begin + 1u]);
+        fetch_ahead(r_begin);
+        prefetch(r_begin);
+        prefetch_rows();
+    }
+#ifdef SECEDO_STAMPS
+    unsigned long long st_barA = 0, st_stage = 0, st_items = 0, st_prim = 0, st_drain = 0, st_nprim = 0, st_ndrain = 0;
+    const unsigned long long st_begin = stamp();
+#endif
+    for (uint32_t r = r_begin; r < r_end; ++r) {
+        const uint32_t la = n_la, lb = n_lb, ib = n_ib, ie = n_ie, jb = n_jb, je = n_je, dsh = n_dsh;
+        const bool staged = n_staged;
+        STAMP(s0);
+        __syncthreads();  // every wave is done with the previous range (first time: with zeroing)
+        STAMP(s1);
+        if (staged) {
+#pragma unroll
+            for (int k = 0; k < JPT; ++k) {
+                const uint32_t i = tid + k * THREADS;
+                if (i < je - jb) sJ[i] = (uint16_t)pJ[k];
+            }
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) {
+                const uint32_t i = tid + k * THREADS;
+                if (i <= lb - la) sOff[i] = (uint16_t)(pO[k] - jb);
+            }
+        }
+        __syncthreads();
+        STAMP(s2);
+
+        const uint32_t nI = ie - ib;
+        upd_w = 0;
+        if (staged) {
+            // items of this thread's row entries: the column entries of the entry's locus are
+            // sJ[j0 .. j0 + c); in a diagonal tile the entries after this one (each pair once)
+            uint32_t item[JPT];
+#pragma unroll
+            for (int k = 0; k < JPT; ++k) {
+                const uint32_t i = tid + k * THREADS;
+                const uint32_t rec = pI[k];
+                const uint32_t lrel = rec >> 16;
+                uint32_t j0 = sOff[lrel];
+                const uint32_t j1 = sOff[lrel + 1];
+                if (diag) j0 = i + dsh + 1u;
+                uint32_t c = (i < nI && j1 > j0) ? j1 - j0 : 0u;
+                // wide entries (deep loci): the whole wave pairs one row entry with 64 column entries at a
+                // time, right here
+                unsigned long long todo = __ballot(c >= IT_WIDE);
+                if (todo) {
+                    if (c >= IT_WIDE) c |= 0x80000000u;  // marks the lanes below; cleared after
+                    while (todo) {
+                        const int src = __builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        const uint32_t recw = __builtin_amdgcn_readlane(rec, src);
+                        const uint32_t cw = __builtin_amdgcn_readlane(c, src) & 0x7FFFFFFFu;
+                        const uint32_t j0w = __builtin_amdgcn_readlane(j0, src);
+                        const uint32_t row_byte = (recw & C_CELL) * (B * 4u);
+                        for (uint32_t base = 0; base < cw; base += 64u) {
+                            const uint32_t jj = j0w + base + lane;
+                            const unsigned long long in = __ballot(base + lane < cw);
+                            const uint32_t w = sJ[min(jj, (uint32_t)CAPJ - 1u)];
+                            pair_slot(recw & IT_REC_MASK, row_byte, w, in);
+                        }
+                    }
+                    if (c & 0x80000000u) c = 0u;
+                }
+                // (j0 can be CAPJ when c is 0: the last entry of a full diagonal range)
+                item[k] = (rec & IT_REC_MASK) | ((j0 & IT_J_MASK) << IT_J_SHIFT) | (c << IT_C_SHIFT);
+            }
+            if (r + 1 < r_end) prefetch(r + 1);  // pJ / pO are free again: the next range's column side
+            STAMP(s3);
+#pragma unroll
+            for (int k = 0; k < JPT; ++k) {
+                // room for 64 more continuations (a drained batch may push up to 64 itself)
+                while (ring_tail - ring_head > (uint32_t)(RING - 64)) drain_one();
+                group4(item[k]);
+            }
+            if (r + 1 < r_end) prefetch_rows();
+            STAMP(s4);
+#ifdef SECEDO_STAMPS
+            st_ndrain += (ring_tail - ring_head + 63u) / 64u;
+            st_nprim += JPT;
+#endif
+            while (ring_tail != ring_head) drain_one();
+            STAMP(s5);
+#ifdef SECEDO_STAMPS
+            st_barA += s1 - s0;
+            st_stage += s2 - s1;
+            st_items += s3 - s2;
+            st_prim += s4 - s3;
+            st_drain += s5 - s4;
+#endif
+        } else {
+            if (r + 1 < r_end) {
+                prefetch(r + 1);
+                prefetch_rows();
+            }
+            // a locus range that does not fit the staging buffers (a single very deep locus): paired
+            // straight from HBM/L2 into HBM (flags are settled by correct_flagged here too)
+            uint32_t upd = 0;
+            for (uint32_t e1 = ib + tid; e1 < ie; e1 += THREADS) {
+                const uint32_t r1 = a.entry32[e1];
+                const uint32_t l = la + (r1 >> 16);
+                const uint32_t j0 = diag ? e1 + 1 : offJ[l];
+                const uint32_t j1 = offJ[l + 1];
+                const uint32_t row = (r1 & C_CELL) * B;
+                for (uint32_t e2 = j0; e2 < j1; ++e2) {
+                    const uint32_t r2 = a.entry32[e2];
+                    const uint32_t x = r1 ^ r2;
+                    if (diag && (x & C_CELL) == 0u) continue;  // same cell (:215)
+                    ++upd;
+                    atomicAdd(&dst[row + (r2 & C_CELL)],
+                              (unsigned long long)((x & (3u << C_BASE_SHIFT)) ? d01 : d10));
+                }
+            }
+            n_updates += upd;
+        }
+        if (lane == 0u) n_updates += upd_w;
+    }
+#ifdef SECEDO_STAMPS
+    if (lane == 0u && (blockIdx.x & 15u) == 0u) {  // a sample of the workgroups, every wave of them
+        atomicAdd(&a.counters[2], st_barA);
+        atomicAdd(&a.counters[3], st_stage);
+        atomicAdd(&a.counters[4], st_items);
+        atomicAdd(&a.counters[5], st_prim);
+        atomicAdd(&a.counters[6], st_drain);
+        atomicAdd(&a.counters[7], stamp() - st_begin);
+        atomicAdd(&a.counters[8], 1ull);
+        atomicAdd(&a.counters[9], st_nprim);
+        atomicAdd(&a.counters[10], st_ndrain);
+        // per wave index: barrier-A wait, pair work (primary + drain), item phase
+        atomicAdd(&a.counters[16 + (tid >> 6) * 4 + 0], st_barA);
+        atomicAdd(&a.counters[16 + (tid >> 6) * 4 + 1], st_prim + st_drain);
+        atomicAdd(&a.counters[16 + (tid >> 6) * 4 + 2], st_items);
+        atomicAdd(&a.counters[16 + (tid >> 6) * 4 + 3], st_stage);
+    }
+#endif
+    __syncthreads();
+
+    // flush: the tile goes to the workgroup's own slab with plain coalesced stores (reduce_slabs adds up)
+    {
+        uint4 *out = reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(a.slab) + (size_t)blockIdx.x * B * B);
+        const uint4 *src = reinterpret_cast<const uint4 *>(tile32);
+        for (uint32_t i = tid; i < B * B / 4; i += THREADS) out[i] = src[i];
+    }
+    // work counter: wave reduction, then one atomic pair per workgroup (see accumulate_tiles); every
+    // incidence counts as an update and as a read pair here, correct_flagged takes back what is neither
+    for (int off = 32; off > 0; off >>= 1) n_updates += __shfl_down(n_updates, off);
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(sJ);
+    if (lane == 0u) red[tid >> 6] = n_updates;
+    __syncthreads();
+    if (tid == 0u) {
+        unsigned long long u = 0;
+        for (int w = 0; w < WAVES; ++w) u += red[w];
+        if (u) {
+            atomicAdd(&a.counters[0], u);
+            atomicAdd(&a.counters[1], u);
+        }
+    }
+}
+
+// ---- the flagged entries of every locus (tail: the read was never flushed; multi: the read has further
+// kept entries), as per-locus lists of entry indices: count, (scan on the host side of the launch), fill
+__global__ __launch_bounds__(256) void flagged_count(const uint32_t *entry32, const uint4 *entry, uint32_t n,
+                                                    uint32_t *cnt) {
+    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < n; g += gridDim.x * 256)
+        if (entry32[g] & (C_TAIL | C_MULTI)) atomicAdd(&cnt[entry[g].w], 1u);
+}
+__global__ __launch_bounds__(256) void flagged_fill(const uint32_t *entry32, const uint4 *entry, uint32_t n,
+                                                   const uint32_t *off, uint32_t *cursor, uint32_t *idx) {
+    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < n; g += gridDim.x * 256)
+        if (entry32[g] & (C_TAIL | C_MULTI)) {
+            const uint32_t l = entry[g].w;
+            idx[off[l] + atomicAdd(&cursor[l], 1u)] = g;
+        }
+}
+
+// x_s, x_d over all loci two multi-locus reads share, if `locus` (the locus of both entries) is the first
+// one they share; false if an earlier locus owns the pair. The logic of pair_value_full / slow_pair.
+__device__ __forceinline__ bool joint_counts(const SlowPathArgs *sp, const uint4 A1, const uint4 A2, uint32_t g1,
+                                             uint32_t g2, uint32_t *xs_out, uint32_t *xd_out) {
+    if (A1.y & A2.y & 0xFFFFu) return false;  // they share an earlier locus
+    const bool same = (((A1.x ^ A2.x) >> 16) & 3u) == 0u;
+    if ((A1.x & A2.x & (META_PREV_OVF | META_NEXT_OVF)) == 0u) {
+        const uint32_t shared = (A1.y & A2.y) >> 16;
+        const uint32_t x = A1.z ^ A2.z;
+        const uint32_t diff = ((x & 0xFFFFu) | (x >> 16)) & shared;
+        const uint32_t nd = __popc(diff);
+        *xd_out = nd + (same ? 0u : 1u);
+        *xs_out = __popc(shared) - nd + (same ? 1u : 0u);
+        return true;
+    }
+    // a 16-locus window overflowed on the same side for both reads: merge-walk their entry lists
+    const uint32_t r1 = sp->entry_read[g1], r2 = sp->entry_read[g2];
+    uint32_t i1 = sp->read_off[r1], e1 = sp->read_off[r1 + 1];
+    uint32_t i2 = sp->read_off[r2], e2 = sp->read_off[r2 + 1];
+    uint32_t xs = 0, xd = 0, first = 0xFFFFFFFFu;
+    while (i1 < e1 && i2 < e2) {
+        const uint32_t l1 = sp->read_locus[i1], l2 = sp->read_locus[i2];
+        if (l1 == l2) {
+            if (first == 0xFFFFFFFFu) first = l1;
+            if (sp->read_base[i1] == sp->read_base[i2]) ++xs; else ++xd;
+            ++i1; ++i2;
+        } else if (l1 < l2) {
+            ++i1;
+        } else {
+            ++i2;
+        }
+    }
+    *xs_out = xs;
+    *xd_out = xd;
+    return first == A1.w;
+}
+
+struct CorrectArgs {
+    const uint32_t *flag_off;  // num_loci + 1
+    const uint32_t *flag_idx;  // entry indices, grouped by locus
+    const uint32_t *unit_off;  // num_loci + 1: first work unit of each locus (a unit = 64 entries q of one locus)
+    const uint32_t *unit_locus;  // unit -> locus
+    uint32_t num_loci;
+    const uint4 *entry;
+    const SlowPathArgs *slow;
+    const long long *lut;
+    uint32_t block_cells, num_blocks;
+    uint32_t tile_begin, tile_end;  // tiles of this launch ...
+    const uint8_t *tile_selected;   // ... or, when non-null, one flag per tile
+    int64_t *acc;
+    unsigned long long *counters;
+};
+
+// Every pair of flagged entries of a locus that belongs to two different matrix rows and to a tile of this
+// launch.
+//   both tail            -> the plain term accumulate_counts added is taken out, so is its update
+//   both multi-locus     -> not the first shared locus: one read pair less (the incidence stays an update);
+//                           first shared locus and n = x_s + x_d >= 2: + D(x_s,x_d) - x_s D(1,0) - x_d D(0,1)
+// A wave takes work units (grid-stride): 64 entries q of one locus -- a lane each, in registers -- against
+// all entries p < q of that locus, which pass through registers 64 at a time and are broadcast with
+// v_readlane (no LDS, one HBM latency per 64 p). Units, not loci, because the corrections are scattered
+// 8-byte atomics, which one CU issues at about one wave-instruction per microsecond: the loci where two
+// nearby informative sites make hundreds of reads multi-locus must be spread over many CUs.
+__global__ __launch_bounds__(256) void correct_flagged(const CorrectArgs a) {
+    const uint32_t n_units = a.unit_off[a.num_loci];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = gridDim.x * 4;
+    const uint32_t B = a.block_cells, nb = a.num_blocks;
+    const long long d10 = a.lut[1 * LUT_DIM + 0], d01 = a.lut[0 * LUT_DIM + 1];
+    long long upd_delta = 0, pair_delta = 0;  // per lane
+    for (uint32_t u = wave; u < n_units; u += n_waves) {
+        const uint32_t l = a.unit_locus[u];
+        const uint32_t f0 = a.flag_off[l], m = a.flag_off[l + 1] - f0;
+        const uint32_t qb = (u - a.unit_off[l]) * 64u, q = qb + lane;
+        uint32_t g2 = 0;
+        uint4 A2 = make_uint4(0, 0, 0, 0);
+        if (q < m) {
+            g2 = a.flag_idx[f0 + q];
+            A2 = a.entry[g2];
+        }
+        const uint32_t row2 = A2.x & 0xFFFFu, b2 = row2 / B;
+        const bool multi2 = A2.y != 0u || (A2.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
+        const uint32_t p_all = min(m, qb + 64u);  // p < q <= qb + 63
+        for (uint32_t pb = 0; pb < p_all; pb += 64u) {
+            uint32_t gp = g2;
+            uint4 Ap = A2;
+            if (pb != qb) {  // (the last chunk of p is the unit's own entries)
+                gp = 0;
+                Ap = make_uint4(0, 0, 0, 0);
+                if (pb + lane < m) {
+                    gp = a.flag_idx[f0 + pb + lane];
+                    Ap = a.entry[gp];
+                }
+            }
+            const uint32_t np = min(64u, p_all - pb);
+            for (uint32_t k = 0; k < np; ++k) {
+                const uint32_t p = pb + k;
+                const uint4 A1 = make_uint4(__builtin_amdgcn_readlane(Ap.x, k), __builtin_amdgcn_readlane(Ap.y, k),
+                                            __builtin_amdgcn_readlane(Ap.z, k), __builtin_amdgcn_readlane(Ap.w, k));
+                const uint32_t g1 = __builtin_amdgcn_readlane(gp, k);
+                if (q >= m || q <= p) continue;
+                const uint32_t row1 = A1.x & 0xFFFFu;
+                if (row1 == row2) continue;  // same cell (:215)
+                const bool tails = (A1.x & A2.x & (1u << 18)) != 0u;  // both never flushed: no pair at all
+                const bool multi1 = A1.y != 0u || (A1.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
+                if (!tails && !(multi1 && multi2)) continue;
+                // the tile of the pair: row block <= column block; inside a diagonal tile either orientation
+                // is read back (the finalize kernels add both)
+                const uint32_t b1 = row1 / B;
+                const uint32_t bI = min(b1, b2), bJ = max(b1, b2);
+                const uint32_t t = bI * nb - bI * (bI - 1u) / 2u + (bJ - bI);
+                if (a.tile_selected ? a.tile_selected[t] == 0 : (t < a.tile_begin || t >= a.tile_end)) continue;
+                const uint32_t rI = b1 <= b2 ? row1 : row2, rJ = b1 <= b2 ? row2 : row1;
+                unsigned long long *cell = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B
+                        + (rI - bI * B) * B + (rJ - bJ * B);
+                const bool same = (((A1.x ^ A2.x) >> 16) & 3u) == 0u;
+                if (tails) {
+                    atomicAdd(cell, (unsigned long long)(-(same ? d10 : d01)));
+                    --upd_delta;
+                    --pair_delta;
+                    continue;
+                }
+                uint32_t xs = 0, xd = 0;
+                // (the order of the two entries does not matter to joint_counts)
+                if (!joint_counts(a.slow, A1, A2, g1, g2, &xs, &xd)) {
+                    --pair_delta;  // counted at their first shared locus
+                    continue;
+                }
+                if (xs + xd < 2u) continue;  // this locus only: the plain term is the whole term
+                const long long joint = (xs < (uint32_t)LUT_DIM && xd < (uint32_t)LUT_DIM)
+                        ? a.lut[xs * LUT_DIM + xd] : llr_fixed_device(a.slow, xs, xd);
+                atomicAdd(cell, (unsigned long long)(joint - (long long)xs * d10 - (long long)xd * d01));
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        upd_delta += __shfl_down(upd_delta, off);
+        pair_delta += __shfl_down(pair_delta, off);
+    }
+    __shared__ long long part[8];
+    if (lane == 0u) {
+        part[wv * 2] = upd_delta;
+        part[wv * 2 + 1] = pair_delta;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        const long long u = part[0] + part[2] + part[4] + part[6], q = part[1] + part[3] + part[5] + part[7];
+        if (u) atomicAdd(&a.counters[0], (unsigned long long)u);
+        if (q) atomicAdd(&a.counters[1], (unsigned long long)q);
+    }
+}
+
+// work units of correct_flagged: ceil(flagged entries / 64) per locus with at least two flagged entries
+__global__ __launch_bounds__(256) void flagged_units(const uint32_t *flag_off, uint32_t n_loci, uint32_t *units) {
+    for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l <= n_loci; l += gridDim.x * 256) {
+        const uint32_t m = l < n_loci ? flag_off[l + 1] - flag_off[l] : 0u;
+        units[l] = m < 2u ? 0u : (m + 63u) / 64u;
+    }
+}
+__global__ __launch_bounds__(256) void flagged_unit_loci(const uint32_t *unit_off, uint32_t n_loci, uint32_t *unit_locus) {
+    for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < n_loci; l += gridDim.x * 256)
+        for (uint32_t u = unit_off[l]; u < unit_off[l + 1]; ++u) unit_locus[u] = l;
+}
+
 // acc[tile] += sum over the tile's workgroups of their slab (count slabs are converted with the two
 // single-locus ratios: exact integer arithmetic). One thread per cell pair of a tile.
-template <int B, bool COUNTS>
+// ATOMIC: the sum is added with an atomic (correct_flagged may be adding to the same cells on another stream)
+template <int B, bool COUNTS, bool ATOMIC = false>
 __global__ __launch_bounds__(256) void reduce_slabs(const void *slab, const uint32_t *tile_wg_begin,
                                                    uint32_t tile_begin, const uint32_t *tile_ids,
                                                    const long long *lut, long long *acc) {
@@ -709,7 +1244,11 @@ __global__ __launch_bounds__(256) void reduce_slabs(const void *slab, const uint
         const long long *p = reinterpret_cast<const long long *>(slab) + cell;
         for (uint32_t w = w0; w < w1; ++w) sum += p[(size_t)w * B * B];
     }
-    if (sum) acc[(size_t)(tile_ids ? tile_ids[t_local] : tile_begin + t_local) * B * B + cell] += sum;
+    long long *dst = &acc[(size_t)(tile_ids ? tile_ids[t_local] : tile_begin + t_local) * B * B + cell];
+    if (sum) {
+        if (ATOMIC) atomicAdd(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)sum);
+        else *dst += sum;
+    }
 }
 
 // max over i < j of D[i][j], clamped at 0 (the diagonal is zero): bits of a non-negative double
@@ -824,7 +1363,130 @@ hipError_t launch_acc(const AccumulateArgs &args, uint32_t grid, hipStream_t str
     return hipGetLastError();
 }
 
+// exclusive prefix sum of n words by one workgroup (n is a number of loci: a few hundred thousand), in tiles
+// of 4096 words: coalesced 16-byte loads, wave scans with DPP, the running total carried in a register
+__global__ __launch_bounds__(1024) void scan_exclusive_1wg(const uint32_t *in, uint32_t *out, uint32_t n) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 4096u) {
+        const uint32_t i0 = base + tid * 4u;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = i0 + k < n ? in[i0 + k] : 0u;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        const uint32_t incl = wave_inclusive_scan(mine);
+        if (lane == 63u) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t s = wsum[w];
+            if ((uint32_t)w < wv) before += s;
+            total += s;
+        }
+        uint32_t run = carry + before + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < n) out[i0 + k] = run;
+            run += v[k];
+        }
+        carry += total;
+        __syncthreads();
+    }
+}
+
+template <int B, int THREADS, int CAPJ, int CAPL>
+hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t stream, const SideStream *side) {
+    constexpr size_t lds = (size_t)B * B * 4 + (size_t)CAPJ * 2 + ((size_t)CAPL + 2) * 2
+            + (size_t)(THREADS / 64) * (size_t)COUNTS_RING * 4;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert((CAPL + 2) % 4 == 0 && CAPJ % 8 == 0, "alignment of the LDS carve-up");
+    auto kern = &accumulate_counts<B, THREADS, CAPJ, CAPL>;
+    static thread_local int configured_device = -1;  // the attribute is per device and sticky
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (configured_device != dev) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        if (e != hipSuccess) return e;
+        configured_device = dev;
+    }
+    // What the flags of the reads mean, per locus over the flagged entries only. Its scattered 8-byte atomics
+    // are bound by the memory side (about 2e10 per second chip-wide), not by the CUs: it runs beside the pair
+    // kernel on a second stream when the caller has one (the pair kernel leaves half the wave slots and a
+    // third of the LDS of every CU free).
+    CorrectArgs c;
+    c.flag_off = args.flag_off;
+    c.flag_idx = args.flag_idx;
+    c.unit_off = args.unit_off;
+    c.unit_locus = args.unit_locus;
+    c.num_loci = args.stride - 1u;
+    c.entry = args.entry;
+    c.slow = args.slow;
+    c.lut = args.lut;
+    c.block_cells = B;
+    c.num_blocks = args.num_blocks;
+    c.tile_begin = args.tile_begin;
+    c.tile_end = args.tile_end;
+    c.tile_selected = args.tile_selected;
+    c.acc = args.acc;
+    c.counters = args.counters;
+    // (an upper bound of the number of units is known without a read-back: one per 64 entries plus one per locus)
+    const uint32_t blocks = std::max(1u, std::min((args.unit_bound + 3u) / 4u, 256u * 8u));
+    const bool beside = side && side->stream;
+    if (beside) {
+        if ((e = hipEventRecord(side->fork, stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
+        hipLaunchKernelGGL(correct_flagged, dim3(blocks), dim3(256), 0, side->stream, c);
+        if ((e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
+    hipLaunchKernelGGL((reduce_slabs<B, true, true>), dim3(args.n_tiles * (B * B / 256)), dim3(256), 0, stream,
+                       args.slab, args.tile_wg_begin, args.tile_begin, args.tile_ids, args.lut,
+                       reinterpret_cast<long long *>(args.acc));
+    if (beside) {
+        if ((e = hipStreamWaitEvent(stream, side->join, 0)) != hipSuccess) return e;
+    } else {
+        hipLaunchKernelGGL(correct_flagged, dim3(blocks), dim3(256), 0, stream, c);
+    }
+    return hipGetLastError();
+}
+
+int pair_mode() {
+    static const int mode = [] {
+        const char *e = std::getenv("SECEDO_PAIR_MODE");
+        return e ? std::atoi(e) : 1;
+    }();
+    return mode;
+}
+
 }  // namespace
+
+bool counts_path_enabled() { return pair_mode() != 0; }
+
+hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint32_t n_entries, uint32_t n_loci,
+                               uint32_t *cnt, uint32_t *cursor, uint32_t *off, uint32_t *idx, uint32_t *unit_off,
+                               uint32_t *unit_locus, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(cnt, 0, ((size_t)n_loci + 1) * 4, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(cursor, 0, ((size_t)n_loci + 1) * 4, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>(((size_t)n_entries + 255) / 256, 256 * 16));
+    if (n_entries)
+        hipLaunchKernelGGL(flagged_count, dim3(blocks), dim3(256), 0, stream, entry32, entry, n_entries, cnt);
+    hipLaunchKernelGGL(scan_exclusive_1wg, dim3(1), dim3(1024), 0, stream, cnt, off, n_loci + 1u);
+    if (n_entries)
+        hipLaunchKernelGGL(flagged_fill, dim3(blocks), dim3(256), 0, stream, entry32, entry, n_entries, off, cursor,
+                           idx);
+    // work units of correct_flagged (cnt is free again: the units per locus, then their prefix)
+    const uint32_t lblocks = std::max(1u, std::min((n_loci + 256u) / 256u, 256u * 8u));
+    hipLaunchKernelGGL(flagged_units, dim3(lblocks), dim3(256), 0, stream, off, n_loci, cnt);
+    hipLaunchKernelGGL(scan_exclusive_1wg, dim3(1), dim3(1024), 0, stream, cnt, unit_off, n_loci + 1u);
+    hipLaunchKernelGGL(flagged_unit_loci, dim3(lblocks), dim3(256), 0, stream, unit_off, n_loci, unit_locus);
+    return hipGetLastError();
+}
 
 size_t accumulate_slab_bytes(uint32_t block_cells, bool count_tile, uint32_t n_workgroups) {
     return (size_t)n_workgroups * block_cells * block_cells * (count_tile ? 4 : 8);
@@ -837,15 +1499,17 @@ StageGeometry stage_geometry(uint32_t block_cells) {
 }
 
 hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, bool stage_masks,
-                             bool count_tile, uint32_t n_tiles, hipStream_t stream) {
+                             bool count_tile, uint32_t n_tiles, hipStream_t stream, const SideStream *side) {
     if (n_tiles == 0) return hipSuccess;
     const uint32_t grid = args.n_workgroups;
     if (block_cells == 128) {
         // the 128 KiB int64 tile leaves no room for the window masks: joint terms go through HBM
+        if (count_tile && pair_mode() != 0) return launch_counts<128, 1024, kCapJ128C, kCapL128C>(args, grid, stream, side);
         if (count_tile) return launch_acc<128, 1024, kCapJ128C, kCapL128C, 1024, false, true>(args, grid, stream);
         return launch_acc<128, 1024, kCapJ128, kCapL128, 512, false, false>(args, grid, stream);
     }
     if (stage_masks) return launch_acc<64, 512, kCapJ64M, kCapL64M, 1024, true, false>(args, grid, stream);
+    if (count_tile && pair_mode() != 0) return launch_counts<64, 512, kCapJ64C, kCapL64C>(args, grid, stream, side);
     if (count_tile) return launch_acc<64, 256, kCapJ64C, kCapL64C, 1024, false, true>(args, grid, stream);
     return launch_acc<64, 256, kCapJ64, kCapL64, 1024, false, false>(args, grid, stream);
 }

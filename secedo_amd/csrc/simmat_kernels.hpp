@@ -64,7 +64,29 @@ struct AccumulateArgs {
     int64_t *acc;              // tile-major: [tile][B*B]
     void *slab;                // one B*B tile (u32 counts or int64) per workgroup of the launch
     unsigned long long *counters;  // [0] incidences examined, [1] read pairs accumulated
+    // the sparse-loci path (accumulate_counts + correct_flagged): the flagged entries of every locus
+    // (build_flagged_lists), the tiles of the launch as the correction kernel needs them
+    const uint32_t *flag_off = nullptr;     // num_loci + 1
+    const uint32_t *flag_idx = nullptr;     // entry indices, grouped by locus
+    const uint32_t *unit_off = nullptr;     // num_loci + 1: work units of correct_flagged (64 entries of a locus)
+    const uint32_t *unit_locus = nullptr;   // unit -> locus
+    uint32_t unit_bound = 0;                // upper bound of the number of units (sizes the grid)
+    uint32_t num_blocks = 0;
+    uint32_t tile_end = 0;                  // tiles [tile_begin, tile_end) when tile_selected == nullptr
+    const uint8_t *tile_selected = nullptr; // one flag per tile (a launch over a tile list)
 };
+
+// true when the count-tile variants run accumulate_counts + correct_flagged (the default; SECEDO_PAIR_MODE=0
+// selects the flattening kernel accumulate_tiles instead, for A/B measurements)
+bool counts_path_enabled();
+// Per-locus lists of the entries whose read is flagged (never flushed, or covering further loci), for
+// correct_flagged: off[num_loci + 1] (exclusive prefix of the per-locus counts), idx[] = entry indices.
+// cnt and cursor are scratch of num_loci + 1 words each. unit_off[num_loci + 1] / unit_locus[] describe the
+// work units of correct_flagged (64 flagged entries of one locus; at most n_entries / 64 + num_loci of them).
+// Depends on the packed pileup only.
+hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint32_t n_entries, uint32_t n_loci,
+                               uint32_t *cnt, uint32_t *cursor, uint32_t *off, uint32_t *idx, uint32_t *unit_off,
+                               uint32_t *unit_locus, hipStream_t stream);
 
 StageGeometry stage_geometry(uint32_t block_cells);
 
@@ -74,8 +96,13 @@ size_t accumulate_slab_bytes(uint32_t block_cells, bool count_tile, uint32_t n_w
 // stage_masks / count_tile: the kernel variants, see accumulate_tiles. count_tile requires fewer
 // than 65536 pairs per cell pair (PackedPileup::pair_bound) and !stage_masks; stage_masks exists
 // for 64-cell tiles only. The accumulator must be zeroed by the caller: the flush is additive.
+// side: a second stream with two events, or null: correct_flagged then runs beside the pair kernel
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
 hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, bool stage_masks,
-                             bool count_tile, uint32_t n_tiles, hipStream_t stream);
+                             bool count_tile, uint32_t n_tiles, hipStream_t stream, const SideStream *side = nullptr);
 
 // mode 0..2 = SECEDO_NORM_*, 3 = raw D
 hipError_t launch_finalize(const int64_t *acc, const uint16_t *tile_row, const uint16_t *tile_col, uint32_t n_tiles,

@@ -208,7 +208,8 @@ def test_shards_with_pair_bounds_across_2_18_share_one_scale():
         assert plan.pair_bound >= 1 << 18 and plan.scale_log2 == 43
         want = plan.finalize(full, "ADD_MIN").clone()
         shards = [sd.chromosome_shard(p, r, world) for r in range(world)]
-        assert [s.n_chr for s in shards] == [1, 1, 1]
+        # cuts follow the entries: the deep chromosome is a shard of its own, one shard is EMPTY, one shallow
+        assert sorted(s.n_chr for s in shards) == [0, 1, 2] and sum(s.n_entries for s in shards) == p.n_entries
         bounds, own_scales = [], []
         for s in shards:
             plan.prepare(s, n, 1000, None, 1, block_cells=64)
@@ -216,7 +217,7 @@ def test_shards_with_pair_bounds_across_2_18_share_one_scale():
             part = plan.new_acc()
             plan.accumulate(part, 0.01, 0.5, 0.01)
             own_scales.append(plan.scale_log2)
-        assert own_scales == [43, 44, 44]  # the hole: each shard on its own picks another scale
+        assert sorted(own_scales) == [43, 44, 44]  # the hole: each shard on its own picks another scale
         total = torch.zeros_like(full)
         for s in shards:
             plan.prepare(s, n, 1000, None, 1, block_cells=64)
