@@ -350,11 +350,12 @@ def main():
             # vector-instruction issue (profiles/r02_pmc_C3.txt).
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "accumulate_tiles", "kernel_ms": kern_ms,
+                         "kernel": "accumulate_counts (pair kernel; with reduce_slabs and, beside it on a second "
+                                   "stream, correct_flagged: the kernels of one accumulate)", "kernel_ms": kern_ms,
                          "kernel_ms_last_timed_step": best["last_ms"],
                          "algorithmic_bytes": b_alg,
                          "hbm_frac_measured": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                         "limiter": "VALU issue + LDS latency (see profiles/)",
+                         "limiter": "VALU issue and LDS atomics, about 60 % busy each (profiles/r02_pmc_C3.txt)",
                          "whole_step": {"algorithmic_bytes": b_alg_step,
                                         "achieved": b_alg_step / step_s / 1e9,
                                         "frac": b_alg_step / step_s / 1e9 / HBM_PEAK_GBPS / world}},

@@ -686,6 +686,11 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         a.unit_bound = (uint32_t)std::min<uint64_t>(h->pk.num_entries / 64 + nl_units(h), 0xFFFFFFFFull);
         a.num_blocks = h->pk.num_blocks;
         a.tile_end = tile_end;
+        {
+            const double per_block_locus = h->pk.num_loci && h->pk.num_blocks
+                    ? (double)h->pk.num_entries / h->pk.num_loci / h->pk.num_blocks : 0.0;
+            a.sparse_blocks = per_block_locus < 2.5;
+        }
         if (list) {  // a launch over a tile list: one flag per tile
             if (h->tile_sel_hash != list_hash || !h->tile_sel.p) {
                 std::vector<uint8_t> sel(std::max<uint32_t>(h->num_tiles, 1), 0);

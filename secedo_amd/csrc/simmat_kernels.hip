@@ -718,9 +718,14 @@ constexpr int COUNTS_RING = 256;     // continuation items per wave
 constexpr uint32_t IT_J_SHIFT = 9, IT_C_SHIFT = 24, IT_J_MASK = 0x1FFFu, IT_WIDE = 32;
 constexpr uint32_t IT_REC_MASK = 0x1FFu;  // cell (7 bits) | base (2 bits)
 
-template <int B, int THREADS, int CAPJ, int CAPL>
+// GROUP: column entries an item is paired with per pass. Measured on one MI355X (accumulate phase, ms):
+//   C3 (3.8 entries per cell block and locus): 4.87 / 4.49 / 4.38 / 5.62 for GROUP 1 / 2 / 3 / 4
+//   C5 (1.3):                                 38.6 / 38.1 / 38.9 / 46.5
+// -- empty slots cost more than trips through the ring: 3 by default, 2 below 2.5 entries per block and locus.
+template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
 __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArgs a) {
     static_assert(CAPJ <= 8192, "13 bits of column index in an item");
+    static_assert(GROUP >= 1 && GROUP <= 4, "group size");
     constexpr size_t TILE_BYTES = (size_t)B * B * 4;
     constexpr int WAVES = THREADS / 64;
     constexpr int JPT = (CAPJ + THREADS - 1) / THREADS;      // staged / held entries per thread
@@ -794,21 +799,20 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
         const uint32_t row_byte = (item & C_CELL) * (B * 4u);
         const unsigned char *p = sJb + ((item >> IT_J_SHIFT) & IT_J_MASK) * 2u;
         // lanes with fewer than four read on inside the staging area: harmless, masked by `in`
-        const uint32_t w0 = *reinterpret_cast<const uint16_t *>(p);
-        const uint32_t w1 = *reinterpret_cast<const uint16_t *>(p + 2);
-        const uint32_t w2 = *reinterpret_cast<const uint16_t *>(p + 4);
-        const uint32_t w3 = *reinterpret_cast<const uint16_t *>(p + 6);
-        const unsigned long long in0 = __ballot(c > 0u), in1 = __ballot(c > 1u), in2 = __ballot(c > 2u),
-                                 in3 = __ballot(c > 3u), more = __ballot(c > 4u);
-        pair_slot(rec9, row_byte, w0, in0);
-        pair_slot(rec9, row_byte, w1, in1);
-        pair_slot(rec9, row_byte, w2, in2);
-        pair_slot(rec9, row_byte, w3, in3);
+        uint32_t w[GROUP];
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) w[u] = *reinterpret_cast<const uint16_t *>(p + 2 * u);
+        unsigned long long in[GROUP];
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) in[u] = __ballot(c > (uint32_t)u);
+        const unsigned long long more = __ballot(c > (uint32_t)GROUP);
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) pair_slot(rec9, row_byte, w[u], in[u]);
         if (more) {
             if (__builtin_amdgcn_inverse_ballot_w64(more)) {
                 const uint32_t slot = ring_tail + __builtin_amdgcn_mbcnt_hi(
                         (uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
-                ring[slot & (RING - 1)] = item + (4u << IT_J_SHIFT) - (4u << IT_C_SHIFT);
+                ring[slot & (RING - 1)] = item + ((uint32_t)GROUP << IT_J_SHIFT) - ((uint32_t)GROUP << IT_C_SHIFT);
             }
             ring_tail += (uint32_t)__popcll(more);
         }
@@ -1396,13 +1400,13 @@ __global__ __launch_bounds__(1024) void scan_exclusive_1wg(const uint32_t *in, u
     }
 }
 
-template <int B, int THREADS, int CAPJ, int CAPL>
+template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
 hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t stream, const SideStream *side) {
     constexpr size_t lds = (size_t)B * B * 4 + (size_t)CAPJ * 2 + ((size_t)CAPL + 2) * 2
             + (size_t)(THREADS / 64) * (size_t)COUNTS_RING * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((CAPL + 2) % 4 == 0 && CAPJ % 8 == 0, "alignment of the LDS carve-up");
-    auto kern = &accumulate_counts<B, THREADS, CAPJ, CAPL>;
+    auto kern = &accumulate_counts<B, THREADS, CAPJ, CAPL, GROUP>;
     static thread_local int configured_device = -1;  // the attribute is per device and sticky
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1504,12 +1508,20 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
     const uint32_t grid = args.n_workgroups;
     if (block_cells == 128) {
         // the 128 KiB int64 tile leaves no room for the window masks: joint terms go through HBM
-        if (count_tile && pair_mode() != 0) return launch_counts<128, 1024, kCapJ128C, kCapL128C>(args, grid, stream, side);
+        if (count_tile && pair_mode() != 0) {
+            static const int g = [] { const char *e = std::getenv("SECEDO_GROUP"); return e ? std::atoi(e) : 0; }();
+            if (g == 1) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 1>(args, grid, stream, side);
+            if (g == 3) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 3>(args, grid, stream, side);
+            if (g == 4) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 4>(args, grid, stream, side);
+            if (g == 2 || (g == 0 && args.sparse_blocks))
+                return launch_counts<128, 1024, kCapJ128C, kCapL128C, 2>(args, grid, stream, side);
+            return launch_counts<128, 1024, kCapJ128C, kCapL128C, 3>(args, grid, stream, side);
+        }
         if (count_tile) return launch_acc<128, 1024, kCapJ128C, kCapL128C, 1024, false, true>(args, grid, stream);
         return launch_acc<128, 1024, kCapJ128, kCapL128, 512, false, false>(args, grid, stream);
     }
     if (stage_masks) return launch_acc<64, 512, kCapJ64M, kCapL64M, 1024, true, false>(args, grid, stream);
-    if (count_tile && pair_mode() != 0) return launch_counts<64, 512, kCapJ64C, kCapL64C>(args, grid, stream, side);
+    if (count_tile && pair_mode() != 0) return launch_counts<64, 512, kCapJ64C, kCapL64C, 4>(args, grid, stream, side);
     if (count_tile) return launch_acc<64, 256, kCapJ64C, kCapL64C, 1024, false, true>(args, grid, stream);
     return launch_acc<64, 256, kCapJ64, kCapL64, 1024, false, false>(args, grid, stream);
 }

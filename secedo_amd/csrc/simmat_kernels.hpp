@@ -21,7 +21,7 @@ struct LlrModelDev {  // LlrModel of llr_table.hpp, by value into the kernel
 // to these limits. LDS per workgroup: B=64: 32 KiB tile + 12/28 KiB; B=128: 128 KiB tile + 24/28 KiB.
 constexpr uint32_t kCapJ64 = 4096, kCapL64 = 2046, kCapJ64M = 4096, kCapL64M = 2046, kCapJ64C = 4096, kCapL64C = 2046;
 constexpr uint32_t kCapJ128 = 4096, kCapL128 = 2046, kCapJ128M = 4096, kCapL128M = 2046;
-constexpr uint32_t kCapJ128C = 8192, kCapL128C = 4094;  // the 64 KiB count tile leaves room for longer ranges
+constexpr uint32_t kCapJ128C = 8192, kCapL128C = 8190;  // the 64 KiB count tile leaves room for longer ranges
 constexpr double kMasksThreshold = 0.05;  // stage the masks when > 5 % of the entries are multi-locus
 
 // Everything only the rare paths touch lives in HBM behind one pointer, so that the kernel's
@@ -71,6 +71,7 @@ struct AccumulateArgs {
     const uint32_t *unit_off = nullptr;     // num_loci + 1: work units of correct_flagged (64 entries of a locus)
     const uint32_t *unit_locus = nullptr;   // unit -> locus
     uint32_t unit_bound = 0;                // upper bound of the number of units (sizes the grid)
+    bool sparse_blocks = false;             // fewer than ~2.5 entries per (cell block, locus): groups of two
     uint32_t num_blocks = 0;
     uint32_t tile_end = 0;                  // tiles [tile_begin, tile_end) when tile_selected == nullptr
     const uint8_t *tile_selected = nullptr; // one flag per tile (a launch over a tile list)

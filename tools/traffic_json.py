@@ -28,10 +28,15 @@ pick = lambda d, name: next(sum(v) / len(v) for k, v in d.items() if name in k)
 f4, f16, w16 = pick(cal_f, "read4") / GIB_KIB, pick(cal_f, "read16") / GIB_KIB, pick(cal_w, "write16") / GIB_KIB
 fetch = per_kernel("pmc_FETCH_SIZE", "FETCH_SIZE")
 write = per_kernel("pmc_WRITE_SIZE", "WRITE_SIZE")
-name = next(k for k in fetch if "accumulate_tiles" in k)
-fk, wk = sum(fetch[name]) / len(fetch[name]), sum(write[name]) / len(write[name])
-# the kernel's loads are 4 bytes per lane (entry32 / offsets), its stores 16 bytes per lane (slab flush)
+# the kernels of one accumulate: the pair kernel (dominant), the slab reduction, the per-locus correction
+names = [k for k in fetch if any(s in k for s in ("accumulate_counts", "accumulate_tiles", "reduce_slabs", "correct_flagged"))]
+name = next(k for k in names if "accumulate_" in k)
+avg = lambda d, k: sum(d[k]) / len(d[k])
+fk, wk = avg(fetch, name), avg(write, name)
+f_all, w_all = sum(avg(fetch, k) for k in names), sum(avg(write, k) for k in names)
+# the loads are 4 bytes per lane (entry32 / offsets), the stores 16 bytes per lane (slab flush)
 hbm = (fk / f4 + wk / w16) * 1024.0
+hbm_all = (f_all / f4 + w_all / w16) * 1024.0
 print(json.dumps({
     "_comment": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes over `python bench.py --steps 3 "
                 "--warmup 1 --no-cpu-baseline`), per accumulate_tiles launch, KiB as the counters report them; "
@@ -41,4 +46,5 @@ print(json.dumps({
                     "WRITE_SIZE_per_true_KiB_write_16B_per_lane": w16},
     "C3": {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "hbm_bytes_per_launch": hbm,
            "hbm_bytes_uncorrected": (fk + wk) * 1024.0, "launches": len(fetch[name]), "kernel": name[:80],
+           "hbm_bytes_per_accumulate_all_kernels": hbm_all, "kernels": [k[:60] for k in names],
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated"}}, indent=1))
