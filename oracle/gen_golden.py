@@ -381,6 +381,75 @@ def laplacian_kat():
     print("laplacian_kat: 3 x 3")
 
 
+SPECTRAL_GEN_CPP = r"""
+// Input matrices of the reference's SpectralClustering.TwoClusters / ThreeClusters tests
+// (tests/test_spectral_clustering.cpp:58-129 and :131-185), regenerated with the same standard-library
+// generator the reference's tests run with (std::default_random_engine, default seed, and
+// std::uniform_int_distribution of this libstdc++): background similarity 0..5, plus 20 four times out
+// of five; inside a clone 100..200. Writes n, then n*n doubles, per matrix.
+#include <cstdint>
+#include <cstdio>
+#include <random>
+#include <vector>
+static void emit(uint32_t n, uint32_t groups, FILE *f) {
+    std::default_random_engine generator;
+    std::uniform_int_distribution<uint32_t> dissimilar(0, 5);
+    std::uniform_int_distribution<uint32_t> similar(100, 200);
+    std::vector<double> m((size_t)n * n, 0.0);
+    auto set = [&](uint32_t i, uint32_t j, double v) { m[(size_t)i * n + j] = v; m[(size_t)j * n + i] = v; };
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t j = 0; j < i; ++j) {
+            if (similar(generator) % 5) set(i, j, dissimilar(generator) + 20);
+            else set(i, j, dissimilar(generator));
+        }
+    const uint32_t part = n / groups;
+    for (uint32_t i = 0; i < part; ++i)
+        for (uint32_t j = 0; j < i; ++j) {
+            if (similar(generator) % 2) {
+                set(i, j, similar(generator));
+            } else {
+                for (uint32_t g = 1; g < groups; ++g) set(i + g * part, j + g * part, similar(generator));
+            }
+        }
+    double dn = n;
+    fwrite(&dn, 8, 1, f);
+    fwrite(m.data(), 8, m.size(), f);
+}
+int main(int argc, char **argv) {
+    FILE *f = fopen(argv[1], "wb");
+    emit(100, 2, f);
+    emit(99, 3, f);
+    fclose(f);
+    return 0;
+}
+"""
+
+
+def spectral_cases():
+    """The similarity matrices the reference's own spectral tests build (TwoClusters: 100 cells, two clones of
+    50; ThreeClusters: 99 cells, three clones of 33) and the assignment those tests expect
+    (tests/test_spectral_clustering.cpp:58-185). The matrices come out of libstdc++'s random distributions,
+    so they are generated here, in the build container, with the same library, and stored."""
+    import subprocess
+    with tempfile.TemporaryDirectory() as tmp:
+        src, exe, out = os.path.join(tmp, "g.cpp"), os.path.join(tmp, "g"), os.path.join(tmp, "m.bin")
+        open(src, "w").write(SPECTRAL_GEN_CPP)
+        subprocess.run(["g++", "-std=c++17", "-O1", src, "-o", exe], check=True)
+        subprocess.run([exe, out], check=True)
+        blob = np.fromfile(out, dtype=np.float64)
+    n2 = int(blob[0])
+    two = blob[1:1 + n2 * n2].reshape(n2, n2)
+    rest = blob[1 + n2 * n2:]
+    n3 = int(rest[0])
+    three = rest[1:1 + n3 * n3].reshape(n3, n3)
+    assert np.array_equal(two, two.T) and np.array_equal(three, three.T) and not np.any(np.diag(two))
+    np.savez_compressed(os.path.join(GOLDEN, "spectral_reference_inputs.npz"), two_clusters=two,
+                        two_expected=np.repeat([0, 1], 50).astype(np.int32), three_clusters=three,
+                        three_expected=np.repeat([0, 1, 2], 33).astype(np.int32))
+    print("spectral_reference_inputs: two clusters mean in/out %.1f / %.1f, three clusters %d x %d" % (
+        two[:50, :50].mean(), two[:50, 50:].mean(), n3, n3))
+
+
 def em_cases():
     """EM refinement (expectation_maximization.cpp): the five inputs of the reference's own
     tests/test_expectation_maximization.cpp:15-85 and three random pileups (one with a permuted
@@ -435,7 +504,7 @@ def main():
         sys.exit("oracle/_ref/libsecedo_ref.so missing: run `make -C oracle ref` in the container")
     os.makedirs(GOLDEN, exist_ok=True)
     for fn in (semantic_probes, kat_llr_table, reference_pileup_files, divide_clusters_shaped,
-               random_cases, wrap_cases, c2_reference_run, files_pipeline, filter_cases, reader_cases, laplacian_kat, em_cases):
+               random_cases, wrap_cases, c2_reference_run, files_pipeline, spectral_cases, filter_cases, reader_cases, laplacian_kat, em_cases):
         if not only or fn.__name__ in only:
             fn()
 

@@ -726,7 +726,11 @@ template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
 __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArgs a) {
     static_assert(CAPJ <= 8192, "13 bits of column index in an item");
     static_assert(GROUP >= 1 && GROUP <= 4, "group size");
-    constexpr size_t TILE_BYTES = (size_t)B * B * 4;
+    // Rows of the LDS tile are B + 1 words apart: the lanes of a wave that share a locus add to the SAME column
+    // (their common column entry) in DIFFERENT rows, and with a row stride of B words all of them would hit one
+    // bank (bank = column mod 32): 3-4 lanes deep at every locus, on top of the random collisions.
+    constexpr uint32_t ROW_WORDS = B + 1;
+    constexpr size_t TILE_BYTES = ((size_t)B * ROW_WORDS * 4 + 15) / 16 * 16;
     constexpr int WAVES = THREADS / 64;
     constexpr int JPT = (CAPJ + THREADS - 1) / THREADS;      // staged / held entries per thread
     constexpr int OPT = (CAPL + 1 + THREADS - 1) / THREADS;  // staged offsets per thread
@@ -773,7 +777,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
         row_begin = __builtin_amdgcn_readfirstlane(row_begin);
         row_end = __builtin_amdgcn_readfirstlane(row_end);
     }
-    for (uint32_t i = tid; i < B * B; i += THREADS) tile32[i] = 0u;
+    for (uint32_t i = tid; i < B * ROW_WORDS; i += THREADS) tile32[i] = 0u;
 
     const long long d10 = a.lut[1 * LUT_DIM + 0], d01 = a.lut[0 * LUT_DIM + 1];
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B;
@@ -781,53 +785,6 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
     uint32_t upd_w = 0;                // this wave's pairs in the current range (wave-uniform)
     uint32_t ring_head = 0, ring_tail = 0;  // wave-uniform, free-running
     const unsigned char *sJb = reinterpret_cast<const unsigned char *>(sJ);
-
-    // one (row entry, column entry) incidence per lane of `in`
-    auto pair_slot = [&](uint32_t rec9, uint32_t row_byte, uint32_t w, unsigned long long in) {
-        const uint32_t x = rec9 ^ w;
-        if (diag) in &= __ballot((x & C_CELL) != 0u);  // same cell (:215)
-        upd_w += (uint32_t)__popcll(in);
-        const uint32_t addr = row_byte + ((w & C_CELL) << 2);
-        if (__builtin_amdgcn_inverse_ballot_w64(in))
-            atomicAdd(reinterpret_cast<uint32_t *>(lds_raw + addr), (x & (3u << C_BASE_SHIFT)) ? 0x10000u : 1u);
-    };
-
-    // 64 items, each against its first four column entries; items with more go to the ring
-    auto group4 = [&](uint32_t item) {
-        const uint32_t c = item >> IT_C_SHIFT;
-        const uint32_t rec9 = item & IT_REC_MASK;
-        const uint32_t row_byte = (item & C_CELL) * (B * 4u);
-        const unsigned char *p = sJb + ((item >> IT_J_SHIFT) & IT_J_MASK) * 2u;
-        // lanes with fewer than four read on inside the staging area: harmless, masked by `in`
-        uint32_t w[GROUP];
-#pragma unroll
-        for (int u = 0; u < GROUP; ++u) w[u] = *reinterpret_cast<const uint16_t *>(p + 2 * u);
-        unsigned long long in[GROUP];
-#pragma unroll
-        for (int u = 0; u < GROUP; ++u) in[u] = __ballot(c > (uint32_t)u);
-        const unsigned long long more = __ballot(c > (uint32_t)GROUP);
-#pragma unroll
-        for (int u = 0; u < GROUP; ++u) pair_slot(rec9, row_byte, w[u], in[u]);
-        if (more) {
-            if (__builtin_amdgcn_inverse_ballot_w64(more)) {
-                const uint32_t slot = ring_tail + __builtin_amdgcn_mbcnt_hi(
-                        (uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
-                ring[slot & (RING - 1)] = item + ((uint32_t)GROUP << IT_J_SHIFT) - ((uint32_t)GROUP << IT_C_SHIFT);
-            }
-            ring_tail += (uint32_t)__popcll(more);
-        }
-    };
-    // one batch from the ring (up to 64 items)
-    auto drain_one = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t n = min(64u, ring_tail - ring_head);
-        uint32_t it = 0u;
-        if (lane < n) it = ring[(ring_head + lane) & (RING - 1)];
-        __builtin_amdgcn_wave_barrier();
-        ring_head += n;
-        group4(it);
-    };
 
     // the next range, in flight in registers while the current one is paired
     uint32_t pJ[JPT], pI[JPT], pO[OPT];
@@ -855,28 +812,31 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
         if (r + 1u < r_end) fetch_ahead(r + 1u);
         n_staged = (n_je - n_jb) <= (uint32_t)CAPJ && (n_ie - n_ib) <= (uint32_t)CAPJ
                 && (n_lb - n_la) <= (uint32_t)CAPL;
+        // Buffer loads: the descriptor (wave-uniform: base and byte count of the slice) does the bounds check, a
+        // lane past the end gets 0 -- no compare, no exec mask, no address arithmetic per load (the per-lane
+        // offset tid * 4 is loop-invariant, k * THREADS * 4 goes in the scalar offset).
         if (n_staged) {
+            const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<uint32_t *>(a.entry32 + n_jb), 0, (int)((n_je - n_jb) * 4u), 0x00020000);
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<uint32_t *>(offJ + n_la), 0, (int)((n_lb - n_la + 1u) * 4u), 0x00020000);
 #pragma unroll
-            for (int k = 0; k < JPT; ++k) {
-                const uint32_t i = tid + k * THREADS;
-                pJ[k] = i < n_je - n_jb ? a.entry32[n_jb + i] : 0u;
-            }
+            for (int k = 0; k < JPT; ++k)
+                pJ[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rj, (int)(tid * 4u), k * THREADS * 4, 0);
 #pragma unroll
-            for (int k = 0; k < OPT; ++k) {
-                const uint32_t i = tid + k * THREADS;
-                pO[k] = i <= n_lb - n_la ? offJ[n_la + i] : 0u;
-            }
+            for (int k = 0; k < OPT; ++k)
+                pO[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ro, (int)(tid * 4u), k * THREADS * 4, 0);
         }
     };
     // the row side of the range prefetch() described; issued later, when the registers of the current
     // range's items are free (the loads still have the ring drain and two barriers to land)
     auto prefetch_rows = [&]() {
         if (n_staged) {
+            const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<uint32_t *>(a.entry32 + n_ib), 0, (int)((n_ie - n_ib) * 4u), 0x00020000);
 #pragma unroll
-            for (int k = 0; k < JPT; ++k) {
-                const uint32_t i = tid + k * THREADS;
-                pI[k] = i < n_ie - n_ib ? a.entry32[n_ib + i] : 0u;
-            }
+            for (int k = 0; k < JPT; ++k)
+                pI[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, (int)(tid * 4u), k * THREADS * 4, 0);
         }
     };
 
@@ -891,115 +851,177 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
     unsigned long long st_barA = 0, st_stage = 0, st_items = 0, st_prim = 0, st_drain = 0, st_nprim = 0, st_ndrain = 0;
     const unsigned long long st_begin = stamp();
 #endif
-    for (uint32_t r = r_begin; r < r_end; ++r) {
-        const uint32_t la = n_la, lb = n_lb, ib = n_ib, ie = n_ie, jb = n_jb, je = n_je, dsh = n_dsh;
-        const bool staged = n_staged;
-        STAMP(s0);
-        __syncthreads();  // every wave is done with the previous range (first time: with zeroing)
-        STAMP(s1);
-        if (staged) {
-#pragma unroll
-            for (int k = 0; k < JPT; ++k) {
-                const uint32_t i = tid + k * THREADS;
-                if (i < je - jb) sJ[i] = (uint16_t)pJ[k];
-            }
-#pragma unroll
-            for (int k = 0; k < OPT; ++k) {
-                const uint32_t i = tid + k * THREADS;
-                if (i <= lb - la) sOff[i] = (uint16_t)(pO[k] - jb);
-            }
-        }
-        __syncthreads();
-        STAMP(s2);
+    // (Compiling the range loop twice, for diagonal tiles and for the others, to drop the run-time `diag` tests
+    // from the pair slots was measured slower -- 4.26 against 3.74 ms of accumulate on C3: 128 VGPRs with a
+    // spill, 9 % more vector instructions -- hence one instance with a wave-uniform flag.)
+    {
+        const bool DIAG = diag;
+        // one (row entry, column entry) incidence per lane of `in`
+        auto pair_slot = [&](uint32_t rec9, uint32_t row_byte, uint32_t w, unsigned long long in) {
+            const uint32_t x = rec9 ^ w;
+            if (DIAG) in &= __ballot((x & C_CELL) != 0u);  // same cell (:215)
+            upd_w += (uint32_t)__popcll(in);
+            const uint32_t addr = row_byte + ((w & C_CELL) << 2);
+            if (__builtin_amdgcn_inverse_ballot_w64(in))
+                atomicAdd(reinterpret_cast<uint32_t *>(lds_raw + addr), (x & (3u << C_BASE_SHIFT)) ? 0x10000u : 1u);
+        };
 
-        const uint32_t nI = ie - ib;
-        upd_w = 0;
-        if (staged) {
-            // items of this thread's row entries: the column entries of the entry's locus are
-            // sJ[j0 .. j0 + c); in a diagonal tile the entries after this one (each pair once)
-            uint32_t item[JPT];
+        // 64 items, each against its first four column entries; items with more go to the ring
+        auto group4 = [&](uint32_t item) {
+            const uint32_t c = item >> IT_C_SHIFT;
+            const uint32_t rec9 = item & IT_REC_MASK;
+            const uint32_t row_byte = (item & C_CELL) * (ROW_WORDS * 4u);
+            const unsigned char *p = sJb + ((item >> IT_J_SHIFT) & IT_J_MASK) * 2u;
+            // lanes with fewer than four read on inside the staging area: harmless, masked by `in`
+            uint32_t w[GROUP];
 #pragma unroll
-            for (int k = 0; k < JPT; ++k) {
-                const uint32_t i = tid + k * THREADS;
-                const uint32_t rec = pI[k];
-                const uint32_t lrel = rec >> 16;
-                uint32_t j0 = sOff[lrel];
-                const uint32_t j1 = sOff[lrel + 1];
-                if (diag) j0 = i + dsh + 1u;
-                uint32_t c = (i < nI && j1 > j0) ? j1 - j0 : 0u;
-                // wide entries (deep loci): the whole wave pairs one row entry with 64 column entries at a
-                // time, right here
-                unsigned long long todo = __ballot(c >= IT_WIDE);
-                if (todo) {
-                    if (c >= IT_WIDE) c |= 0x80000000u;  // marks the lanes below; cleared after
-                    while (todo) {
-                        const int src = __builtin_ctzll(todo);
-                        todo &= todo - 1ull;
-                        const uint32_t recw = __builtin_amdgcn_readlane(rec, src);
-                        const uint32_t cw = __builtin_amdgcn_readlane(c, src) & 0x7FFFFFFFu;
-                        const uint32_t j0w = __builtin_amdgcn_readlane(j0, src);
-                        const uint32_t row_byte = (recw & C_CELL) * (B * 4u);
-                        for (uint32_t base = 0; base < cw; base += 64u) {
-                            const uint32_t jj = j0w + base + lane;
-                            const unsigned long long in = __ballot(base + lane < cw);
-                            const uint32_t w = sJ[min(jj, (uint32_t)CAPJ - 1u)];
-                            pair_slot(recw & IT_REC_MASK, row_byte, w, in);
+            for (int u = 0; u < GROUP; ++u) w[u] = *reinterpret_cast<const uint16_t *>(p + 2 * u);
+            unsigned long long in[GROUP];
+#pragma unroll
+            for (int u = 0; u < GROUP; ++u) in[u] = __ballot(c > (uint32_t)u);
+            const unsigned long long more = __ballot(c > (uint32_t)GROUP);
+#pragma unroll
+            for (int u = 0; u < GROUP; ++u) pair_slot(rec9, row_byte, w[u], in[u]);
+            if (more) {
+                if (__builtin_amdgcn_inverse_ballot_w64(more)) {
+                    const uint32_t slot = ring_tail + __builtin_amdgcn_mbcnt_hi(
+                            (uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                    ring[slot & (RING - 1)] = item + ((uint32_t)GROUP << IT_J_SHIFT) - ((uint32_t)GROUP << IT_C_SHIFT);
+                }
+                ring_tail += (uint32_t)__popcll(more);
+            }
+        };
+        // one batch from the ring (up to 64 items)
+        auto drain_one = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n = min(64u, ring_tail - ring_head);
+            uint32_t it = 0u;
+            if (lane < n) it = ring[(ring_head + lane) & (RING - 1)];
+            __builtin_amdgcn_wave_barrier();
+            ring_head += n;
+            group4(it);
+        };
+
+        for (uint32_t r = r_begin; r < r_end; ++r) {
+            const uint32_t la = n_la, ib = n_ib, ie = n_ie, jb = n_jb, dsh = n_dsh;
+            const bool staged = n_staged;
+            STAMP(s0);
+            __syncthreads();  // every wave is done with the previous range (first time: with zeroing)
+            STAMP(s1);
+            if (staged) {
+                // (slots past the slice get the zeros of the buffer loads: the staging arrays hold JPT * THREADS
+                // entries and OPT * THREADS offsets, so every store is inside them, and nothing reads those slots)
+                static_assert(JPT * THREADS <= CAPJ && OPT * THREADS <= CAPL + 2, "unconditional staging stores");
+#pragma unroll
+                for (int k = 0; k < JPT; ++k) sJ[tid + k * THREADS] = (uint16_t)pJ[k];
+#pragma unroll
+                for (int k = 0; k < OPT; ++k) sOff[tid + k * THREADS] = (uint16_t)(pO[k] - jb);
+            }
+            __syncthreads();
+            STAMP(s2);
+
+            const uint32_t nI = ie - ib;
+            upd_w = 0;
+            if (staged) {
+                // items of this thread's row entries: the column entries of the entry's locus are
+                // sJ[j0 .. j0 + c); in a diagonal tile the entries after this one (each pair once)
+                uint32_t item[JPT];
+                uint32_t any_wide = 0;
+#pragma unroll
+                for (int k = 0; k < JPT; ++k) {
+                    const uint32_t i = tid + k * THREADS;
+                    const uint32_t rec = pI[k];
+                    const uint32_t lrel = rec >> 16;
+                    uint32_t j0 = sOff[lrel];
+                    const uint32_t j1 = sOff[lrel + 1];
+                    if (DIAG) j0 = i + dsh + 1u;
+                    const uint32_t c = (i < nI && j1 > j0) ? j1 - j0 : 0u;
+                    any_wide |= c;
+                    // (j0 can be CAPJ when c is 0: the last entry of a full diagonal range; c >= 256 spills into
+                    // nothing: the item is rebuilt below)
+                    item[k] = (rec & IT_REC_MASK) | ((j0 & IT_J_MASK) << IT_J_SHIFT) | (c << IT_C_SHIFT);
+                }
+                // wide entries (deep loci; none when loci are sparse: one test for the thread's JPT items): the
+                // whole wave pairs one row entry with 64 column entries at a time, right here
+                if (__ballot(any_wide >= IT_WIDE)) {
+#pragma unroll
+                    for (int k = 0; k < JPT; ++k) {
+                        const uint32_t i = tid + k * THREADS;
+                        const uint32_t rec = pI[k];
+                        const uint32_t lrel = rec >> 16;
+                        uint32_t j0 = sOff[lrel];
+                        const uint32_t j1 = sOff[lrel + 1];
+                        if (DIAG) j0 = i + dsh + 1u;
+                        const uint32_t c = (i < nI && j1 > j0) ? j1 - j0 : 0u;
+                        unsigned long long todo = __ballot(c >= IT_WIDE);
+                        while (todo) {
+                            const int src = __builtin_ctzll(todo);
+                            todo &= todo - 1ull;
+                            const uint32_t recw = __builtin_amdgcn_readlane(rec, src);
+                            const uint32_t cw = __builtin_amdgcn_readlane(c, src);
+                            const uint32_t j0w = __builtin_amdgcn_readlane(j0, src);
+                            const uint32_t row_byte = (recw & C_CELL) * (ROW_WORDS * 4u);
+                            for (uint32_t base = 0; base < cw; base += 64u) {
+                                const uint32_t jj = j0w + base + lane;
+                                const unsigned long long in = __ballot(base + lane < cw);
+                                const uint32_t w = sJ[min(jj, (uint32_t)CAPJ - 1u)];
+                                pair_slot(recw & IT_REC_MASK, row_byte, w, in);
+                            }
                         }
+                        if (c >= IT_WIDE) item[k] = 0u;  // done
                     }
-                    if (c & 0x80000000u) c = 0u;
                 }
-                // (j0 can be CAPJ when c is 0: the last entry of a full diagonal range)
-                item[k] = (rec & IT_REC_MASK) | ((j0 & IT_J_MASK) << IT_J_SHIFT) | (c << IT_C_SHIFT);
-            }
-            if (r + 1 < r_end) prefetch(r + 1);  // pJ / pO are free again: the next range's column side
-            STAMP(s3);
+                if (r + 1 < r_end) prefetch(r + 1);  // pJ / pO are free again: the next range's column side
+                STAMP(s3);
 #pragma unroll
-            for (int k = 0; k < JPT; ++k) {
-                // room for 64 more continuations (a drained batch may push up to 64 itself)
-                while (ring_tail - ring_head > (uint32_t)(RING - 64)) drain_one();
-                group4(item[k]);
-            }
-            if (r + 1 < r_end) prefetch_rows();
-            STAMP(s4);
-#ifdef SECEDO_STAMPS
-            st_ndrain += (ring_tail - ring_head + 63u) / 64u;
-            st_nprim += JPT;
-#endif
-            while (ring_tail != ring_head) drain_one();
-            STAMP(s5);
-#ifdef SECEDO_STAMPS
-            st_barA += s1 - s0;
-            st_stage += s2 - s1;
-            st_items += s3 - s2;
-            st_prim += s4 - s3;
-            st_drain += s5 - s4;
-#endif
-        } else {
-            if (r + 1 < r_end) {
-                prefetch(r + 1);
-                prefetch_rows();
-            }
-            // a locus range that does not fit the staging buffers (a single very deep locus): paired
-            // straight from HBM/L2 into HBM (flags are settled by correct_flagged here too)
-            uint32_t upd = 0;
-            for (uint32_t e1 = ib + tid; e1 < ie; e1 += THREADS) {
-                const uint32_t r1 = a.entry32[e1];
-                const uint32_t l = la + (r1 >> 16);
-                const uint32_t j0 = diag ? e1 + 1 : offJ[l];
-                const uint32_t j1 = offJ[l + 1];
-                const uint32_t row = (r1 & C_CELL) * B;
-                for (uint32_t e2 = j0; e2 < j1; ++e2) {
-                    const uint32_t r2 = a.entry32[e2];
-                    const uint32_t x = r1 ^ r2;
-                    if (diag && (x & C_CELL) == 0u) continue;  // same cell (:215)
-                    ++upd;
-                    atomicAdd(&dst[row + (r2 & C_CELL)],
-                              (unsigned long long)((x & (3u << C_BASE_SHIFT)) ? d01 : d10));
+                for (int k = 0; k < JPT; ++k) {
+                    // room for 64 more continuations (a drained batch may push up to 64 itself)
+                    while (ring_tail - ring_head > (uint32_t)(RING - 64)) drain_one();
+                    group4(item[k]);
                 }
+                if (r + 1 < r_end) prefetch_rows();
+                STAMP(s4);
+#ifdef SECEDO_STAMPS
+                st_ndrain += (ring_tail - ring_head + 63u) / 64u;
+                st_nprim += JPT;
+#endif
+                while (ring_tail != ring_head) drain_one();
+                STAMP(s5);
+#ifdef SECEDO_STAMPS
+                st_barA += s1 - s0;
+                st_stage += s2 - s1;
+                st_items += s3 - s2;
+                st_prim += s4 - s3;
+                st_drain += s5 - s4;
+#endif
+            } else {
+                if (r + 1 < r_end) {
+                    prefetch(r + 1);
+                    prefetch_rows();
+                }
+                // a locus range that does not fit the staging buffers (a single very deep locus): paired
+                // straight from HBM/L2 into HBM (flags are settled by correct_flagged here too)
+                uint32_t upd = 0;
+                for (uint32_t e1 = ib + tid; e1 < ie; e1 += THREADS) {
+                    const uint32_t r1 = a.entry32[e1];
+                    const uint32_t l = la + (r1 >> 16);
+                    const uint32_t j0 = DIAG ? e1 + 1 : offJ[l];
+                    const uint32_t j1 = offJ[l + 1];
+                    const uint32_t row = (r1 & C_CELL) * B;
+                    for (uint32_t e2 = j0; e2 < j1; ++e2) {
+                        const uint32_t r2 = a.entry32[e2];
+                        const uint32_t x = r1 ^ r2;
+                        if (DIAG && (x & C_CELL) == 0u) continue;  // same cell (:215)
+                        ++upd;
+                        atomicAdd(&dst[row + (r2 & C_CELL)],
+                                  (unsigned long long)((x & (3u << C_BASE_SHIFT)) ? d01 : d10));
+                    }
+                }
+                n_updates += upd;
             }
-            n_updates += upd;
+            if (lane == 0u) n_updates += upd_w;
         }
-        if (lane == 0u) n_updates += upd_w;
     }
 #ifdef SECEDO_STAMPS
     if (lane == 0u && (blockIdx.x & 15u) == 0u) {  // a sample of the workgroups, every wave of them
@@ -1023,9 +1045,8 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
 
     // flush: the tile goes to the workgroup's own slab with plain coalesced stores (reduce_slabs adds up)
     {
-        uint4 *out = reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(a.slab) + (size_t)blockIdx.x * B * B);
-        const uint4 *src = reinterpret_cast<const uint4 *>(tile32);
-        for (uint32_t i = tid; i < B * B / 4; i += THREADS) out[i] = src[i];
+        uint32_t *out = reinterpret_cast<uint32_t *>(a.slab) + (size_t)blockIdx.x * B * B;
+        for (uint32_t i = tid; i < B * B; i += THREADS) out[i] = tile32[(i / B) * ROW_WORDS + (i % B)];  // dense rows
     }
     // work counter: wave reduction, then one atomic pair per workgroup (see accumulate_tiles); every
     // incidence counts as an update and as a read pair here, correct_flagged takes back what is neither
@@ -1402,7 +1423,7 @@ __global__ __launch_bounds__(1024) void scan_exclusive_1wg(const uint32_t *in, u
 
 template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
 hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t stream, const SideStream *side) {
-    constexpr size_t lds = (size_t)B * B * 4 + (size_t)CAPJ * 2 + ((size_t)CAPL + 2) * 2
+    constexpr size_t lds = ((size_t)B * (B + 1) * 4 + 15) / 16 * 16 + (size_t)CAPJ * 2 + ((size_t)CAPL + 2) * 2
             + (size_t)(THREADS / 64) * (size_t)COUNTS_RING * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((CAPL + 2) % 4 == 0 && CAPJ % 8 == 0, "alignment of the LDS carve-up");

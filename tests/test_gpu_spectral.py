@@ -158,3 +158,30 @@ def test_divide_cluster_demo_runs_end_to_end():
                          capture_output=True, text=True).stdout.strip().splitlines()[-1]
     line = json.loads(out)
     assert line["cells"] == 64 and line["split_purity"] == 1.0
+
+
+def test_reference_two_and_three_cluster_inputs():
+    """The similarity matrices the reference's own spectral tests build (SpectralClustering.TwoClusters /
+    ThreeClusters, tests/test_spectral_clustering.cpp:58-185; regenerated with the same libstdc++ generator,
+    oracle/gen_golden.py: spectral_cases) through the GPU eigensolver: eigenpairs against LAPACK as everywhere,
+    and the assignment those tests expect -- two clones of 50 by the sign of the Fiedler vector (the
+    reference's FIEDLER rule, spectral_clustering.cpp:218-228; the test tolerates 3 misplaced cells, here none),
+    three clones of 33 by the second and third eigenvector."""
+    z = np.load(os.path.join(GOLDEN, "spectral_reference_inputs.npz"))
+    a = z["two_clusters"]
+    vals, vecs, _ = check_against_lapack(a, 20, 7)
+    side = (vecs[:, 1] > 0).astype(np.int32)
+    expect = z["two_expected"]
+    assert np.array_equal(side, expect) or np.array_equal(1 - side, expect)
+    assert vals[1] < 0.5 * vals[2]  # one clear gap after the two clone directions
+
+    a = z["three_clusters"]
+    vals, vecs, _ = check_against_lapack(a, 20, 7)
+    emb = vecs[:, 1:3]
+    expect = z["three_expected"]
+    centres = np.stack([emb[expect == g].mean(axis=0) for g in range(3)])
+    nearest = np.argmin(((emb[:, None, :] - centres[None, :, :]) ** 2).sum(axis=2), axis=1)
+    assert np.array_equal(nearest, expect)  # 33 / 33 / 33, as the reference's test asks
+    spread = max(np.linalg.norm(emb[expect == g] - centres[g], axis=1).max() for g in range(3))
+    sep = min(np.linalg.norm(centres[g] - centres[h]) for g in range(3) for h in range(g))
+    assert spread < 0.25 * sep
