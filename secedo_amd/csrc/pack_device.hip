@@ -598,10 +598,13 @@ __device__ __forceinline__ unsigned long long bin_key(uint32_t blk, uint32_t l, 
 
 // binning key (cell block, locus, cell) of every kept entry, in per-read (CSR) order; validates the
 // group -> row mapping
+// ... and, per kept entry, what k_records needs of its read in 5 bytes (appearance rank; base | multi-locus
+// flag): the reads are adjacent here, in k_records' binned order they are five scattered gathers
 __global__ void k_keys2(Raw in, const uint32_t *sval, const unsigned long long *incl,
-                        const uint32_t *read_locus, uint32_t num_cells, uint32_t B,
+                        const uint32_t *read_locus, const uint32_t *run_rank, const uint32_t *read_off,
+                        uint32_t num_cells, uint32_t B,
                         uint32_t lbits, unsigned long long *key2, uint32_t *val2, uint32_t *t_read,
-                        unsigned long long *entry_kc, Scalars *sc) {
+                        uint32_t *krank, uint8_t *kflags, unsigned long long *entry_kc, Scalars *sc) {
     const uint32_t n = in.n_entries;
     for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
         const unsigned long long cur = incl[s], prev = s ? incl[s - 1] : 0ull;
@@ -624,7 +627,10 @@ __global__ void k_keys2(Raw in, const uint32_t *sval, const unsigned long long *
         const uint32_t blk = cell / B, cib = cell - blk * B;
         key2[k] = bin_key(blk, read_locus[k], cib, lbits);
         val2[k] = k;
-        t_read[k] = incl_reads(cur) - 1;
+        const uint32_t r = incl_reads(cur) - 1;
+        t_read[k] = r;
+        krank[k] = run_rank[r];
+        kflags[k] = (uint8_t)((in.id_base(sval[s]) & 3u) | (read_off[r + 1] - read_off[r] > 1u ? 4u : 0u));
         // counting path: back in pileup order, where the entries of a locus are adjacent; one 8-byte
         // scatter per entry carries k and (block, cell in block)
         if (entry_kc) entry_kc[sval[s]] = ((unsigned long long)((blk << kCibBits) | cib) << 32) | k;
@@ -932,7 +938,7 @@ __global__ void k_locus_info(Raw in, const uint32_t *range_off, const Scalars *s
 // entry records at their final (binned) position d: window masks from the per-read lists
 __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_t *sval2, uint32_t n,
                           const uint32_t *t_read, const uint32_t *read_off, const uint32_t *read_locus,
-                          const uint8_t *read_base, const uint32_t *run_rank, const uint32_t *rbeg,
+                          const uint8_t *read_base, const uint32_t *krank, const uint8_t *kflags, const uint32_t *rbeg,
                           const uint32_t *flushed, const uint32_t *locus_chr, const uint32_t *locus_rel, uint32_t B,
                           uint32_t lbits, uint4 *entry, uint32_t *entry32, uint32_t *mask32, uint32_t *entry_read) {
     for (uint32_t d = blockIdx.x * TPB + threadIdx.x; d < n; d += gridDim.x * TPB) {
@@ -942,11 +948,18 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
         const unsigned long long grp = key >> kCibBits;
         const uint32_t blk = (uint32_t)(grp >> lbits), l = (uint32_t)grp & ((1u << lbits) - 1u);
         const uint32_t cell = blk * B + cib;
-        const uint32_t r = t_read[k];
-        const uint32_t lo = read_off[r], hi = read_off[r + 1];
-        const uint32_t base = read_base[k];
+        const uint32_t fl = kflags[k];
+        const uint32_t base = fl & 3u;
+        const bool multi = (fl & 4u) != 0u;
         const uint32_t chr = locus_chr[l];
-        const bool tail = run_rank[r] - rbeg[chr] >= flushed[chr];
+        const bool tail = krank[k] - rbeg[chr] >= flushed[chr];
+        // the read's list of kept entries: only a multi-locus read has neighbours to look for
+        uint32_t r = 0, lo = k, hi = k + 1;
+        if (multi) {
+            r = t_read[k];
+            lo = read_off[r];
+            hi = read_off[r + 1];
+        }
         uint32_t meta = cell | (base << kMetaBaseShift) | (tail ? kMetaTail : 0u);
         uint32_t masks = 0, bases = 0;
         bool wide = false;
@@ -972,11 +985,11 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
         }
         // the 16-byte record and the read index serve the flagged entries only: pairs of two multi-locus
         // reads, and (correct_flagged) pairs of two reads that were never flushed
-        if (hi - lo > 1 || tail) {
+        if (multi || tail) {
             entry[d] = make_uint4(meta, masks, bases, l);
-            entry_read[d] = r;
+            entry_read[d] = r;  // (read only for pairs of two multi-locus reads)
         }
-        entry32[d] = cib | (base << kC_BaseShift) | (tail ? kC_Tail : 0u) | (hi - lo > 1 ? kC_Multi : 0u)
+        entry32[d] = cib | (base << kC_BaseShift) | (tail ? kC_Tail : 0u) | (multi ? kC_Multi : 0u)
                 | (wide ? kC_Wide : 0u) | (locus_rel[l] << 16);
         if (mask32)  // staged by the clustered-loci tile variant only
             mask32[d] = (masks & 0xFFu) | (((masks >> 16) & 0xFFu) << 8) | ((bases & 0xFFu) << 16)
@@ -1293,8 +1306,12 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     };
     if (force_radix) HIP_OK(hipMemsetAsync(blk_cnt, 0, (n_off + 1) * 4, stream));
     HIP_OK(hipMemsetAsync(per_cell_sq, 0, ((size_t)nb * B + 1) * 8, stream));
-    hipLaunchKernelGGL(k_keys2, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, incl, read_locus, num_cells, B,
-                       lbits, key2_a, val2_a, t_read, entry_kc, sc);
+    // per kept entry what k_records needs of its read: appearance rank (the duplicate-rule flags in WORK_A
+    // are dead) and base | multi flag (the grouped ids in VAL_A are dead)
+    uint32_t *krank = work_a;
+    uint8_t *kflags = S[VAL_A].as<uint8_t>();
+    hipLaunchKernelGGL(k_keys2, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, incl, read_locus, run_rank,
+                       read_off, num_cells, B, lbits, key2_a, val2_a, t_read, krank, kflags, entry_kc, sc);
     trace.mark("k_keys2 launched");
     const uint32_t slice_grid = std::min<uint32_t>(2048, (n_kept + 4095) / 4096);
     if (force_radix) {
@@ -1336,7 +1353,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         hipLaunchKernelGGL(k_locus_info, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, pk.range_off.as<uint32_t>(), sc,
                            locus_chr, locus_rel);
         hipLaunchKernelGGL(k_records, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, raw, key2_b, val2_b, n_kept,
-                           t_read, read_off, read_locus, read_base, run_rank, rbeg, flushed, locus_chr, locus_rel, B,
+                           t_read, read_off, read_locus, read_base, krank, kflags, rbeg, flushed, locus_chr, locus_rel, B,
                            lbits, pk.entry.as<uint4>(),
                            pk.entry32.as<uint32_t>(), pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr,
                            pk.entry_read.as<uint32_t>());
