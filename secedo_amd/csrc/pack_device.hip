@@ -67,6 +67,7 @@ struct Scalars {
     uint32_t split_changed;
     uint32_t id_exceeded;  // the id space is larger than the caller assumed (the size of the previous call)
     uint32_t max_read_entries;  // kept entries of the longest read id run
+    uint32_t caps_wrong;        // the locus ranges were cut for the count tile, and the pair bound forbids it
     unsigned long long id_space;  // sum over chromosomes of (largest - smallest read id + 1)
     unsigned long long multi_entries;
     unsigned long long pair_bound;
@@ -686,70 +687,10 @@ __global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, const un
             if (k == kNoEntry) continue;
             const uint32_t cc = (uint32_t)(kc >> 32);
             const uint32_t pos = atomicAdd(&cursor[cc >> kCibBits], 1u);
-            grouped[pos] = ((unsigned long long)(cc & ((1u << kCibBits) - 1u)) << 32) | k;
+            // cell in block | locus << 7 above k (k_entry_records; the radix path never comes here)
+            grouped[pos] = ((unsigned long long)((cc & ((1u << kCibBits) - 1u)) | (l << kCibBits)) << 32) | k;
         }
         __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// rank inside the (block, locus) group by (cell, k) -> the order the binning sort gives; the first
-// entry of a cell at a locus also adds (entries of the cell at the locus)^2 to the cell's sum (the
-// Cauchy-Schwarz pair bound), through LDS: a workgroup's slice spans few cell blocks.
-constexpr int TPB_RANK = 1024;  // many entries in flight per workgroup: the loop is a chain of gathers
-__global__ __launch_bounds__(TPB_RANK) void k_bin_rank(const unsigned long long *key2, const unsigned long long *grouped,
-                                                 uint32_t n, uint32_t B, uint32_t L, uint32_t lbits,
-                                                 const uint32_t *blk_off, unsigned long long *skey2,
-                                                 uint32_t *sval2, unsigned long long *per_cell_sq, Scalars *sc) {
-    constexpr uint32_t SLOTS = 512;
-    __shared__ unsigned long long sq[SLOTS];
-    __shared__ uint32_t first_cell;
-    const uint32_t per_block = (n + gridDim.x - 1) / gridDim.x;
-    const uint32_t d0 = blockIdx.x * per_block, d1 = min(n, d0 + per_block);
-    for (uint32_t i = threadIdx.x; i < SLOTS; i += TPB_RANK) sq[i] = 0;
-    if (threadIdx.x == 0 && d0 < n) {
-        const unsigned long long key = key2[(uint32_t)grouped[d0]];
-        first_cell = (uint32_t)(key >> (kCibBits + lbits)) * B;
-    }
-    __syncthreads();
-    for (uint32_t p = d0 + threadIdx.x; p < d1; p += TPB_RANK) {
-        const unsigned long long mine = grouped[p];
-        const uint32_t k = (uint32_t)mine;
-        const unsigned long long key = key2[k];
-        const unsigned long long grp = key >> kCibBits;
-        const uint32_t blk = (uint32_t)(grp >> lbits), l = (uint32_t)grp & ((1u << lbits) - 1u);
-        const size_t g = (size_t)blk * (L + 1) + l;
-        const uint32_t b = blk_off[g], len = blk_off[g + 1] - b;
-        uint32_t rank = p - b, same = 1;
-        bool first = true;
-        if (len > kRankScanLimit) {
-            sc->regroup = 1;
-        } else if (len > 1) {
-            rank = 0;
-            same = 0;
-            for (uint32_t q = b; q < b + len; ++q) {
-                const unsigned long long other = grouped[q];
-                rank += other < mine ? 1u : 0u;
-                if ((other >> 32) == (mine >> 32)) {
-                    ++same;
-                    if (other < mine) first = false;
-                }
-            }
-        }
-        skey2[b + rank] = key;
-        sval2[b + rank] = k;
-        if (first) {
-            const uint32_t cell = blk * B + (uint32_t)(mine >> 32);
-            const uint32_t rel = cell - first_cell;
-            const unsigned long long v = (unsigned long long)same * same;
-            if (rel < SLOTS) atomicAdd(&sq[rel], v);
-            else atomicAdd(&per_cell_sq[cell], v);
-        }
-    }
-    __syncthreads();
-    if (d0 < n) {
-        for (uint32_t i = threadIdx.x; i < SLOTS; i += TPB_RANK) {
-            if (sq[i]) atomicAdd(&per_cell_sq[first_cell + i], sq[i]);
-        }
     }
 }
 
@@ -890,10 +831,12 @@ __global__ __launch_bounds__(TPB) void k_ranges_segment(const uint32_t *blk_off,
 __global__ __launch_bounds__(TPB) void k_ranges_compact(const uint32_t *seg_ends_both, const uint32_t *seg_count_both,
                                                        size_t variant_stride, uint32_t n_seg, CapChoice caps,
                                                        uint32_t *range_off, const unsigned long long *per_cell_sq,
-                                                       uint32_t n_cells_padded, Scalars *sc) {
-    // the pair bound first: the largest per-cell sum of squares (it used to be a launch of its own)
+                                                       uint32_t n_cells_padded, int force_variant, Scalars *sc) {
+    // force_variant < 0: the pair bound first (the largest per-cell sum of squares), then the limits it allows;
+    // 0 / 1: the limits of the int64 tile / of the count tile, whatever the bound (the counting path cuts for
+    // the count tile before the bound is known, k_pair_bound checks afterwards)
     __shared__ unsigned long long s_best[TPB / 64];
-    {
+    if (force_variant < 0) {
         unsigned long long best = 0;
         for (uint32_t i = threadIdx.x; i < n_cells_padded; i += TPB) best = max(best, per_cell_sq[i]);
         for (int off = 32; off > 0; off >>= 1) best = max(best, (unsigned long long)__shfl_down(best, off));
@@ -905,7 +848,7 @@ __global__ __launch_bounds__(TPB) void k_ranges_compact(const uint32_t *seg_ends
         }
         __syncthreads();
     }
-    const bool use_counts = caps.counts(sc);
+    const bool use_counts = force_variant < 0 ? caps.counts(sc) : force_variant == 1;
     const uint32_t cap_loci = use_counts ? caps.loci_counts : caps.loci_plain;
     const uint32_t *seg_ends = seg_ends_both + (use_counts ? variant_stride : 0);
     const uint32_t *seg_count = seg_count_both + (use_counts ? variant_stride : 0);
@@ -994,6 +937,155 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
         if (mask32)  // staged by the clustered-loci tile variant only
             mask32[d] = (masks & 0xFFu) | (((masks >> 16) & 0xFFu) << 8) | ((bases & 0xFFu) << 16)
                     | (((bases >> 16) & 0xFFu) << 24);
+    }
+}
+
+// ---- counting path: k_bin_rank + k_records in one pass ------------------------------------------------
+// Nothing depends on the order of the entries inside a (cell block, locus) group (the pair kernels enumerate
+// every pair of a locus once, in whatever order the entries stand; diagonal tiles pair an entry with the
+// entries after it), so the entries stay where k_bin_place put them: no ranking, no sorted copy of keys and
+// values. k_bin_place packs the locus next to (cell in block, k) in its 8 bytes, the block follows from the
+// position (a search over the nb block boundaries, held in LDS), and a thread per entry scans its group for
+// the entries of the same cell: an entry of a cell with n entries at the locus adds n to the cell's sum, n of
+// them n^2 -- the Cauchy-Schwarz pair bound. (A thread per GROUP instead read the tables once per group but
+// walked its entries one after the other, a chain of gathers per thread: 7.4 ms on C3 against 2.7.)
+struct RecordTables {  // by value: what a record needs beside the group's own entries
+    const uint32_t *t_read, *read_off, *read_locus;
+    const uint8_t *read_base;
+    const uint32_t *krank;
+    const uint8_t *kflags;
+    const uint32_t *rbeg, *flushed, *locus_chr, *locus_rel;
+    uint4 *entry;
+    uint32_t *entry32, *mask32, *entry_read;
+};
+
+__device__ __forceinline__ void emit_record(const RecordTables &t, uint32_t d, uint32_t k, uint32_t cib, uint32_t cell,
+                                            uint32_t l, uint32_t lrel, uint32_t rb, uint32_t fl_chr) {
+    const uint32_t fl = t.kflags[k];
+    const uint32_t base = fl & 3u;
+    const bool multi = (fl & 4u) != 0u;
+    const bool tail = t.krank[k] - rb >= fl_chr;
+    // the read's list of kept entries: only a multi-locus read has neighbours to look for
+    uint32_t r = 0, lo = k, hi = k + 1;
+    if (multi) {
+        r = t.t_read[k];
+        lo = t.read_off[r];
+        hi = t.read_off[r + 1];
+    }
+    uint32_t meta = cell | (base << kMetaBaseShift) | (tail ? kMetaTail : 0u);
+    uint32_t masks = 0, bases = 0;
+    bool wide = false;
+    for (uint32_t j = k; j-- > lo;) {
+        const uint32_t dist = l - t.read_locus[j];
+        if (dist > kNarrowWindow) wide = true;
+        if (dist > kWindow) {
+            meta |= kMetaPrevOvf;
+            break;
+        }
+        masks |= 1u << (dist - 1);
+    }
+    for (uint32_t j = k + 1; j < hi; ++j) {
+        const uint32_t dist = t.read_locus[j] - l;
+        if (dist > kNarrowWindow) wide = true;
+        if (dist > kWindow) {
+            meta |= kMetaNextOvf;
+            break;
+        }
+        masks |= 1u << (16 + dist - 1);
+        bases |= (uint32_t)(t.read_base[j] & 1u) << (dist - 1);
+        bases |= (uint32_t)((t.read_base[j] >> 1) & 1u) << (16 + dist - 1);
+    }
+    // the 16-byte record and the read index serve the flagged entries only (see k_records)
+    if (multi || tail) {
+        t.entry[d] = make_uint4(meta, masks, bases, l);
+        t.entry_read[d] = r;
+    }
+    t.entry32[d] = cib | (base << kC_BaseShift) | (tail ? kC_Tail : 0u) | (multi ? kC_Multi : 0u)
+            | (wide ? kC_Wide : 0u) | (lrel << 16);
+    if (t.mask32)
+        t.mask32[d] = (masks & 0xFFu) | (((masks >> 16) & 0xFFu) << 8) | ((bases & 0xFFu) << 16)
+                | (((bases >> 16) & 0xFFu) << 24);
+}
+
+constexpr int TPB_REC = 512;
+__global__ __launch_bounds__(TPB_REC) void k_entry_records(const unsigned long long *grouped, const uint32_t *blk_off,
+                                                          uint32_t n, uint32_t nb, uint32_t L, uint32_t B,
+                                                          uint32_t lbits, RecordTables t,
+                                                          unsigned long long *per_cell_sq, Scalars *sc) {
+    constexpr uint32_t SLOTS = 512;
+    __shared__ unsigned long long sq[SLOTS];
+    __shared__ uint32_t blk_start[1025];  // first entry of every cell block (nb <= 1024), and the end
+    __shared__ uint32_t first_cell;
+    const uint32_t per_block = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t d0 = blockIdx.x * per_block, d1 = min(n, d0 + per_block);
+    for (uint32_t i = threadIdx.x; i < SLOTS; i += TPB_REC) sq[i] = 0;
+    for (uint32_t i = threadIdx.x; i <= nb; i += TPB_REC) blk_start[i] = i < nb ? blk_off[(size_t)i * (L + 1)] : n;
+    __syncthreads();
+    auto block_of = [&](uint32_t p) {  // last block whose first entry is <= p (empty blocks share a start)
+        uint32_t lo = 0, hi = nb;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (blk_start[mid] <= p) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    if (threadIdx.x == 0 && d0 < n) first_cell = block_of(d0) * B;
+    __syncthreads();
+    const uint32_t lmask = (1u << lbits) - 1u;
+    for (uint32_t p = d0 + threadIdx.x; p < d1; p += TPB_REC) {
+        const unsigned long long mine = grouped[p];
+        const uint32_t k = (uint32_t)mine, cib = (uint32_t)(mine >> 32) & ((1u << kCibBits) - 1u);
+        const uint32_t l = (uint32_t)(mine >> (32 + kCibBits)) & lmask;
+        const uint32_t blk = block_of(p);
+        const size_t g = (size_t)blk * (L + 1) + l;
+        const uint32_t b = blk_off[g], len = blk_off[g + 1] - b;
+        uint32_t same = 1;
+        if (len > kRankScanLimit) {
+            sc->regroup = 1;
+        } else if (len > 1) {
+            same = 0;
+            for (uint32_t q = b; q < b + len; ++q)
+                same += ((uint32_t)(grouped[q] >> 32) & ((1u << kCibBits) - 1u)) == cib ? 1u : 0u;
+        }
+        const uint32_t cell = blk * B + cib;
+        const uint32_t chr = t.locus_chr[l];
+        emit_record(t, p, k, cib, cell, l, t.locus_rel[l], t.rbeg[chr], t.flushed[chr]);
+        const uint32_t rel = cell - first_cell;
+        if (rel < SLOTS) atomicAdd(&sq[rel], (unsigned long long)same);
+        else atomicAdd(&per_cell_sq[cell], (unsigned long long)same);
+    }
+    __syncthreads();
+    if (d0 < n)
+        for (uint32_t i = threadIdx.x; i < SLOTS; i += TPB_REC)
+            if (sq[i]) atomicAdd(&per_cell_sq[first_cell + i], sq[i]);
+}
+
+// the pair bound (largest per-cell sum of squares), and whether the locus ranges, cut for the count tile
+// before it was known, have to be cut again
+__global__ __launch_bounds__(TPB) void k_pair_bound(const unsigned long long *per_cell_sq, uint32_t n_cells_padded,
+                                                   CapChoice caps, uint32_t assumed_counts, Scalars *sc) {
+    __shared__ unsigned long long s_best[TPB / 64];
+    unsigned long long best = 0;
+    for (uint32_t i = threadIdx.x; i < n_cells_padded; i += TPB) best = max(best, per_cell_sq[i]);
+    for (int off = 32; off > 0; off >>= 1) best = max(best, (unsigned long long)__shfl_down(best, off));
+    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TPB / 64; ++w) best = max(best, s_best[w]);
+        sc->pair_bound = max(sc->pair_bound, best);
+        sc->caps_wrong = (assumed_counts && !caps.counts(sc)) ? 1u : 0u;
+    }
+}
+
+// after the ranges were cut again: the range-relative locus of every entry (bits 16-31 of the compact form)
+__global__ __launch_bounds__(TPB) void k_fix_locus_rel(const uint32_t *blk_off, uint32_t nb, uint32_t L,
+                                                      const uint32_t *locus_rel, uint32_t *entry32) {
+    const uint32_t n_groups = nb * (L + 1);
+    for (uint32_t g = blockIdx.x * TPB + threadIdx.x; g < n_groups; g += gridDim.x * TPB) {
+        const uint32_t b = blk_off[g], e = blk_off[g + 1];
+        if (b == e) continue;
+        const uint32_t lrel = locus_rel[g % (L + 1)] << 16;
+        for (uint32_t d = b; d < e; ++d) entry32[d] = (entry32[d] & 0xFFFFu) | lrel;
     }
 }
 
@@ -1259,6 +1351,10 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     const StageGeometry geo = geometry(block_cells);
     const uint32_t B = block_cells, nb = (num_cells + B - 1) / B;
     const uint32_t lbits = (uint32_t)bits_for(L - 1);
+    if (!force_radix && lbits + kCibBits > 32u) {  // k_bin_place packs the locus into 25 bits at most
+        *retry = kRetryRadix;
+        return std::string();
+    }
     pk.num_cells = num_cells;
     pk.block_cells = B;
     pk.num_blocks = nb;
@@ -1340,28 +1436,59 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             unsigned long long *grouped = key_b;  // the sorted entry keys are dead after k_dup_rule
             hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_kc, blk_off,
                                grouped);
-            hipLaunchKernelGGL(k_bin_rank, dim3(std::min<uint32_t>(1u << 16, (n_kept + 4095) / 4096)), dim3(TPB_RANK), 0,
-                               stream, key2_a, grouped, n_kept, B, L, lbits, blk_off, key2_b, val2_b, per_cell_sq, sc);
         }
     }
     // the locus ranges were cut for both sets of limits on the side stream (after the flush chain): pick
     HIP_OK(hipStreamWaitEvent(stream, pk.ev_join, 0));
     side_join.joined = true;
-    hipLaunchKernelGGL(k_ranges_compact, dim3(1), dim3(TPB), 0, stream, seg_ends, seg_count, variant_stride, n_seg, caps,
-                       pk.range_off.as<uint32_t>(), per_cell_sq, n_kept ? nb * B : 0u, sc);
-    if (n_kept) {
-        hipLaunchKernelGGL(k_locus_info, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, pk.range_off.as<uint32_t>(), sc,
-                           locus_chr, locus_rel);
-        hipLaunchKernelGGL(k_records, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, raw, key2_b, val2_b, n_kept,
-                           t_read, read_off, read_locus, read_base, krank, kflags, rbeg, flushed, locus_chr, locus_rel, B,
-                           lbits, pk.entry.as<uint4>(),
-                           pk.entry32.as<uint32_t>(), pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr,
-                           pk.entry_read.as<uint32_t>());
+    if (force_radix) {
+        hipLaunchKernelGGL(k_ranges_compact, dim3(1), dim3(TPB), 0, stream, seg_ends, seg_count, variant_stride, n_seg,
+                           caps, pk.range_off.as<uint32_t>(), per_cell_sq, n_kept ? nb * B : 0u, -1, sc);
+        if (n_kept) {
+            hipLaunchKernelGGL(k_locus_info, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, pk.range_off.as<uint32_t>(),
+                               sc, locus_chr, locus_rel);
+            hipLaunchKernelGGL(k_records, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, raw, key2_b, val2_b, n_kept,
+                               t_read, read_off, read_locus, read_base, krank, kflags, rbeg, flushed, locus_chr,
+                               locus_rel, B, lbits, pk.entry.as<uint4>(), pk.entry32.as<uint32_t>(),
+                               pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr, pk.entry_read.as<uint32_t>());
+        }
+    } else {
+        // Counting path: the entries stay in k_bin_place's order and one pass, a thread per (block, locus)
+        // group, writes the records and sums the per-cell squares. The locus ranges (their range-relative
+        // locus is part of a record) are cut for the count tile if it is allowed at all; the pair bound comes
+        // out of the same pass, and if it forbids the count tile the ranges are cut again and the records
+        // patched (deep pileups only).
+        const int assumed = caps.allow_counts ? 1 : 0;
+        hipLaunchKernelGGL(k_ranges_compact, dim3(1), dim3(TPB), 0, stream, seg_ends, seg_count, variant_stride, n_seg,
+                           caps, pk.range_off.as<uint32_t>(), per_cell_sq, 0u, assumed, sc);
+        if (n_kept) {
+            hipLaunchKernelGGL(k_locus_info, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, pk.range_off.as<uint32_t>(),
+                               sc, locus_chr, locus_rel);
+            const RecordTables tables{t_read, read_off, read_locus, read_base, krank, kflags, rbeg, flushed, locus_chr,
+                                      locus_rel, pk.entry.as<uint4>(), pk.entry32.as<uint32_t>(),
+                                      pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr, pk.entry_read.as<uint32_t>()};
+            const unsigned long long *grouped = key_b;
+            hipLaunchKernelGGL(k_entry_records, dim3(std::min<uint32_t>(1u << 16, (n_kept + 4095) / 4096)), dim3(TPB_REC),
+                               0, stream, grouped, blk_off, n_kept, nb, L, B, lbits, tables, per_cell_sq, sc);
+        }
+        hipLaunchKernelGGL(k_pair_bound, dim3(1), dim3(TPB), 0, stream, per_cell_sq, n_kept ? nb * B : 0u, caps,
+                           (uint32_t)assumed, sc);
     }
     // read-back 3: errors of the group mapping, pair bound (-> tile variant), number of ranges
     trace.mark("records launched");
     HIP_OK(read_scalars(pk, stream, sc, nullptr, &hsc, nullptr));
     trace.mark("read-back 3 arrived");
+    if (!force_radix && hsc.caps_wrong && !hsc.regroup && hsc.error == 0) {
+        hipLaunchKernelGGL(k_ranges_compact, dim3(1), dim3(TPB), 0, stream, seg_ends, seg_count, variant_stride, n_seg,
+                           caps, pk.range_off.as<uint32_t>(), per_cell_sq, 0u, 0, sc);
+        if (n_kept) {
+            hipLaunchKernelGGL(k_locus_info, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, pk.range_off.as<uint32_t>(),
+                               sc, locus_chr, locus_rel);
+            hipLaunchKernelGGL(k_fix_locus_rel, dim3(blocks_for(n_off)), dim3(TPB), 0, stream, blk_off, nb, L, locus_rel,
+                               pk.entry32.as<uint32_t>());
+        }
+        HIP_OK(read_scalars(pk, stream, sc, nullptr, &hsc, nullptr));  // the number of ranges
+    }
     if (hsc.error == 1) return "group id outside group_id_to_pos";
     if (hsc.error == 2) return "group_id_to_pos maps outside the matrix";
     if (hsc.regroup) {
