@@ -68,6 +68,8 @@ struct Scalars {
     uint32_t id_exceeded;  // the id space is larger than the caller assumed (the size of the previous call)
     uint32_t max_read_entries;  // kept entries of the longest read id run
     uint32_t caps_wrong;        // the locus ranges were cut for the count tile, and the pair bound forbids it
+    uint32_t n_multi_id;        // entries whose read id occurs more than once in its chromosome (k_compact_m)
+    uint32_t reads_total;       // reads of the whole pileup (k_arank_m)
     unsigned long long id_space;  // sum over chromosomes of (largest - smallest read id + 1)
     unsigned long long multi_entries;
     unsigned long long pair_bound;
@@ -365,6 +367,106 @@ __global__ void k_id_rank(Raw in, const uint32_t *dense, const uint32_t *id_off,
     }
 }
 
+constexpr uint32_t kCibBits = 7;
+constexpr uint32_t kNoEntry = 0xFFFFFFFFu;  // low word of an entry_kc slot: the entry was dropped
+
+// ---- the single-entry fast path ---------------------------------------------------------------------
+// With sparse loci nine reads in ten have ONE entry (the id histogram says which), and for those the whole
+// read assembly -- scatter, rank, duplicate rule, per-read lists, per-read info -- is the identity. Only the
+// entries of ids that occur more than once ("M entries") go through it, as a compacted pileup of their own
+// (the kernels below see a Raw whose entry arrays are the compacted copies); the others ("S entries") meet
+// them again at the appearance-rank scan (every S entry is the first and only entry of its read) and at
+// the binning.
+__global__ void k_classify(const uint32_t *dense, const uint32_t *hist, uint32_t n, const Scalars *sc, uint32_t *flags) {
+    const bool void_run = sc->id_exceeded != 0;  // the id table was too small: dense[] was not written
+    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e <= n; e += gridDim.x * TPB)
+        flags[e] = (e < n && !void_run && hist[dense[e]] > 1u) ? 1u : 0u;
+}
+// m_idx = exclusive scan of the flags: entry e is an M entry iff m_idx[e + 1] != m_idx[e]
+__global__ void k_compact_m(Raw in, const uint32_t *eloc, const uint32_t *dense, const uint32_t *m_idx,
+                            uint32_t *m_entry, uint32_t *rid_m, uint32_t *idb_m, uint32_t *eloc_m,
+                            uint32_t *dense_m, Scalars *sc) {
+    const uint32_t n = in.n_entries;
+    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
+        const uint32_t j = m_idx[e];
+        if (m_idx[e + 1] == j) continue;
+        m_entry[j] = e;
+        rid_m[j] = in.read_ids[e];
+        idb_m[j] = in.id_base(e);
+        eloc_m[j] = eloc[e];
+        dense_m[j] = dense[e];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->n_multi_id = m_idx[n];
+}
+struct MultiOnly {  // histogram of the ids that occur more than once (input of the offset scan)
+    const uint32_t *hist;
+    __device__ __forceinline__ uint32_t operator()(uint32_t d) const {
+        const uint32_t h = hist[d];
+        return h > 1u ? h : 0u;
+    }
+};
+// marks in pileup order: an S entry is the first entry of its read; an M entry has its mark from k_dup_mark
+__global__ void k_mark_global(const uint32_t *m_idx, const uint32_t *mark_m, uint32_t n, uint32_t *mark) {
+    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e <= n; e += gridDim.x * TPB) {
+        uint32_t v = 0;
+        if (e < n) {
+            const uint32_t j = m_idx[e];
+            v = m_idx[e + 1] != j ? mark_m[j] : 1u;
+        }
+        mark[e] = v;
+    }
+}
+// appearance ranks of the M entries (k_read_info reads the rank of a read's first entry), the number of reads
+__global__ void k_arank_m(const uint32_t *arank, const uint32_t *m_entry, uint32_t n_m, uint32_t n, uint32_t *arank_m,
+                          Scalars *sc) {
+    for (uint32_t j = blockIdx.x * TPB + threadIdx.x; j < n_m; j += gridDim.x * TPB) arank_m[j] = arank[m_entry[j]];
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->reads_total = arank[n];
+}
+// start positions of the single-entry reads, in appearance order (k_read_info writes those of the others)
+__global__ void k_single_starts(Raw in, const uint32_t *eloc, const uint32_t *m_idx, const uint32_t *arank,
+                                uint32_t mfl, uint32_t *starts_by_rank, Scalars *sc) {
+    const uint32_t n = in.n_entries;
+    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
+        if (m_idx[e + 1] != m_idx[e]) continue;
+        const uint32_t p = in.locus_pos[eloc[e]];
+        starts_by_rank[arank[e]] = p;
+        if ((unsigned long long)p + mfl > 0xFFFFFFFFull) sc->need_host = 1;
+    }
+}
+// per chromosome the first appearance rank
+__global__ void k_rbeg(Raw in, const uint32_t *arank, uint32_t *rbeg) {
+    for (uint32_t c = blockIdx.x * TPB + threadIdx.x; c <= in.n_chr; c += gridDim.x * TPB)
+        rbeg[c] = arank[(uint32_t)in.locus_entry_off[in.chr_locus_off[c]]];
+}
+// the S entries' part of k_keys2: (block, cell, k) in pileup order, appearance rank and base per kept entry;
+// their k follow the kept M entries'
+__global__ void k_single_keys(Raw in, const uint32_t *m_idx, const uint32_t *arank, uint32_t kept_m,
+                              uint32_t num_cells, uint32_t B, uint32_t *krank, uint8_t *kflags,
+                              unsigned long long *entry_kc, Scalars *sc) {
+    const uint32_t n = in.n_entries;
+    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
+        const uint32_t j = m_idx[e];
+        if (m_idx[e + 1] != j) continue;
+        const uint32_t ib = in.id_base(e);
+        const uint32_t group = ib >> 2;
+        uint32_t cell = 0;
+        if (group >= in.n_groups) {
+            sc->error = 1;
+        } else {
+            cell = in.g2p[group];
+            if (cell >= num_cells) {
+                sc->error = 2;
+                cell = 0;
+            }
+        }
+        const uint32_t blk = cell / B, cib = cell - blk * B;
+        const uint32_t k = kept_m + (e - j);
+        krank[k] = arank[e];
+        kflags[k] = (uint8_t)(ib & 3u);
+        entry_kc[e] = ((unsigned long long)((blk << kCibBits) | cib) << 32) | k;
+    }
+}
+
 // Input of the one scan over the sorted order: low word = first entry of a read (head of a run of
 // equal keys), high word = the entry survives the duplicate rule. The inclusive sums give, per
 // position, the 1-based read number and the number of kept entries up to and including it.
@@ -435,7 +537,7 @@ __global__ __launch_bounds__(TPB) void k_read_info(Raw in, const unsigned long l
     __shared__ unsigned long long part[TPB / 64];
     __shared__ uint32_t part_len[TPB / 64];
     const uint32_t n = in.n_entries;
-    const uint32_t n_runs = incl_reads(incl[n - 1]);
+    const uint32_t n_runs = n ? incl_reads(incl[n - 1]) : 0u;
     unsigned long long multi = 0;
     uint32_t longest = 0;
     for (uint32_t r = blockIdx.x * TPB + threadIdx.x; r < n_runs; r += gridDim.x * TPB) {
@@ -455,8 +557,9 @@ __global__ __launch_bounds__(TPB) void k_read_info(Raw in, const unsigned long l
         if (k1 - k0 > 1) multi += k1 - k0;
         longest = max(longest, k1 - k0);
     }
-    for (uint32_t c = blockIdx.x * TPB + threadIdx.x; c <= in.n_chr; c += gridDim.x * TPB) {
-        rbeg[c] = arank[(uint32_t)in.locus_entry_off[in.chr_locus_off[c]]];
+    if (rbeg) {  // (the single-entry fast path has the ranks of all entries elsewhere: k_rbeg)
+        for (uint32_t c = blockIdx.x * TPB + threadIdx.x; c <= in.n_chr; c += gridDim.x * TPB)
+            rbeg[c] = arank[(uint32_t)in.locus_entry_off[in.chr_locus_off[c]]];
     }
     // one atomic per workgroup: same-address atomics are slow
     for (int off = 32; off > 0; off >>= 1) {
@@ -591,8 +694,6 @@ __global__ void k_split_update(Raw in, const unsigned long long *skey, const uin
 
 // The binning key: cell block | locus (lbits bits) | cell in block (7 bits) -- bit fields, so that
 // taking it apart costs shifts instead of 64-bit divisions.
-constexpr uint32_t kCibBits = 7;
-constexpr uint32_t kNoEntry = 0xFFFFFFFFu;  // low word of an entry_kc slot: the entry was dropped
 __device__ __forceinline__ unsigned long long bin_key(uint32_t blk, uint32_t l, uint32_t cib, uint32_t lbits) {
     return ((((unsigned long long)blk << lbits) | l) << kCibBits) | cib;
 }
@@ -605,12 +706,15 @@ __global__ void k_keys2(Raw in, const uint32_t *sval, const unsigned long long *
                         const uint32_t *read_locus, const uint32_t *run_rank, const uint32_t *read_off,
                         uint32_t num_cells, uint32_t B,
                         uint32_t lbits, unsigned long long *key2, uint32_t *val2, uint32_t *t_read,
-                        uint32_t *krank, uint8_t *kflags, unsigned long long *entry_kc, Scalars *sc) {
+                        uint32_t *krank, uint8_t *kflags, unsigned long long *entry_kc, const uint32_t *entry_map,
+                        Scalars *sc) {
+    // entry_map: the pileup entry of a (compacted) entry of `in` (single-entry fast path), or null: itself
     const uint32_t n = in.n_entries;
     for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
         const unsigned long long cur = incl[s], prev = s ? incl[s - 1] : 0ull;
+        const uint32_t e_out = entry_map ? entry_map[sval[s]] : sval[s];
         if (incl_kept(cur) == incl_kept(prev)) {
-            if (entry_kc) entry_kc[sval[s]] = kNoEntry;
+            if (entry_kc) entry_kc[e_out] = kNoEntry;
             continue;
         }
         const uint32_t k = incl_kept(prev);
@@ -626,15 +730,17 @@ __global__ void k_keys2(Raw in, const uint32_t *sval, const unsigned long long *
             }
         }
         const uint32_t blk = cell / B, cib = cell - blk * B;
-        key2[k] = bin_key(blk, read_locus[k], cib, lbits);
-        val2[k] = k;
+        if (key2) {  // the radix path sorts these; the counting path bins through entry_kc
+            key2[k] = bin_key(blk, read_locus[k], cib, lbits);
+            val2[k] = k;
+        }
         const uint32_t r = incl_reads(cur) - 1;
         t_read[k] = r;
         krank[k] = run_rank[r];
         kflags[k] = (uint8_t)((in.id_base(sval[s]) & 3u) | (read_off[r + 1] - read_off[r] > 1u ? 4u : 0u));
         // counting path: back in pileup order, where the entries of a locus are adjacent; one 8-byte
         // scatter per entry carries k and (block, cell in block)
-        if (entry_kc) entry_kc[sval[s]] = ((unsigned long long)((blk << kCibBits) | cib) << 32) | k;
+        if (entry_kc) entry_kc[e_out] = ((unsigned long long)((blk << kCibBits) | cib) << 32) | k;
     }
 }
 
@@ -1114,7 +1220,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     DevicePacked &pk = *out;
     // worst-case block count (64-cell blocks) for buffers sized before the tile size is chosen
     const size_t n_off_max = (size_t)((num_cells + 63) / 64) * ((size_t)L + 1);
-    enum { KEY_A, KEY_B, VAL_A, VAL_B, ELOC, WORK_A, WORK_B, RUNS, CUB, TMP, MISC, BIN, ENTRY_KC };
+    enum { KEY_A, KEY_B, VAL_A, VAL_B, ELOC, WORK_A, WORK_B, RUNS, CUB, TMP, MISC, BIN, ENTRY_KC,
+           M_IDX, M_ENTRY, RID_M, IDB_M, ELOC_M, DENSE_M, MARK_M, ARANK_M };
     auto &S = pk.scratch;
     // the counting scheme for read ids needs a table over the id space
     const size_t id_space_cap = std::min<size_t>((size_t)kIdSpaceFactor * E + 1024, (size_t)1 << 30);
@@ -1203,18 +1310,74 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     HIP_OK(S[WORK_A].ensure(std::max<size_t>((size_t)E + 1, counting ? id_space + 1 : 0) * 4));
     HIP_OK(S[WORK_B].ensure(std::max<size_t>((size_t)2 * E + 2, counting ? id_space + 1 : 0) * 4));
     uint32_t *work_a = S[WORK_A].as<uint32_t>(), *work_b = S[WORK_B].as<uint32_t>();
+    // The single-entry fast path (counting scheme only; SECEDO_PACK_SPLIT=0 turns it off): `sub` is the pileup
+    // the read assembly of stages 1-4 sees -- the whole one, or the compacted entries of the ids that occur more
+    // than once (n_m of them; m_entry maps them back, m_idx is the exclusive scan of their flags).
+    static const bool split_allowed = [] {
+        const char *e = std::getenv("SECEDO_PACK_SPLIT");
+        return !(e && std::atoi(e) == 0);
+    }();
+    const bool split_singles = counting && split_allowed;
+    Raw sub = raw;
+    const uint32_t *sub_eloc = eloc;
+    uint32_t n_m = E;
+    uint32_t *m_idx = nullptr, *m_entry = nullptr;
     if (counting) {
         uint32_t *hist = work_a, *id_off = work_b, *grouped = val_a;
         uint32_t *dense = S[KEY_A].as<uint32_t>();  // the radix path's unsorted keys live here
         HIP_OK(hipMemsetAsync(hist, 0, (id_space + 1) * 4, stream));
         hipLaunchKernelGGL(k_id_hist, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_base, id_negmin, sc,
                            dense, hist);
-        cub_cap = S[CUB].bytes;
-        HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, hist, id_off, (int)(id_space + 1), stream));
-        hipLaunchKernelGGL(k_id_scatter, dim3(blocks_for(E)), dim3(TPB), 0, stream, dense, E, id_off, sc, hist,
-                           grouped);
-        hipLaunchKernelGGL(k_id_rank, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, dense, id_off, grouped, eloc,
-                           key_b, val_b, sloc, sc);
+        if (split_singles) {
+            // the entries of ids that occur more than once, as a compacted pileup of their own (see k_classify)
+            HIP_OK(S[M_IDX].ensure(((size_t)E + 2) * 4));
+            m_idx = S[M_IDX].as<uint32_t>();
+            HIP_OK(S[MARK_M].ensure(((size_t)E + 2) * 4));
+            uint32_t *flags = S[MARK_M].as<uint32_t>();  // the M entries' marks come later (k_dup_mark)
+            hipLaunchKernelGGL(k_classify, dim3(blocks_for(E)), dim3(TPB), 0, stream, dense, hist, E, sc, flags);
+            cub_cap = S[CUB].bytes;
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, flags, m_idx, (int)E + 1, stream));
+            for (int a : {M_ENTRY, RID_M, IDB_M, ELOC_M, DENSE_M, ARANK_M}) HIP_OK(S[a].ensure((size_t)E * 4 + 16));
+            m_entry = S[M_ENTRY].as<uint32_t>();
+            uint32_t *dense_m = S[DENSE_M].as<uint32_t>();
+            hipLaunchKernelGGL(k_compact_m, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, dense, m_idx, m_entry,
+                               S[RID_M].as<uint32_t>(), S[IDB_M].as<uint32_t>(), S[ELOC_M].as<uint32_t>(), dense_m, sc);
+            // read-back 1b: how many entries take the general path (sizes every launch over them)
+            HIP_OK(read_scalars(pk, stream, sc, nullptr, &hsc, nullptr));
+            if (hsc.error == 3) return "positions must be strictly increasing within a chromosome";
+            if (hsc.id_exceeded) {
+                pk.id_space_hint = 0;
+                *retry = kRetrySameScheme;
+                return std::string();
+            }
+            n_m = hsc.n_multi_id;
+            sub = raw;
+            sub.read_ids = S[RID_M].as<uint32_t>();
+            sub.id_base16 = nullptr;
+            sub.id_base32 = S[IDB_M].as<uint32_t>();
+            sub.n_entries = n_m;
+            sub_eloc = S[ELOC_M].as<uint32_t>();
+            cub_cap = S[CUB].bytes;
+            {
+                hipcub::CountingInputIterator<uint32_t> ids(0u);
+                hipcub::TransformInputIterator<uint32_t, MultiOnly, hipcub::CountingInputIterator<uint32_t>> multi_hist(
+                        ids, MultiOnly{hist});
+                HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, multi_hist, id_off, (int)(id_space + 1), stream));
+            }
+            if (n_m) {
+                hipLaunchKernelGGL(k_id_scatter, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, dense_m, n_m, id_off, sc,
+                                   hist, grouped);
+                hipLaunchKernelGGL(k_id_rank, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, dense_m, id_off, grouped,
+                                   sub_eloc, key_b, val_b, sloc, sc);
+            }
+        } else {
+            cub_cap = S[CUB].bytes;
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, hist, id_off, (int)(id_space + 1), stream));
+            hipLaunchKernelGGL(k_id_scatter, dim3(blocks_for(E)), dim3(TPB), 0, stream, dense, E, id_off, sc, hist,
+                               grouped);
+            hipLaunchKernelGGL(k_id_rank, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, dense, id_off, grouped, eloc,
+                               key_b, val_b, sloc, sc);
+        }
     } else {
         const uint32_t id_bits = (uint32_t)bits_for(hsc.max_read_id);
         hipLaunchKernelGGL(k_entry_keys, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_bits, key_a, val_a);
@@ -1258,22 +1421,40 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     // reads from the current `split` flags, then completed counts and the flush chain. The chain is
     // sequential (one lane per chromosome) and only the final gather needs its result: it runs on a
     // side stream, next to the grouping of the kept entries.
+    // (`sub` / n_m: the entries that go through the read assembly -- all of them, or with the single-entry
+    // fast path those of the ids that occur more than once; marks and ranks are always those of the whole pileup)
     auto build_reads = [&]() -> std::string {
-        hipLaunchKernelGGL(k_dup_mark, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sval, sloc, split, E, keep,
-                           mark);
-        {
+        uint32_t *mark_sub = split_singles ? S[MARK_M].as<uint32_t>() : mark;
+        if (n_m) {
+            hipLaunchKernelGGL(k_dup_mark, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, skey, sval, sloc, split, n_m,
+                               keep, mark_sub);
             hipcub::CountingInputIterator<uint32_t> positions(0u);
             hipcub::TransformInputIterator<unsigned long long, HeadKeepOp, hipcub::CountingInputIterator<uint32_t>>
                     flags(positions, HeadKeepOp{skey, keep, split});
             cub_cap = S[CUB].bytes;
-            HIP_OK(hipcub::DeviceScan::InclusiveSum(cub_tmp, cub_cap, flags, incl, (int)E, stream));
+            HIP_OK(hipcub::DeviceScan::InclusiveSum(cub_tmp, cub_cap, flags, incl, (int)n_m, stream));
         }
+        if (split_singles)
+            hipLaunchKernelGGL(k_mark_global, dim3(blocks_for(E)), dim3(TPB), 0, stream, m_idx, mark_sub, E, mark);
         cub_cap = S[CUB].bytes;
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, mark, arank, (int)E + 1, stream));
-        hipLaunchKernelGGL(k_runs_csr, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, incl, sval, sloc, E, run_start,
-                           read_locus, read_base);
-        hipLaunchKernelGGL(k_read_info, dim3(std::min<uint32_t>(blocks_for(E), 2048)), dim3(TPB), 0, stream, raw, incl,
-                           run_start, sval, sloc, arank, mfl, run_rank, starts_by_rank, rbeg, read_off, sc);
+        const uint32_t *arank_sub = arank;
+        if (split_singles) {
+            uint32_t *arank_m = S[ARANK_M].as<uint32_t>();
+            hipLaunchKernelGGL(k_arank_m, dim3(blocks_for(std::max(n_m, 1u))), dim3(TPB), 0, stream, arank, m_entry, n_m,
+                               E, arank_m, sc);
+            arank_sub = arank_m;
+            hipLaunchKernelGGL(k_rbeg, dim3(1), dim3(TPB), 0, stream, raw, arank, rbeg);
+            hipLaunchKernelGGL(k_single_starts, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, m_idx, arank, mfl,
+                               starts_by_rank, sc);
+        }
+        if (n_m) {
+            hipLaunchKernelGGL(k_runs_csr, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, incl, sval, sloc, n_m,
+                               run_start, read_locus, read_base);
+            hipLaunchKernelGGL(k_read_info, dim3(std::min<uint32_t>(blocks_for(n_m), 2048)), dim3(TPB), 0, stream, sub,
+                               incl, run_start, sval, sloc, arank_sub, mfl, run_rank, starts_by_rank,
+                               split_singles ? nullptr : rbeg, read_off, sc);
+        }
         HIP_OK(hipEventRecord(pk.ev_fork, stream));
         HIP_OK(hipStreamWaitEvent(pk.side, pk.ev_fork, 0));
         hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, pk.side, raw, starts_by_rank, rbeg, mfl, cnt);
@@ -1295,7 +1476,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     // read-back 2: status flags, R, number of kept entries, multi-locus statistics
     unsigned long long totals = 0;  // reads | kept entries << 32
     trace.mark("reads built (launched)");
-    HIP_OK(read_scalars(pk, stream, sc, incl + (E - 1), &hsc, &totals));
+    HIP_OK(read_scalars(pk, stream, sc, n_m ? incl + (n_m - 1) : nullptr, &hsc, &totals));
     trace.mark("read-back 2 arrived");
     if (hsc.error == 3) return "positions must be strictly increasing within a chromosome";
     if (hsc.id_exceeded) {
@@ -1318,11 +1499,11 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         // (they move forward with the flushes they cause: a few rounds).
         bool stable = false;
         split = S[TMP].as<uint32_t>();
-        HIP_OK(hipMemsetAsync(split, 0, (size_t)E * 4, stream));
+        HIP_OK(hipMemsetAsync(split, 0, (size_t)std::max(n_m, 1u) * 4, stream));
         for (int round = 0; round < kMaxSplitRounds && !stable; ++round) {
             HIP_OK(hipStreamWaitEvent(stream, pk.ev_join, 0));  // the chain of the previous build
             HIP_OK(hipMemsetAsync(&sc->split_changed, 0, 4, stream));
-            hipLaunchKernelGGL(k_split_update, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, skey, sloc, mfl,
+            hipLaunchKernelGGL(k_split_update, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, skey, sloc, mfl,
                                flush_loci, flush_count, split, sc);
             HIP_OK(read_scalars(pk, stream, sc, nullptr, &hsc, nullptr));
             if (!hsc.split_changed) {
@@ -1332,14 +1513,18 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             HIP_OK(hipMemsetAsync(&sc->multi_entries, 0, 8, stream));  // k_read_info adds to it
             const std::string err = build_reads();
             if (!err.empty()) return err;
-            HIP_OK(read_scalars(pk, stream, sc, incl + (E - 1), &hsc, &totals));
+            HIP_OK(read_scalars(pk, stream, sc, n_m ? incl + (n_m - 1) : nullptr, &hsc, &totals));
         }
         if (!stable) {
             *need_host = true;  // did not settle: the exact sequential emulation decides
             return std::string();
         }
     }
-    const uint32_t R = (uint32_t)totals, n_kept = (uint32_t)(totals >> 32);
+    // (single-entry fast path: `totals` counts the reads and kept entries of the M entries; every S entry is a
+    // read and a kept entry of its own)
+    const uint32_t kept_m = (uint32_t)(totals >> 32);
+    const uint32_t R = split_singles ? hsc.reads_total : (uint32_t)totals;
+    const uint32_t n_kept = split_singles ? kept_m + (E - n_m) : kept_m;
     const size_t nk = std::max<uint32_t>(n_kept, 1);
     pk.multi_entries = hsc.multi_entries;
     pk.max_read_entries = std::max(hsc.max_read_entries, n_kept ? 1u : 0u);
@@ -1406,8 +1591,13 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     // are dead) and base | multi flag (the grouped ids in VAL_A are dead)
     uint32_t *krank = work_a;
     uint8_t *kflags = S[VAL_A].as<uint8_t>();
-    hipLaunchKernelGGL(k_keys2, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, sval, incl, read_locus, run_rank,
-                       read_off, num_cells, B, lbits, key2_a, val2_a, t_read, krank, kflags, entry_kc, sc);
+    if (n_m)
+        hipLaunchKernelGGL(k_keys2, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, sval, incl, read_locus, run_rank,
+                           read_off, num_cells, B, lbits, force_radix ? key2_a : nullptr, force_radix ? val2_a : nullptr,
+                           t_read, krank, kflags, entry_kc, split_singles ? m_entry : nullptr, sc);
+    if (split_singles)
+        hipLaunchKernelGGL(k_single_keys, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, m_idx, arank, kept_m, num_cells,
+                           B, krank, kflags, entry_kc, sc);
     trace.mark("k_keys2 launched");
     const uint32_t slice_grid = std::min<uint32_t>(2048, (n_kept + 4095) / 4096);
     if (force_radix) {
