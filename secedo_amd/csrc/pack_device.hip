@@ -35,6 +35,7 @@ DevicePacked::~DevicePacked() {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_offsets) (void)hipEventDestroy(ev_offsets);
+    if (ev_counts) (void)hipEventDestroy(ev_counts);
     if (mailbox) (void)hipHostFree(mailbox);
 }
 
@@ -194,16 +195,6 @@ __device__ __forceinline__ uint32_t last_le(const T *a, uint32_t n, T x) {
     while (hi - lo > 1) {
         const uint32_t mid = lo + (hi - lo) / 2;
         if (a[mid] <= x) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-// number of elements <= x in a non-decreasing array
-__device__ __forceinline__ uint32_t count_le(const uint32_t *a, uint32_t n, uint32_t x) {
-    uint32_t lo = 0, hi = n;  // answer in [lo, hi]
-    while (lo < hi) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if (a[mid] <= x) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
@@ -377,11 +368,15 @@ constexpr uint32_t kNoEntry = 0xFFFFFFFFu;  // low word of an entry_kc slot: the
 // (the kernels below see a Raw whose entry arrays are the compacted copies); the others ("S entries") meet
 // them again at the appearance-rank scan (every S entry is the first and only entry of its read) and at
 // the binning.
-__global__ void k_classify(const uint32_t *dense, const uint32_t *hist, uint32_t n, const Scalars *sc, uint32_t *flags) {
-    const bool void_run = sc->id_exceeded != 0;  // the id table was too small: dense[] was not written
-    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e <= n; e += gridDim.x * TPB)
-        flags[e] = (e < n && !void_run && hist[dense[e]] > 1u) ? 1u : 0u;
-}
+struct IsMultiId {  // input of the scan that numbers the M entries: 1 where the entry's id occurs again
+    const uint32_t *dense, *hist;
+    uint32_t n;
+    const Scalars *sc;
+    __device__ __forceinline__ uint32_t operator()(uint32_t e) const {
+        // (sc->id_exceeded: the id table was too small and dense[] was not written; the attempt is void)
+        return (e < n && sc->id_exceeded == 0u && hist[dense[e]] > 1u) ? 1u : 0u;
+    }
+};
 // m_idx = exclusive scan of the flags: entry e is an M entry iff m_idx[e + 1] != m_idx[e]
 __global__ void k_compact_m(Raw in, const uint32_t *eloc, const uint32_t *dense, const uint32_t *m_idx,
                             uint32_t *m_entry, uint32_t *rid_m, uint32_t *idb_m, uint32_t *eloc_m,
@@ -405,33 +400,22 @@ struct MultiOnly {  // histogram of the ids that occur more than once (input of 
         return h > 1u ? h : 0u;
     }
 };
-// marks in pileup order: an S entry is the first entry of its read; an M entry has its mark from k_dup_mark
-__global__ void k_mark_global(const uint32_t *m_idx, const uint32_t *mark_m, uint32_t n, uint32_t *mark) {
-    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e <= n; e += gridDim.x * TPB) {
-        uint32_t v = 0;
-        if (e < n) {
-            const uint32_t j = m_idx[e];
-            v = m_idx[e + 1] != j ? mark_m[j] : 1u;
-        }
-        mark[e] = v;
+// marks in pileup order (input of the appearance-rank scan): an S entry is the first entry of its read; an
+// M entry has its mark from k_dup_mark
+struct MarkOf {
+    const uint32_t *m_idx, *mark_m;
+    uint32_t n;
+    __device__ __forceinline__ uint32_t operator()(uint32_t e) const {
+        if (e >= n) return 0u;
+        const uint32_t j = m_idx[e];
+        return m_idx[e + 1] != j ? mark_m[j] : 1u;
     }
-}
+};
 // appearance ranks of the M entries (k_read_info reads the rank of a read's first entry), the number of reads
 __global__ void k_arank_m(const uint32_t *arank, const uint32_t *m_entry, uint32_t n_m, uint32_t n, uint32_t *arank_m,
                           Scalars *sc) {
     for (uint32_t j = blockIdx.x * TPB + threadIdx.x; j < n_m; j += gridDim.x * TPB) arank_m[j] = arank[m_entry[j]];
     if (blockIdx.x == 0 && threadIdx.x == 0) sc->reads_total = arank[n];
-}
-// start positions of the single-entry reads, in appearance order (k_read_info writes those of the others)
-__global__ void k_single_starts(Raw in, const uint32_t *eloc, const uint32_t *m_idx, const uint32_t *arank,
-                                uint32_t mfl, uint32_t *starts_by_rank, Scalars *sc) {
-    const uint32_t n = in.n_entries;
-    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
-        if (m_idx[e + 1] != m_idx[e]) continue;
-        const uint32_t p = in.locus_pos[eloc[e]];
-        starts_by_rank[arank[e]] = p;
-        if ((unsigned long long)p + mfl > 0xFFFFFFFFull) sc->need_host = 1;
-    }
 }
 // per chromosome the first appearance rank
 __global__ void k_rbeg(Raw in, const uint32_t *arank, uint32_t *rbeg) {
@@ -532,8 +516,7 @@ __global__ void k_runs_csr(Raw in, const unsigned long long *incl, const uint32_
 __global__ __launch_bounds__(TPB) void k_read_info(Raw in, const unsigned long long *incl, const uint32_t *run_start,
                                                   const uint32_t *sval, const uint32_t *sloc,
                                                   const uint32_t *arank, uint32_t mfl, uint32_t *run_rank,
-                                                  uint32_t *starts_by_rank, uint32_t *rbeg, uint32_t *read_off,
-                                                  Scalars *sc) {
+                                                  uint32_t *rbeg, uint32_t *read_off, Scalars *sc) {
     __shared__ unsigned long long part[TPB / 64];
     __shared__ uint32_t part_len[TPB / 64];
     const uint32_t n = in.n_entries;
@@ -550,7 +533,6 @@ __global__ __launch_bounds__(TPB) void k_read_info(Raw in, const unsigned long l
         if ((unsigned long long)p1 + mfl > 0xFFFFFFFFull) sc->need_host = 1;
         const uint32_t rk = arank[e0];
         run_rank[r] = rk;
-        starts_by_rank[rk] = p0;
         const uint32_t k0 = s0 ? incl_kept(incl[s0 - 1]) : 0u, k1 = incl_kept(incl[s1 - 1]);
         read_off[r] = k0;
         if (r == n_runs - 1) read_off[n_runs] = k1;
@@ -583,13 +565,23 @@ __global__ __launch_bounds__(TPB) void k_read_info(Raw in, const unsigned long l
     }
 }
 
-// completed-prefix count per locus (:348-352): reads of the chromosome with start + mfl <= position
-__global__ void k_completed(Raw in, const uint32_t *starts_by_rank, const uint32_t *rbeg, uint32_t mfl,
-                            uint32_t *cnt) {
+// completed-prefix count per locus (:348-352): reads of the chromosome with start + mfl <= position. A read
+// starts at the position of its first entry, and `arank` counts the first entries in pileup order, so the
+// reads that started at or before a locus are the ranks up to the end of that locus: a search over the
+// chromosome's positions instead of a table of start positions per read.
+__global__ void k_completed(Raw in, const uint32_t *arank, const uint32_t *rbeg, uint32_t mfl, uint32_t *cnt,
+                            Scalars *sc) {
     for (uint32_t l = blockIdx.x * TPB + threadIdx.x; l < in.n_loci; l += gridDim.x * TPB) {
         const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
-        const uint32_t pos = in.locus_pos[l];
-        cnt[l] = pos < mfl ? 0u : count_le(starts_by_rank + rbeg[c], rbeg[c + 1] - rbeg[c], pos - mfl);
+        const uint32_t pos = in.locus_pos[l], l0 = in.chr_locus_off[c];
+        if ((unsigned long long)pos + mfl > 0xFFFFFFFFull && in.locus_entry_off[l + 1] > in.locus_entry_off[l])
+            sc->need_host = 1;  // start + mfl leaves 32 bits (the reference computes in uint32 there)
+        uint32_t done = 0;
+        if (pos >= mfl && in.locus_pos[l0] <= pos - mfl) {
+            const uint32_t lp = l0 + last_le<uint32_t>(in.locus_pos + l0, l - l0 + 1, pos - mfl);
+            done = arank[(uint32_t)in.locus_entry_off[lp + 1]] - rbeg[c];
+        }
+        cnt[l] = done;
     }
 }
 
@@ -1333,10 +1325,13 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             HIP_OK(S[M_IDX].ensure(((size_t)E + 2) * 4));
             m_idx = S[M_IDX].as<uint32_t>();
             HIP_OK(S[MARK_M].ensure(((size_t)E + 2) * 4));
-            uint32_t *flags = S[MARK_M].as<uint32_t>();  // the M entries' marks come later (k_dup_mark)
-            hipLaunchKernelGGL(k_classify, dim3(blocks_for(E)), dim3(TPB), 0, stream, dense, hist, E, sc, flags);
-            cub_cap = S[CUB].bytes;
-            HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, flags, m_idx, (int)E + 1, stream));
+            {
+                hipcub::CountingInputIterator<uint32_t> entries(0u);
+                hipcub::TransformInputIterator<uint32_t, IsMultiId, hipcub::CountingInputIterator<uint32_t>> flags(
+                        entries, IsMultiId{dense, hist, E, sc});
+                cub_cap = S[CUB].bytes;
+                HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, flags, m_idx, (int)E + 1, stream));
+            }
             for (int a : {M_ENTRY, RID_M, IDB_M, ELOC_M, DENSE_M, ARANK_M}) HIP_OK(S[a].ensure((size_t)E * 4 + 16));
             m_entry = S[M_ENTRY].as<uint32_t>();
             uint32_t *dense_m = S[DENSE_M].as<uint32_t>();
@@ -1397,7 +1392,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *mark = S[KEY_A].as<uint32_t>();  // the unsorted keys / dense ids are dead
     uint32_t *arank = mark + (E + 1);
     uint32_t *run_start = S[RUNS].as<uint32_t>();
-    uint32_t *run_rank = run_start + E + 1, *starts_by_rank = run_rank + E;
+    uint32_t *run_rank = run_start + E + 1;
     // cuts of reads that outlive max_fragment_length: none on the first build (null), later the flags of
     // k_split_update in TMP, which is free until k_keys2 writes the read index per kept entry there
     uint32_t *split = nullptr;
@@ -1417,6 +1412,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         HIP_OK(hipEventCreateWithFlags(&pk.ev_fork, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&pk.ev_join, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&pk.ev_offsets, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&pk.ev_counts, hipEventDisableTiming));
     }
     // reads from the current `split` flags, then completed counts and the flush chain. The chain is
     // sequential (one lane per chromosome) and only the final gather needs its result: it runs on a
@@ -1434,10 +1430,15 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             cub_cap = S[CUB].bytes;
             HIP_OK(hipcub::DeviceScan::InclusiveSum(cub_tmp, cub_cap, flags, incl, (int)n_m, stream));
         }
-        if (split_singles)
-            hipLaunchKernelGGL(k_mark_global, dim3(blocks_for(E)), dim3(TPB), 0, stream, m_idx, mark_sub, E, mark);
         cub_cap = S[CUB].bytes;
-        HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, mark, arank, (int)E + 1, stream));
+        if (split_singles) {
+            hipcub::CountingInputIterator<uint32_t> entries(0u);
+            hipcub::TransformInputIterator<uint32_t, MarkOf, hipcub::CountingInputIterator<uint32_t>> marks(
+                    entries, MarkOf{m_idx, mark_sub, E});
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, marks, arank, (int)E + 1, stream));
+        } else {
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, mark, arank, (int)E + 1, stream));
+        }
         const uint32_t *arank_sub = arank;
         if (split_singles) {
             uint32_t *arank_m = S[ARANK_M].as<uint32_t>();
@@ -1445,19 +1446,18 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
                                E, arank_m, sc);
             arank_sub = arank_m;
             hipLaunchKernelGGL(k_rbeg, dim3(1), dim3(TPB), 0, stream, raw, arank, rbeg);
-            hipLaunchKernelGGL(k_single_starts, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, m_idx, arank, mfl,
-                               starts_by_rank, sc);
         }
         if (n_m) {
             hipLaunchKernelGGL(k_runs_csr, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, incl, sval, sloc, n_m,
                                run_start, read_locus, read_base);
             hipLaunchKernelGGL(k_read_info, dim3(std::min<uint32_t>(blocks_for(n_m), 2048)), dim3(TPB), 0, stream, sub,
-                               incl, run_start, sval, sloc, arank_sub, mfl, run_rank, starts_by_rank,
-                               split_singles ? nullptr : rbeg, read_off, sc);
+                               incl, run_start, sval, sloc, arank_sub, mfl, run_rank, split_singles ? nullptr : rbeg,
+                               read_off, sc);
         }
         HIP_OK(hipEventRecord(pk.ev_fork, stream));
         HIP_OK(hipStreamWaitEvent(pk.side, pk.ev_fork, 0));
-        hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, pk.side, raw, starts_by_rank, rbeg, mfl, cnt);
+        hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, pk.side, raw, arank, rbeg, mfl, cnt, sc);
+        HIP_OK(hipEventRecord(pk.ev_counts, pk.side));  // the ranks' buffer is recycled in stage 5
         hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, pk.side, raw, cnt, 4u * num_threads, sc, flushed,
                            flush_loci, flush_count);
         HIP_OK(hipEventRecord(pk.ev_join, pk.side));
@@ -1585,6 +1585,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         HIP_OK(hipEventRecord(pk.ev_join, pk.side));
         return std::string();
     };
+    HIP_OK(hipStreamWaitEvent(stream, pk.ev_counts, 0));  // k_completed (side stream) has read the ranks
     if (force_radix) HIP_OK(hipMemsetAsync(blk_cnt, 0, (n_off + 1) * 4, stream));
     HIP_OK(hipMemsetAsync(per_cell_sq, 0, ((size_t)nb * B + 1) * 8, stream));
     // per kept entry what k_records needs of its read: appearance rank (the duplicate-rule flags in WORK_A
