@@ -35,7 +35,7 @@ DevicePacked::~DevicePacked() {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_offsets) (void)hipEventDestroy(ev_offsets);
-    if (ev_counts) (void)hipEventDestroy(ev_counts);
+    if (ev_flush) (void)hipEventDestroy(ev_flush);
     if (mailbox) (void)hipHostFree(mailbox);
 }
 
@@ -360,6 +360,12 @@ __global__ void k_id_rank(Raw in, const uint32_t *dense, const uint32_t *id_off,
 
 constexpr uint32_t kCibBits = 7;
 constexpr uint32_t kNoEntry = 0xFFFFFFFFu;  // low word of an entry_kc slot: the entry was dropped
+// Single-entry fast path: an S entry (the only entry of its read) needs no k -- nothing of its read is looked
+// up again -- so the low word of its entry_kc slot carries kSingle | appearance rank and its base sits above
+// (block, cell in block) in the high word; k_bin_place turns the rank into the tail flag.
+constexpr uint32_t kSingle = 0x80000000u;
+constexpr uint32_t kSingleBaseShift = 29;  // in the high word of entry_kc (block << 7 | cell in block below)
+constexpr uint32_t kSingleTail = 4u;       // in the low word of a grouped S entry: kSingle | tail | base
 
 // ---- the single-entry fast path ---------------------------------------------------------------------
 // With sparse loci nine reads in ten have ONE entry (the id histogram says which), and for those the whole
@@ -422,35 +428,6 @@ __global__ void k_rbeg(Raw in, const uint32_t *arank, uint32_t *rbeg) {
     for (uint32_t c = blockIdx.x * TPB + threadIdx.x; c <= in.n_chr; c += gridDim.x * TPB)
         rbeg[c] = arank[(uint32_t)in.locus_entry_off[in.chr_locus_off[c]]];
 }
-// the S entries' part of k_keys2: (block, cell, k) in pileup order, appearance rank and base per kept entry;
-// their k follow the kept M entries'
-__global__ void k_single_keys(Raw in, const uint32_t *m_idx, const uint32_t *arank, uint32_t kept_m,
-                              uint32_t num_cells, uint32_t B, uint32_t *krank, uint8_t *kflags,
-                              unsigned long long *entry_kc, Scalars *sc) {
-    const uint32_t n = in.n_entries;
-    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
-        const uint32_t j = m_idx[e];
-        if (m_idx[e + 1] != j) continue;
-        const uint32_t ib = in.id_base(e);
-        const uint32_t group = ib >> 2;
-        uint32_t cell = 0;
-        if (group >= in.n_groups) {
-            sc->error = 1;
-        } else {
-            cell = in.g2p[group];
-            if (cell >= num_cells) {
-                sc->error = 2;
-                cell = 0;
-            }
-        }
-        const uint32_t blk = cell / B, cib = cell - blk * B;
-        const uint32_t k = kept_m + (e - j);
-        krank[k] = arank[e];
-        kflags[k] = (uint8_t)(ib & 3u);
-        entry_kc[e] = ((unsigned long long)((blk << kCibBits) | cib) << 32) | k;
-    }
-}
-
 // Input of the one scan over the sorted order: low word = first entry of a read (head of a run of
 // equal keys), high word = the entry survives the duplicate rule. The inclusive sums give, per
 // position, the 1-based read number and the number of kept entries up to and including it.
@@ -740,8 +717,12 @@ __global__ void k_keys2(Raw in, const uint32_t *sval, const unsigned long long *
 // pileup, so one wave per locus counts them per cell block in LDS and writes the locus' column of
 // the (block, locus) histogram with plain stores -- global atomics would all hit the handful of
 // addresses of the loci in flight.
-__global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, const unsigned long long *entry_kc,
-                                                 uint32_t *blk_cnt) {
+// Single-entry fast path (m_idx != null): the S entries' slots are made here -- (block, cell) from the group
+// map, validated as k_keys2 does for the M entries -- since this is the first pass over the pileup order
+// after the appearance ranks exist.
+__global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, unsigned long long *entry_kc,
+                                                 const uint32_t *m_idx, const uint32_t *arank, uint32_t num_cells,
+                                                 uint32_t B, uint32_t *blk_cnt, Scalars *sc) {
     extern __shared__ uint32_t lds_hist[];
     uint32_t *hist = lds_hist + (threadIdx.x >> 6) * nb;
     const uint32_t lane = threadIdx.x & 63u, L = in.n_loci;
@@ -752,6 +733,25 @@ __global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, const uns
         __builtin_amdgcn_wave_barrier();
         const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
         for (uint32_t e = e0 + lane; e < e1; e += 64u) {
+            if (m_idx && m_idx[e + 1] == m_idx[e]) {
+                const uint32_t ib = in.id_base(e);
+                const uint32_t group = ib >> 2;
+                uint32_t cell = 0;
+                if (group >= in.n_groups) {
+                    sc->error = 1;
+                } else {
+                    cell = in.g2p[group];
+                    if (cell >= num_cells) {
+                        sc->error = 2;
+                        cell = 0;
+                    }
+                }
+                const uint32_t blk = cell / B, cib = cell - blk * B;
+                entry_kc[e] = ((unsigned long long)(((ib & 3u) << kSingleBaseShift) | (blk << kCibBits) | cib) << 32)
+                        | kSingle | arank[e];
+                atomicAdd(&hist[blk], 1u);
+                continue;
+            }
             const unsigned long long kc = entry_kc[e];
             if ((uint32_t)kc != kNoEntry) atomicAdd(&hist[(uint32_t)(kc >> 32) >> kCibBits], 1u);
         }
@@ -768,8 +768,8 @@ __global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, const uns
 // ... and places them: position = group offset + LDS cursor (arbitrary order inside the group).
 // grouped[pos] = cell-in-block << 32 | k, the final order inside a group being (cell, k)
 __global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, const unsigned long long *entry_kc,
-                                                  const uint32_t *blk_off,
-                                                  unsigned long long *grouped) {
+                                                  const uint32_t *blk_off, const uint32_t *rbeg,
+                                                  const uint32_t *flushed, unsigned long long *grouped) {
     extern __shared__ uint32_t lds_hist[];
     uint32_t *cursor = lds_hist + (threadIdx.x >> 6) * nb;
     const uint32_t lane = threadIdx.x & 63u, L = in.n_loci;
@@ -779,11 +779,17 @@ __global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, const un
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
+        const uint32_t chr = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
+        const uint32_t rb = rbeg[chr], fl_chr = flushed[chr];
         for (uint32_t e = e0 + lane; e < e1; e += 64u) {
             const unsigned long long kc = entry_kc[e];
-            const uint32_t k = (uint32_t)kc;
+            uint32_t k = (uint32_t)kc;
             if (k == kNoEntry) continue;
-            const uint32_t cc = (uint32_t)(kc >> 32);
+            uint32_t cc = (uint32_t)(kc >> 32);
+            if (k & kSingle) {  // rank -> tail flag (as emit_record tests it for an M entry); base beside it
+                k = kSingle | ((k & ~kSingle) - rb >= fl_chr ? kSingleTail : 0u) | (cc >> kSingleBaseShift);
+                cc &= (1u << kSingleBaseShift) - 1u;
+            }
             const uint32_t pos = atomicAdd(&cursor[cc >> kCibBits], 1u);
             // cell in block | locus << 7 above k (k_entry_records; the radix path never comes here)
             grouped[pos] = ((unsigned long long)((cc & ((1u << kCibBits) - 1u)) | (l << kCibBits)) << 32) | k;
@@ -1059,10 +1065,17 @@ struct RecordTables {  // by value: what a record needs beside the group's own e
 
 __device__ __forceinline__ void emit_record(const RecordTables &t, uint32_t d, uint32_t k, uint32_t cib, uint32_t cell,
                                             uint32_t l, uint32_t lrel, uint32_t rb, uint32_t fl_chr) {
-    const uint32_t fl = t.kflags[k];
-    const uint32_t base = fl & 3u;
-    const bool multi = (fl & 4u) != 0u;
-    const bool tail = t.krank[k] - rb >= fl_chr;
+    uint32_t base;
+    bool multi = false, tail;
+    if (k & kSingle) {  // single-entry fast path: all there is to know came along (k_bin_place)
+        base = k & 3u;
+        tail = (k & kSingleTail) != 0u;
+    } else {
+        const uint32_t fl = t.kflags[k];
+        base = fl & 3u;
+        multi = (fl & 4u) != 0u;
+        tail = t.krank[k] - rb >= fl_chr;
+    }
     // the read's list of kept entries: only a multi-locus read has neighbours to look for
     uint32_t r = 0, lo = k, hi = k + 1;
     if (multi) {
@@ -1235,7 +1248,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *locus_chr = cnt + L, *locus_rel = locus_chr + L;
     uint32_t *flush_loci = locus_rel + L, *flush_count = flush_loci + L;
     // KEY_A: sort keys in, later mark[E+1] | arank[E+1], later the per-(block, locus) counts
-    HIP_OK(S[KEY_A].ensure(std::max<size_t>({(size_t)E * 8, ((size_t)2 * E + 4) * 4, (n_off_max + 1) * 4})));
+    // (marks and appearance ranks, 2 (E + 1) words, with the (block, locus) counts behind them: the ranks are
+    // still read when the counts are written, k_bin_hist)
+    HIP_OK(S[KEY_A].ensure(std::max<size_t>((size_t)E * 8, ((size_t)2 * E + 4 + n_off_max + 1) * 4)));
     // KEY_B: sorted keys, later (counting path) the kept entries grouped by (block, locus)
     HIP_OK(S[KEY_B].ensure((size_t)E * 8));
     HIP_OK(S[VAL_A].ensure((size_t)E * 4));
@@ -1412,7 +1427,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         HIP_OK(hipEventCreateWithFlags(&pk.ev_fork, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&pk.ev_join, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&pk.ev_offsets, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&pk.ev_counts, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&pk.ev_flush, hipEventDisableTiming));
     }
     // reads from the current `split` flags, then completed counts and the flush chain. The chain is
     // sequential (one lane per chromosome) and only the final gather needs its result: it runs on a
@@ -1457,9 +1472,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         HIP_OK(hipEventRecord(pk.ev_fork, stream));
         HIP_OK(hipStreamWaitEvent(pk.side, pk.ev_fork, 0));
         hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, pk.side, raw, arank, rbeg, mfl, cnt, sc);
-        HIP_OK(hipEventRecord(pk.ev_counts, pk.side));  // the ranks' buffer is recycled in stage 5
         hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, pk.side, raw, cnt, 4u * num_threads, sc, flushed,
                            flush_loci, flush_count);
+        HIP_OK(hipEventRecord(pk.ev_flush, pk.side));
         HIP_OK(hipEventRecord(pk.ev_join, pk.side));
         return std::string();
     };
@@ -1536,7 +1551,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     const StageGeometry geo = geometry(block_cells);
     const uint32_t B = block_cells, nb = (num_cells + B - 1) / B;
     const uint32_t lbits = (uint32_t)bits_for(L - 1);
-    if (!force_radix && lbits + kCibBits > 32u) {  // k_bin_place packs the locus into 25 bits at most
+    // k_bin_place packs the locus into 25 bits at most, and bit 31 of a k marks an S entry
+    if (!force_radix && (lbits + kCibBits > 32u || E >= kSingle)) {
         *retry = kRetryRadix;
         return std::string();
     }
@@ -1557,7 +1573,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *val2_b = val2_a + nk;
     const size_t n_off = (size_t)nb * ((size_t)L + 1);
     uint32_t *blk_off = pk.blk_off.as<uint32_t>();
-    uint32_t *blk_cnt = S[KEY_A].as<uint32_t>();  // mark / arank are dead after k_ranks
+    uint32_t *blk_cnt = S[KEY_A].as<uint32_t>() + 2 * ((size_t)E + 1);  // behind the marks and ranks
     // counting path: per pileup entry its k and cell (entry -> locus and the per-read scratch are dead)
     unsigned long long *entry_kc = force_radix ? nullptr : S[ENTRY_KC].as<unsigned long long>();
     // The pair bound decides the tile variant, and the tile variant the staging limits of the locus ranges;
@@ -1585,7 +1601,6 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         HIP_OK(hipEventRecord(pk.ev_join, pk.side));
         return std::string();
     };
-    HIP_OK(hipStreamWaitEvent(stream, pk.ev_counts, 0));  // k_completed (side stream) has read the ranks
     if (force_radix) HIP_OK(hipMemsetAsync(blk_cnt, 0, (n_off + 1) * 4, stream));
     HIP_OK(hipMemsetAsync(per_cell_sq, 0, ((size_t)nb * B + 1) * 8, stream));
     // per kept entry what k_records needs of its read: appearance rank (the duplicate-rule flags in WORK_A
@@ -1596,9 +1611,6 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         hipLaunchKernelGGL(k_keys2, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, sval, incl, read_locus, run_rank,
                            read_off, num_cells, B, lbits, force_radix ? key2_a : nullptr, force_radix ? val2_a : nullptr,
                            t_read, krank, kflags, entry_kc, split_singles ? m_entry : nullptr, sc);
-    if (split_singles)
-        hipLaunchKernelGGL(k_single_keys, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, m_idx, arank, kept_m, num_cells,
-                           B, krank, kflags, entry_kc, sc);
     trace.mark("k_keys2 launched");
     const uint32_t slice_grid = std::min<uint32_t>(2048, (n_kept + 4095) / 4096);
     if (force_radix) {
@@ -1616,7 +1628,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     } else {
         const uint32_t locus_grid = std::min<uint32_t>(blocks_for((uint64_t)L * 64), 8192);
         const size_t lds = (size_t)(TPB / 64) * nb * 4;
-        hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_kc, blk_cnt);
+        hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_kc,
+                           split_singles ? m_idx : nullptr, arank, num_cells, B, blk_cnt, sc);
         trace.mark("k_bin_hist launched");
         cub_cap = S[CUB].bytes;
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
@@ -1625,8 +1638,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         if (!err.empty()) return err;
         if (n_kept) {
             unsigned long long *grouped = key_b;  // the sorted entry keys are dead after k_dup_rule
-            hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_kc, blk_off,
-                               grouped);
+            HIP_OK(hipStreamWaitEvent(stream, pk.ev_flush, 0));  // the S entries' tail flags
+            hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_kc, blk_off, rbeg,
+                               flushed, grouped);
         }
     }
     // the locus ranges were cut for both sets of limits on the side stream (after the flush chain): pick

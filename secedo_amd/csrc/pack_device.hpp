@@ -55,7 +55,7 @@ struct DevicePacked {
     // side stream for the branch of the pipeline nothing else waits for until the final gather
     // (completed counts + flush chain); created on first use
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_offsets = nullptr, ev_counts = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_offsets = nullptr, ev_flush = nullptr;
     // pinned host words the packing's scalar read-backs arrive in (polled; see read_scalars)
     void *mailbox = nullptr;
     unsigned long long mailbox_seq = 0;
