@@ -91,9 +91,8 @@ struct secedo_simmat {
     uint32_t num_tiles = 0;
     DevBuf tile_row, tile_col, lut, counters, max_bits, slow_args, slab, plan_wg_tile, plan_wg_begin;
     uint32_t plan_tile_begin = 0xFFFFFFFFu, plan_tile_end = 0, plan_ranges = 0, plan_blocks = 0, plan_workgroups = 0;
-    DevBuf flag_cnt, flag_cur, flag_off, flag_idx, unit_off, unit_locus, tile_sel;  // sparse-loci path: flagged entries
+    DevBuf flag_tmp, flag_pre, flag_rec, flag_idx;  // sparse-loci path: the flagged entries, compact
     bool flags_ready = false;                                 // ... of the current packed pileup
-    uint64_t tile_sel_hash = 0;
     DevBuf own_acc, own_out;  // used by the one-shot entry point only
     DevBuf tile_ids;          // tile list of accumulate_list / max_of_tiles
     std::vector<uint16_t> host_tile_row, host_tile_col;
@@ -110,7 +109,7 @@ struct secedo_simmat {
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timed = false;
-    secedo::SideStream side;  // correct_flagged beside accumulate_counts (created on first use)
+    secedo::SideStream side;  // the flagged entries' lists are built beside accumulate_counts (created on first use)
 };
 
 namespace {
@@ -462,7 +461,6 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
     h->prepared = true;
     h->timed = false;
     h->flags_ready = false;
-    h->tile_sel_hash = 0;
     return SECEDO_OK;
 }
 
@@ -492,7 +490,6 @@ int secedo_simmat_zero_acc(secedo_simmat_t *h, int64_t *d_acc, void *stream) {
     return SECEDO_OK;
 }
 
-static uint64_t nl_units(const secedo_simmat_t *h) { return (uint64_t)h->pk.num_loci + 1; }
 
 // tiles [tile_begin, tile_end) when list == nullptr, else the n_list tiles of `list` (global indices)
 static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double theta, uint32_t tile_begin,
@@ -663,51 +660,10 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
     a.counters = h->counters.as<unsigned long long>();
 
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, 96 * sizeof(unsigned long long), s));
-    if (h->pk.count_tile && !h->pk.stage_masks && secedo::counts_path_enabled()) {
-        // accumulate_counts + correct_flagged: the per-locus lists of flagged entries, once per prepare
-        if (!h->flags_ready) {
-            const size_t nl = (size_t)h->pk.num_loci + 1;
-            HIP_TRY(h->flag_cnt.ensure(nl * 4));
-            HIP_TRY(h->flag_cur.ensure(nl * 4));
-            HIP_TRY(h->flag_off.ensure(nl * 4));
-            HIP_TRY(h->flag_idx.ensure(std::max<size_t>(h->pk.num_entries, 1) * 4));
-            HIP_TRY(h->unit_off.ensure(nl * 4));
-            HIP_TRY(h->unit_locus.ensure((h->pk.num_entries / 64 + nl) * 4));
-            HIP_TRY(secedo::build_flagged_lists(a.entry32, a.entry, (uint32_t)h->pk.num_entries, h->pk.num_loci,
-                                                h->flag_cnt.as<uint32_t>(), h->flag_cur.as<uint32_t>(),
-                                                h->flag_off.as<uint32_t>(), h->flag_idx.as<uint32_t>(),
-                                                h->unit_off.as<uint32_t>(), h->unit_locus.as<uint32_t>(), s));
-            h->flags_ready = true;
-        }
-        a.flag_off = h->flag_off.as<uint32_t>();
-        a.flag_idx = h->flag_idx.as<uint32_t>();
-        a.unit_off = h->unit_off.as<uint32_t>();
-        a.unit_locus = h->unit_locus.as<uint32_t>();
-        a.unit_bound = (uint32_t)std::min<uint64_t>(h->pk.num_entries / 64 + nl_units(h), 0xFFFFFFFFull);
-        a.num_blocks = h->pk.num_blocks;
-        a.tile_end = tile_end;
-        {
-            const double per_block_locus = h->pk.num_loci && h->pk.num_blocks
-                    ? (double)h->pk.num_entries / h->pk.num_loci / h->pk.num_blocks : 0.0;
-            a.sparse_blocks = per_block_locus < 2.5;
-        }
-        if (list) {  // a launch over a tile list: one flag per tile
-            if (h->tile_sel_hash != list_hash || !h->tile_sel.p) {
-                std::vector<uint8_t> sel(std::max<uint32_t>(h->num_tiles, 1), 0);
-                for (uint32_t k = 0; k < n_list; ++k) sel[list[k]] = 1;
-                HIP_TRY(h->tile_sel.upload(sel));
-                h->tile_sel_hash = list_hash;
-            }
-            a.tile_selected = h->tile_sel.as<uint8_t>();
-        }
-    }
-    HIP_TRY(hipEventRecord(h->ev_begin, s));
-    // 16-bit pair counters per cell pair are safe when no cell pair can collect 65536 pairs
-    const bool count_tile = h->pk.count_tile;
-    HIP_TRY(h->slab.ensure(secedo::accumulate_slab_bytes(h->pk.block_cells, count_tile, a.n_workgroups)));
-    a.slab = h->slab.p;
     const secedo::SideStream *side = nullptr;
-    if (a.flag_off) {  // the sparse-loci path: its correction kernel runs beside the pair kernel
+    if (h->pk.count_tile && !h->pk.stage_masks && secedo::counts_path_enabled()) {
+        // accumulate_counts + correct_tiles. The compact list of flagged entries, once per prepare, is read by
+        // the second kernel only: it is built on a stream of the handle's own while the pair kernel runs
         static const bool serial = [] {
             const char *e = std::getenv("SECEDO_CORRECT_SERIAL");
             return e && std::atoi(e) != 0;
@@ -720,7 +676,42 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
             }
             side = &h->side;
         }
+        if (!h->flags_ready) {
+            const uint32_t ne = (uint32_t)h->pk.num_entries;
+            const size_t scan_bytes = secedo::flagged_scan_bytes(ne);
+            HIP_TRY(h->flag_tmp.ensure(std::max<size_t>(scan_bytes, 16)));
+            HIP_TRY(h->flag_pre.ensure(((size_t)ne + 1) * 4));
+            HIP_TRY(h->flag_rec.ensure(std::max<size_t>(ne, 1) * 16));
+            HIP_TRY(h->flag_idx.ensure(std::max<size_t>(ne, 1) * 4));
+            hipStream_t list_stream = s;
+            if (side) {
+                HIP_TRY(hipEventRecord(side->fork, s));
+                HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+                list_stream = side->stream;
+            }
+            HIP_TRY(secedo::build_flagged_lists(a.entry32, a.entry, ne, h->flag_tmp.p, h->flag_tmp.bytes,
+                                                h->flag_pre.as<uint32_t>(), h->flag_rec.as<uint4>(),
+                                                h->flag_idx.as<uint32_t>(), list_stream));
+            if (side) {
+                HIP_TRY(hipEventRecord(side->join, side->stream));
+                if (n_tiles == 0) HIP_TRY(hipStreamWaitEvent(s, side->join, 0));  // nothing below waits for it
+            }
+            h->flags_ready = true;
+        }
+        a.flag_pre = h->flag_pre.as<uint32_t>();
+        a.flag_rec = h->flag_rec.as<uint4>();
+        a.flag_idx = h->flag_idx.as<uint32_t>();
+        {
+            const double per_block_locus = h->pk.num_loci && h->pk.num_blocks
+                    ? (double)h->pk.num_entries / h->pk.num_loci / h->pk.num_blocks : 0.0;
+            a.sparse_blocks = per_block_locus < 2.5;
+        }
     }
+    HIP_TRY(hipEventRecord(h->ev_begin, s));
+    // 16-bit pair counters per cell pair are safe when no cell pair can collect 65536 pairs
+    const bool count_tile = h->pk.count_tile;
+    HIP_TRY(h->slab.ensure(secedo::accumulate_slab_bytes(h->pk.block_cells, count_tile, a.n_workgroups)));
+    a.slab = h->slab.p;
     HIP_TRY(secedo::launch_accumulate(a, h->pk.block_cells, h->pk.stage_masks, count_tile, n_tiles, s, side));
     HIP_TRY(hipEventRecord(h->ev_end, s));
     h->timed = true;
@@ -846,6 +837,13 @@ int secedo_simmat_last_counts(secedo_simmat_t *h, uint64_t *updates, uint64_t *r
     if (std::getenv("SECEDO_STAMPS_PRINT")) {  // diagnostic builds (-DSECEDO_STAMPS) only
         unsigned long long st[16] = {0};
         HIP_TRY(hipMemcpy(st, h->counters.p, sizeof(st), hipMemcpyDeviceToHost));
+        if (std::getenv("SECEDO_STAMPS_COUNTS")) {  // correct_tiles (-DSECEDO_STAMPS)
+            unsigned long long cf[4] = {0};
+            HIP_TRY(hipMemcpy(cf, h->counters.as<unsigned long long>() + 82, sizeof(cf), hipMemcpyDeviceToHost));
+            if (cf[0])
+                std::fprintf(stderr, "[stamps-correct] pair tests %llu, tail terms %llu, joint terms %llu, later-locus pairs %llu\n",
+                             cf[0], cf[1], cf[2], cf[3]);
+        }
         if (st[8] && std::getenv("SECEDO_STAMPS_COUNTS")) {  // accumulate_counts (-DSECEDO_STAMPS)
             const double w = (double)st[8];
             std::fprintf(stderr, "[stamps-counts] sampled waves %llu | per wave cycles: total %.0f barrier-A %.0f stage+barrier-B %.0f "

@@ -12,6 +12,7 @@
 #include "simmat_kernels.hpp"
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdlib>
@@ -1064,26 +1065,32 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
     }
 }
 
-// ---- the flagged entries of every locus (tail: the read was never flushed; multi: the read has further
-// kept entries), as per-locus lists of entry indices: count, (scan on the host side of the launch), fill
-__global__ __launch_bounds__(256) void flagged_count(const uint32_t *entry32, const uint4 *entry, uint32_t n,
-                                                    uint32_t *cnt) {
-    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < n; g += gridDim.x * 256)
-        if (entry32[g] & (C_TAIL | C_MULTI)) atomicAdd(&cnt[entry[g].w], 1u);
-}
-__global__ __launch_bounds__(256) void flagged_fill(const uint32_t *entry32, const uint4 *entry, uint32_t n,
-                                                   const uint32_t *off, uint32_t *cursor, uint32_t *idx) {
-    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < n; g += gridDim.x * 256)
-        if (entry32[g] & (C_TAIL | C_MULTI)) {
-            const uint32_t l = entry[g].w;
-            idx[off[l] + atomicAdd(&cursor[l], 1u)] = g;
+// ---- the flagged entries (tail: the read was never flushed; multi: the read has further kept entries), compacted
+// in the order of the packed entries, i.e. by (cell block, locus): pre[d] = flagged entries before entry d, so
+// the flagged entries of the group (b, l) are [pre[blk_off[b][l]], pre[blk_off[b][l + 1]]) of the compact list
+struct FlaggedOp {  // input of the prefix sum
+    const uint32_t *entry32;
+    uint32_t n;
+    __device__ __forceinline__ uint32_t operator()(uint32_t d) const {
+        return (d < n && (entry32[d] & (C_TAIL | C_MULTI)) != 0u) ? 1u : 0u;
+    }
+};
+__global__ __launch_bounds__(256) void flagged_compact(const uint32_t *entry32, const uint4 *entry, uint32_t n,
+                                                      const uint32_t *pre, uint4 *rec, uint32_t *idx) {
+    for (uint32_t d = blockIdx.x * 256 + threadIdx.x; d < n; d += gridDim.x * 256)
+        if (entry32[d] & (C_TAIL | C_MULTI)) {
+            const uint32_t i = pre[d];
+            rec[i] = entry[d];
+            idx[i] = d;
         }
 }
 
-// x_s, x_d over all loci two multi-locus reads share, if `locus` (the locus of both entries) is the first
-// one they share; false if an earlier locus owns the pair. The logic of pair_value_full / slow_pair.
-__device__ __forceinline__ bool joint_counts(const SlowPathArgs *sp, const uint4 A1, const uint4 A2, uint32_t g1,
-                                             uint32_t g2, uint32_t *xs_out, uint32_t *xd_out) {
+// x_s, x_d over all loci two multi-locus reads share, if the locus of both entries is the first one they
+// share; false if an earlier locus owns the pair. The logic of pair_value_full / slow_pair. i1, i2: the
+// entries' places in the compact list (their entry indices are looked up only on the slow path).
+__device__ __forceinline__ bool joint_counts(const SlowPathArgs *sp, const uint32_t *flag_idx, const uint4 A1,
+                                             const uint4 A2, uint32_t i1, uint32_t i2, uint32_t *xs_out,
+                                             uint32_t *xd_out) {
     if (A1.y & A2.y & 0xFFFFu) return false;  // they share an earlier locus
     const bool same = (((A1.x ^ A2.x) >> 16) & 3u) == 0u;
     if ((A1.x & A2.x & (META_PREV_OVF | META_NEXT_OVF)) == 0u) {
@@ -1096,20 +1103,20 @@ __device__ __forceinline__ bool joint_counts(const SlowPathArgs *sp, const uint4
         return true;
     }
     // a 16-locus window overflowed on the same side for both reads: merge-walk their entry lists
-    const uint32_t r1 = sp->entry_read[g1], r2 = sp->entry_read[g2];
-    uint32_t i1 = sp->read_off[r1], e1 = sp->read_off[r1 + 1];
-    uint32_t i2 = sp->read_off[r2], e2 = sp->read_off[r2 + 1];
+    const uint32_t r1 = sp->entry_read[flag_idx[i1]], r2 = sp->entry_read[flag_idx[i2]];
+    uint32_t j1 = sp->read_off[r1], e1 = sp->read_off[r1 + 1];
+    uint32_t j2 = sp->read_off[r2], e2 = sp->read_off[r2 + 1];
     uint32_t xs = 0, xd = 0, first = 0xFFFFFFFFu;
-    while (i1 < e1 && i2 < e2) {
-        const uint32_t l1 = sp->read_locus[i1], l2 = sp->read_locus[i2];
+    while (j1 < e1 && j2 < e2) {
+        const uint32_t l1 = sp->read_locus[j1], l2 = sp->read_locus[j2];
         if (l1 == l2) {
             if (first == 0xFFFFFFFFu) first = l1;
-            if (sp->read_base[i1] == sp->read_base[i2]) ++xs; else ++xd;
-            ++i1; ++i2;
+            if (sp->read_base[j1] == sp->read_base[j2]) ++xs; else ++xd;
+            ++j1; ++j2;
         } else if (l1 < l2) {
-            ++i1;
+            ++j1;
         } else {
-            ++i2;
+            ++j2;
         }
     }
     *xs_out = xs;
@@ -1118,136 +1125,156 @@ __device__ __forceinline__ bool joint_counts(const SlowPathArgs *sp, const uint4
 }
 
 struct CorrectArgs {
-    const uint32_t *flag_off;  // num_loci + 1
-    const uint32_t *flag_idx;  // entry indices, grouped by locus
-    const uint32_t *unit_off;  // num_loci + 1: first work unit of each locus (a unit = 64 entries q of one locus)
-    const uint32_t *unit_locus;  // unit -> locus
-    uint32_t num_loci;
-    const uint4 *entry;
+    const uint32_t *blk_off;   // num_blocks * stride (the packed pileup's group offsets)
+    uint32_t stride;           // num_loci + 1
+    const uint32_t *flag_pre;  // entries + 1
+    const uint4 *flag_rec;     // the flagged entries' records, compact
+    const uint32_t *flag_idx;  // ... and entry indices
     const SlowPathArgs *slow;
     const long long *lut;
-    uint32_t block_cells, num_blocks;
-    uint32_t tile_begin, tile_end;  // tiles of this launch ...
-    const uint8_t *tile_selected;   // ... or, when non-null, one flag per tile
+    const uint16_t *tile_row, *tile_col;
+    uint32_t tile_begin;       // tiles of this launch: [tile_begin, tile_begin + gridDim.x) ...
+    const uint32_t *tile_ids;  // ... or, when non-null, by global index
+    const void *slab;          // accumulate_counts' count tiles, one per workgroup of its launch
+    const uint32_t *tile_wg_begin;
     int64_t *acc;
     unsigned long long *counters;
 };
 
-// Every pair of flagged entries of a locus that belongs to two different matrix rows and to a tile of this
-// launch.
-//   both tail            -> the plain term accumulate_counts added is taken out, so is its update
-//   both multi-locus     -> not the first shared locus: one read pair less (the incidence stays an update);
-//                           first shared locus and n = x_s + x_d >= 2: + D(x_s,x_d) - x_s D(1,0) - x_d D(0,1)
-// A wave takes work units (grid-stride): 64 entries q of one locus -- a lane each, in registers -- against
-// all entries p < q of that locus, which pass through registers 64 at a time and are broadcast with
-// v_readlane (no LDS, one HBM latency per 64 p). Units, not loci, because the corrections are scattered
-// 8-byte atomics, which one CU issues at about one wave-instruction per microsecond: the loci where two
-// nearby informative sites make hundreds of reads multi-locus must be spread over many CUs.
-__global__ __launch_bounds__(256) void correct_flagged(const CorrectArgs a) {
-    const uint32_t n_units = a.unit_off[a.num_loci];
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = gridDim.x * 4;
-    const uint32_t B = a.block_cells, nb = a.num_blocks;
+// One workgroup per tile (I, J) of the launch, after accumulate_counts. Two things in one pass over the tile:
+//
+// 1. What the flags mean. Every pair of flagged entries of one locus, one in cell block I and one in J, of
+//    two different matrix rows:
+//      both tail            -> the plain term accumulate_counts added is taken out, so is its update
+//      both multi-locus     -> not the first shared locus: one read pair less (the incidence stays an update);
+//                              first shared locus and n = x_s + x_d >= 2: + D(x_s,x_d) - x_s D(1,0) - x_d D(0,1)
+//    A thread takes a flagged entry p of block I and walks the flagged entries q of the same locus in block J
+//    (in a diagonal tile those behind p: every pair once); the terms are added into an int64 tile in LDS.
+//    (Round 2 first did this per locus with one scattered 8-byte global atomic per term -- 23 million of them
+//    on C3, at the ~2e10 per second the memory side serves chip-wide: 1.2 ms, and beside the pair kernel it
+//    cost that kernel 0.8 ms. In LDS the same terms are a few tens of microseconds per tile.)
+// 2. reduce_slabs: the count tiles of the tile's accumulate_counts workgroups, converted with the two
+//    single-locus ratios (exact integer arithmetic), plus the LDS tile, added to acc[tile] with plain coalesced
+//    read-modify-writes: nothing else touches the tile during the launch.
+template <int B, int THREADS>
+__global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
+    extern __shared__ unsigned long long corr[];  // B * B
+    __shared__ long long part[2 * (THREADS / 64)];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t t_local = blockIdx.x;
+    const uint32_t t = a.tile_ids ? a.tile_ids[t_local] : a.tile_begin + t_local;
+    const uint32_t I = a.tile_row[t], J = a.tile_col[t];
+    const bool diag = I == J;
+    for (uint32_t i = tid; i < (uint32_t)(B * B); i += THREADS) corr[i] = 0ull;
+    __syncthreads();
     const long long d10 = a.lut[1 * LUT_DIM + 0], d01 = a.lut[0 * LUT_DIM + 1];
     long long upd_delta = 0, pair_delta = 0;  // per lane
-    for (uint32_t u = wave; u < n_units; u += n_waves) {
-        const uint32_t l = a.unit_locus[u];
-        const uint32_t f0 = a.flag_off[l], m = a.flag_off[l + 1] - f0;
-        const uint32_t qb = (u - a.unit_off[l]) * 64u, q = qb + lane;
-        uint32_t g2 = 0;
-        uint4 A2 = make_uint4(0, 0, 0, 0);
-        if (q < m) {
-            g2 = a.flag_idx[f0 + q];
-            A2 = a.entry[g2];
-        }
-        const uint32_t row2 = A2.x & 0xFFFFu, b2 = row2 / B;
-        const bool multi2 = A2.y != 0u || (A2.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
-        const uint32_t p_all = min(m, qb + 64u);  // p < q <= qb + 63
-        for (uint32_t pb = 0; pb < p_all; pb += 64u) {
-            uint32_t gp = g2;
-            uint4 Ap = A2;
-            if (pb != qb) {  // (the last chunk of p is the unit's own entries)
-                gp = 0;
-                Ap = make_uint4(0, 0, 0, 0);
-                if (pb + lane < m) {
-                    gp = a.flag_idx[f0 + pb + lane];
-                    Ap = a.entry[gp];
-                }
+#ifdef SECEDO_STAMPS
+    unsigned long long dg_tests = 0, dg_tail = 0, dg_joint = 0, dg_later = 0;
+#endif
+    const size_t rowI = (size_t)I * a.stride, rowJ = (size_t)J * a.stride;
+    const uint32_t p0 = a.flag_pre[a.blk_off[rowI]], p1 = a.flag_pre[a.blk_off[rowI + a.stride - 1u]];
+    for (uint32_t p = p0 + tid; p < p1; p += THREADS) {
+        const uint4 A1 = a.flag_rec[p];
+        const size_t g = rowJ + A1.w;
+        const uint32_t c0 = a.blk_off[g], c1 = a.blk_off[g + 1];
+        if (c0 == c1) continue;
+        uint32_t q = a.flag_pre[c0];
+        const uint32_t q1 = a.flag_pre[c1];
+        if (diag) q = p + 1u;  // p lies in [pre[c0], pre[c1]) itself
+        const uint32_t row1 = (A1.x & 0xFFFFu) - I * B;
+        const bool multi1 = A1.y != 0u || (A1.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
+        for (; q < q1; ++q) {
+            const uint4 A2 = a.flag_rec[q];
+            const uint32_t row2 = (A2.x & 0xFFFFu) - J * B;
+            if (diag && row1 == row2) continue;  // same cell (:215)
+#ifdef SECEDO_STAMPS
+            ++dg_tests;
+#endif
+            const bool tails = (A1.x & A2.x & (1u << 18)) != 0u;  // both never flushed: no pair at all
+            const bool multi2 = A2.y != 0u || (A2.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
+            if (!tails && !(multi1 && multi2)) continue;
+            // (inside a diagonal tile either orientation is read back: the finalize kernels add both)
+            unsigned long long *cell = &corr[row1 * B + row2];
+            const bool same = (((A1.x ^ A2.x) >> 16) & 3u) == 0u;
+            if (tails) {
+                atomicAdd(cell, (unsigned long long)(-(same ? d10 : d01)));
+                --upd_delta;
+                --pair_delta;
+#ifdef SECEDO_STAMPS
+                ++dg_tail;
+#endif
+                continue;
             }
-            const uint32_t np = min(64u, p_all - pb);
-            for (uint32_t k = 0; k < np; ++k) {
-                const uint32_t p = pb + k;
-                const uint4 A1 = make_uint4(__builtin_amdgcn_readlane(Ap.x, k), __builtin_amdgcn_readlane(Ap.y, k),
-                                            __builtin_amdgcn_readlane(Ap.z, k), __builtin_amdgcn_readlane(Ap.w, k));
-                const uint32_t g1 = __builtin_amdgcn_readlane(gp, k);
-                if (q >= m || q <= p) continue;
-                const uint32_t row1 = A1.x & 0xFFFFu;
-                if (row1 == row2) continue;  // same cell (:215)
-                const bool tails = (A1.x & A2.x & (1u << 18)) != 0u;  // both never flushed: no pair at all
-                const bool multi1 = A1.y != 0u || (A1.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
-                if (!tails && !(multi1 && multi2)) continue;
-                // the tile of the pair: row block <= column block; inside a diagonal tile either orientation
-                // is read back (the finalize kernels add both)
-                const uint32_t b1 = row1 / B;
-                const uint32_t bI = min(b1, b2), bJ = max(b1, b2);
-                const uint32_t t = bI * nb - bI * (bI - 1u) / 2u + (bJ - bI);
-                if (a.tile_selected ? a.tile_selected[t] == 0 : (t < a.tile_begin || t >= a.tile_end)) continue;
-                const uint32_t rI = b1 <= b2 ? row1 : row2, rJ = b1 <= b2 ? row2 : row1;
-                unsigned long long *cell = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B
-                        + (rI - bI * B) * B + (rJ - bJ * B);
-                const bool same = (((A1.x ^ A2.x) >> 16) & 3u) == 0u;
-                if (tails) {
-                    atomicAdd(cell, (unsigned long long)(-(same ? d10 : d01)));
-                    --upd_delta;
-                    --pair_delta;
-                    continue;
-                }
-                uint32_t xs = 0, xd = 0;
-                // (the order of the two entries does not matter to joint_counts)
-                if (!joint_counts(a.slow, A1, A2, g1, g2, &xs, &xd)) {
-                    --pair_delta;  // counted at their first shared locus
-                    continue;
-                }
-                if (xs + xd < 2u) continue;  // this locus only: the plain term is the whole term
-                const long long joint = (xs < (uint32_t)LUT_DIM && xd < (uint32_t)LUT_DIM)
-                        ? a.lut[xs * LUT_DIM + xd] : llr_fixed_device(a.slow, xs, xd);
-                atomicAdd(cell, (unsigned long long)(joint - (long long)xs * d10 - (long long)xd * d01));
+            uint32_t xs = 0, xd = 0;
+            // (the order of the two entries does not matter to joint_counts)
+            if (!joint_counts(a.slow, a.flag_idx, A1, A2, p, q, &xs, &xd)) {
+                --pair_delta;  // counted at their first shared locus
+#ifdef SECEDO_STAMPS
+                ++dg_later;
+#endif
+                continue;
             }
+            if (xs + xd < 2u) continue;  // this locus only: the plain term is the whole term
+            const long long joint = (xs < (uint32_t)LUT_DIM && xd < (uint32_t)LUT_DIM)
+                    ? a.lut[xs * LUT_DIM + xd] : llr_fixed_device(a.slow, xs, xd);
+            atomicAdd(cell, (unsigned long long)(joint - (long long)xs * d10 - (long long)xd * d01));
+#ifdef SECEDO_STAMPS
+            ++dg_joint;
+#endif
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
         upd_delta += __shfl_down(upd_delta, off);
         pair_delta += __shfl_down(pair_delta, off);
     }
-    __shared__ long long part[8];
     if (lane == 0u) {
-        part[wv * 2] = upd_delta;
-        part[wv * 2 + 1] = pair_delta;
+        part[(tid >> 6) * 2] = upd_delta;
+        part[(tid >> 6) * 2 + 1] = pair_delta;
     }
+#ifdef SECEDO_STAMPS
+    for (int off = 32; off > 0; off >>= 1) {
+        dg_tests += __shfl_down(dg_tests, off);
+        dg_tail += __shfl_down(dg_tail, off);
+        dg_joint += __shfl_down(dg_joint, off);
+        dg_later += __shfl_down(dg_later, off);
+    }
+    if (lane == 0u) {
+        atomicAdd(&a.counters[82], dg_tests);
+        atomicAdd(&a.counters[83], dg_tail);
+        atomicAdd(&a.counters[84], dg_joint);
+        atomicAdd(&a.counters[85], dg_later);
+    }
+#endif
     __syncthreads();
-    if (threadIdx.x == 0u) {
-        const long long u = part[0] + part[2] + part[4] + part[6], q = part[1] + part[3] + part[5] + part[7];
+    if (tid == 0u) {
+        long long u = 0, q = 0;
+        for (int w = 0; w < THREADS / 64; ++w) {
+            u += part[2 * w];
+            q += part[2 * w + 1];
+        }
         if (u) atomicAdd(&a.counters[0], (unsigned long long)u);
         if (q) atomicAdd(&a.counters[1], (unsigned long long)q);
     }
-}
-
-// work units of correct_flagged: ceil(flagged entries / 64) per locus with at least two flagged entries
-__global__ __launch_bounds__(256) void flagged_units(const uint32_t *flag_off, uint32_t n_loci, uint32_t *units) {
-    for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l <= n_loci; l += gridDim.x * 256) {
-        const uint32_t m = l < n_loci ? flag_off[l + 1] - flag_off[l] : 0u;
-        units[l] = m < 2u ? 0u : (m + 63u) / 64u;
+    // the count tiles of the pair kernel's workgroups of this tile + the corrections -> acc
+    const uint32_t w0 = a.tile_wg_begin[t_local], w1 = a.tile_wg_begin[t_local + 1];
+    long long *dst = reinterpret_cast<long long *>(a.acc) + (size_t)t * B * B;
+    for (uint32_t c = tid; c < (uint32_t)(B * B); c += THREADS) {
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(a.slab) + c;
+        uint32_t n_same = 0, n_diff = 0;
+        for (uint32_t w = w0; w < w1; ++w) {
+            const uint32_t v = s[(size_t)w * B * B];
+            n_same += v & 0xFFFFu;
+            n_diff += v >> 16;
+        }
+        const long long sum = (long long)n_same * d10 + (long long)n_diff * d01 + (long long)corr[c];
+        if (sum) dst[c] += sum;
     }
-}
-__global__ __launch_bounds__(256) void flagged_unit_loci(const uint32_t *unit_off, uint32_t n_loci, uint32_t *unit_locus) {
-    for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < n_loci; l += gridDim.x * 256)
-        for (uint32_t u = unit_off[l]; u < unit_off[l + 1]; ++u) unit_locus[u] = l;
 }
 
 // acc[tile] += sum over the tile's workgroups of their slab (count slabs are converted with the two
 // single-locus ratios: exact integer arithmetic). One thread per cell pair of a tile.
-// ATOMIC: the sum is added with an atomic (correct_flagged may be adding to the same cells on another stream)
-template <int B, bool COUNTS, bool ATOMIC = false>
+template <int B, bool COUNTS>
 __global__ __launch_bounds__(256) void reduce_slabs(const void *slab, const uint32_t *tile_wg_begin,
                                                    uint32_t tile_begin, const uint32_t *tile_ids,
                                                    const long long *lut, long long *acc) {
@@ -1270,10 +1297,7 @@ __global__ __launch_bounds__(256) void reduce_slabs(const void *slab, const uint
         for (uint32_t w = w0; w < w1; ++w) sum += p[(size_t)w * B * B];
     }
     long long *dst = &acc[(size_t)(tile_ids ? tile_ids[t_local] : tile_begin + t_local) * B * B + cell];
-    if (sum) {
-        if (ATOMIC) atomicAdd(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)sum);
-        else *dst += sum;
-    }
+    if (sum) *dst += sum;
 }
 
 // max over i < j of D[i][j], clamped at 0 (the diagonal is zero): bits of a non-negative double
@@ -1388,39 +1412,6 @@ hipError_t launch_acc(const AccumulateArgs &args, uint32_t grid, hipStream_t str
     return hipGetLastError();
 }
 
-// exclusive prefix sum of n words by one workgroup (n is a number of loci: a few hundred thousand), in tiles
-// of 4096 words: coalesced 16-byte loads, wave scans with DPP, the running total carried in a register
-__global__ __launch_bounds__(1024) void scan_exclusive_1wg(const uint32_t *in, uint32_t *out, uint32_t n) {
-    __shared__ uint32_t wsum[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < n; base += 4096u) {
-        const uint32_t i0 = base + tid * 4u;
-        uint32_t v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = i0 + k < n ? in[i0 + k] : 0u;
-        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
-        const uint32_t incl = wave_inclusive_scan(mine);
-        if (lane == 63u) wsum[wv] = incl;
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const uint32_t s = wsum[w];
-            if ((uint32_t)w < wv) before += s;
-            total += s;
-        }
-        uint32_t run = carry + before + incl - mine;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (i0 + k < n) out[i0 + k] = run;
-            run += v[k];
-        }
-        carry += total;
-        __syncthreads();
-    }
-}
-
 template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
 hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t stream, const SideStream *side) {
     constexpr size_t lds = ((size_t)B * (B + 1) * 4 + 15) / 16 * 16 + (size_t)CAPJ * 2 + ((size_t)CAPL + 2) * 2
@@ -1438,44 +1429,39 @@ hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t 
         if (e != hipSuccess) return e;
         configured_device = dev;
     }
-    // What the flags of the reads mean, per locus over the flagged entries only. Its scattered 8-byte atomics
-    // are bound by the memory side (about 2e10 per second chip-wide), not by the CUs: it runs beside the pair
-    // kernel on a second stream when the caller has one (the pair kernel leaves half the wave slots and a
-    // third of the LDS of every CU free).
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
+    // What the flags of the reads mean, and the count tiles' way into the accumulator: one workgroup per tile.
+    // The flagged entries' lists may still be in the making on the side stream (build_flagged_lists).
+    if (side && side->stream) {
+        if ((e = hipStreamWaitEvent(stream, side->join, 0)) != hipSuccess) return e;
+    }
     CorrectArgs c;
-    c.flag_off = args.flag_off;
+    c.blk_off = args.blk_off;
+    c.stride = args.stride;
+    c.flag_pre = args.flag_pre;
+    c.flag_rec = args.flag_rec;
     c.flag_idx = args.flag_idx;
-    c.unit_off = args.unit_off;
-    c.unit_locus = args.unit_locus;
-    c.num_loci = args.stride - 1u;
-    c.entry = args.entry;
     c.slow = args.slow;
     c.lut = args.lut;
-    c.block_cells = B;
-    c.num_blocks = args.num_blocks;
+    c.tile_row = args.tile_row;
+    c.tile_col = args.tile_col;
     c.tile_begin = args.tile_begin;
-    c.tile_end = args.tile_end;
-    c.tile_selected = args.tile_selected;
+    c.tile_ids = args.tile_ids;
+    c.slab = args.slab;
+    c.tile_wg_begin = args.tile_wg_begin;
     c.acc = args.acc;
     c.counters = args.counters;
-    // (an upper bound of the number of units is known without a read-back: one per 64 entries plus one per locus)
-    const uint32_t blocks = std::max(1u, std::min((args.unit_bound + 3u) / 4u, 256u * 8u));
-    const bool beside = side && side->stream;
-    if (beside) {
-        if ((e = hipEventRecord(side->fork, stream)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
-        hipLaunchKernelGGL(correct_flagged, dim3(blocks), dim3(256), 0, side->stream, c);
-        if ((e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
+    constexpr int CT = B == 128 ? 1024 : 256;
+    constexpr size_t corr_lds = (size_t)B * B * 8;
+    auto corr = &correct_tiles<B, CT>;
+    static thread_local int corr_device = -1;
+    if (corr_device != dev) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(corr), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)corr_lds);
+        if (e != hipSuccess) return e;
+        corr_device = dev;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
-    hipLaunchKernelGGL((reduce_slabs<B, true, true>), dim3(args.n_tiles * (B * B / 256)), dim3(256), 0, stream,
-                       args.slab, args.tile_wg_begin, args.tile_begin, args.tile_ids, args.lut,
-                       reinterpret_cast<long long *>(args.acc));
-    if (beside) {
-        if ((e = hipStreamWaitEvent(stream, side->join, 0)) != hipSuccess) return e;
-    } else {
-        hipLaunchKernelGGL(correct_flagged, dim3(blocks), dim3(256), 0, stream, c);
-    }
+    hipLaunchKernelGGL(corr, dim3(args.n_tiles), dim3(CT), corr_lds, stream, c);
     return hipGetLastError();
 }
 
@@ -1491,25 +1477,26 @@ int pair_mode() {
 
 bool counts_path_enabled() { return pair_mode() != 0; }
 
-hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint32_t n_entries, uint32_t n_loci,
-                               uint32_t *cnt, uint32_t *cursor, uint32_t *off, uint32_t *idx, uint32_t *unit_off,
-                               uint32_t *unit_locus, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(cnt, 0, ((size_t)n_loci + 1) * 4, stream);
+size_t flagged_scan_bytes(uint32_t n_entries) {
+    size_t bytes = 0;
+    hipcub::CountingInputIterator<uint32_t> ids(0u);
+    hipcub::TransformInputIterator<uint32_t, FlaggedOp, hipcub::CountingInputIterator<uint32_t>> in(
+            ids, FlaggedOp{nullptr, 0});
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, static_cast<uint32_t *>(nullptr), (int)n_entries + 1);
+    return bytes;
+}
+
+hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint32_t n_entries, void *scan_tmp,
+                               size_t scan_tmp_bytes, uint32_t *pre, uint4 *rec, uint32_t *idx, hipStream_t stream) {
+    hipcub::CountingInputIterator<uint32_t> ids(0u);
+    hipcub::TransformInputIterator<uint32_t, FlaggedOp, hipcub::CountingInputIterator<uint32_t>> in(
+            ids, FlaggedOp{entry32, n_entries});
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_tmp_bytes, in, pre, (int)n_entries + 1, stream);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(cursor, 0, ((size_t)n_loci + 1) * 4, stream);
-    if (e != hipSuccess) return e;
-    const uint32_t blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>(((size_t)n_entries + 255) / 256, 256 * 16));
-    if (n_entries)
-        hipLaunchKernelGGL(flagged_count, dim3(blocks), dim3(256), 0, stream, entry32, entry, n_entries, cnt);
-    hipLaunchKernelGGL(scan_exclusive_1wg, dim3(1), dim3(1024), 0, stream, cnt, off, n_loci + 1u);
-    if (n_entries)
-        hipLaunchKernelGGL(flagged_fill, dim3(blocks), dim3(256), 0, stream, entry32, entry, n_entries, off, cursor,
-                           idx);
-    // work units of correct_flagged (cnt is free again: the units per locus, then their prefix)
-    const uint32_t lblocks = std::max(1u, std::min((n_loci + 256u) / 256u, 256u * 8u));
-    hipLaunchKernelGGL(flagged_units, dim3(lblocks), dim3(256), 0, stream, off, n_loci, cnt);
-    hipLaunchKernelGGL(scan_exclusive_1wg, dim3(1), dim3(1024), 0, stream, cnt, unit_off, n_loci + 1u);
-    hipLaunchKernelGGL(flagged_unit_loci, dim3(lblocks), dim3(256), 0, stream, unit_off, n_loci, unit_locus);
+    if (n_entries) {
+        const uint32_t blocks = (uint32_t)std::min<size_t>(((size_t)n_entries + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(flagged_compact, dim3(blocks), dim3(256), 0, stream, entry32, entry, n_entries, pre, rec, idx);
+    }
     return hipGetLastError();
 }
 

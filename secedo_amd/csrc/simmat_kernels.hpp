@@ -64,30 +64,23 @@ struct AccumulateArgs {
     int64_t *acc;              // tile-major: [tile][B*B]
     void *slab;                // one B*B tile (u32 counts or int64) per workgroup of the launch
     unsigned long long *counters;  // [0] incidences examined, [1] read pairs accumulated
-    // the sparse-loci path (accumulate_counts + correct_flagged): the flagged entries of every locus
-    // (build_flagged_lists), the tiles of the launch as the correction kernel needs them
-    const uint32_t *flag_off = nullptr;     // num_loci + 1
-    const uint32_t *flag_idx = nullptr;     // entry indices, grouped by locus
-    const uint32_t *unit_off = nullptr;     // num_loci + 1: work units of correct_flagged (64 entries of a locus)
-    const uint32_t *unit_locus = nullptr;   // unit -> locus
-    uint32_t unit_bound = 0;                // upper bound of the number of units (sizes the grid)
+    // the sparse-loci path (accumulate_counts + correct_tiles): the flagged entries, compact (build_flagged_lists)
+    const uint32_t *flag_pre = nullptr;     // entries + 1: flagged entries before each entry
+    const uint4 *flag_rec = nullptr;        // their full entries ...
+    const uint32_t *flag_idx = nullptr;     // ... and entry indices
     bool sparse_blocks = false;             // fewer than ~2.5 entries per (cell block, locus): groups of two
-    uint32_t num_blocks = 0;
-    uint32_t tile_end = 0;                  // tiles [tile_begin, tile_end) when tile_selected == nullptr
-    const uint8_t *tile_selected = nullptr; // one flag per tile (a launch over a tile list)
 };
 
-// true when the count-tile variants run accumulate_counts + correct_flagged (the default; SECEDO_PAIR_MODE=0
+// true when the count-tile variants run accumulate_counts + correct_tiles (the default; SECEDO_PAIR_MODE=0
 // selects the flattening kernel accumulate_tiles instead, for A/B measurements)
 bool counts_path_enabled();
-// Per-locus lists of the entries whose read is flagged (never flushed, or covering further loci), for
-// correct_flagged: off[num_loci + 1] (exclusive prefix of the per-locus counts), idx[] = entry indices.
-// cnt and cursor are scratch of num_loci + 1 words each. unit_off[num_loci + 1] / unit_locus[] describe the
-// work units of correct_flagged (64 flagged entries of one locus; at most n_entries / 64 + num_loci of them).
-// Depends on the packed pileup only.
-hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint32_t n_entries, uint32_t n_loci,
-                               uint32_t *cnt, uint32_t *cursor, uint32_t *off, uint32_t *idx, uint32_t *unit_off,
-                               uint32_t *unit_locus, hipStream_t stream);
+// The entries whose read is flagged (never flushed, or covering further loci), compacted in entry order --
+// which is (cell block, locus) order -- for correct_tiles: pre[n_entries + 1] (exclusive prefix of the flag),
+// rec[] / idx[] = the flagged entries' records and indices (room for n_entries each). scan_tmp: at least
+// flagged_scan_bytes(n_entries). Depends on the packed pileup only.
+size_t flagged_scan_bytes(uint32_t n_entries);
+hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint32_t n_entries, void *scan_tmp,
+                               size_t scan_tmp_bytes, uint32_t *pre, uint4 *rec, uint32_t *idx, hipStream_t stream);
 
 StageGeometry stage_geometry(uint32_t block_cells);
 
@@ -97,7 +90,7 @@ size_t accumulate_slab_bytes(uint32_t block_cells, bool count_tile, uint32_t n_w
 // stage_masks / count_tile: the kernel variants, see accumulate_tiles. count_tile requires fewer
 // than 65536 pairs per cell pair (PackedPileup::pair_bound) and !stage_masks; stage_masks exists
 // for 64-cell tiles only. The accumulator must be zeroed by the caller: the flush is additive.
-// side: a second stream with two events, or null: correct_flagged then runs beside the pair kernel
+// side: the stream (with two events) the flagged entries' lists are built on beside the pair kernel, or null
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
