@@ -91,7 +91,7 @@ struct secedo_simmat {
     uint32_t num_tiles = 0;
     DevBuf tile_row, tile_col, lut, counters, max_bits, slow_args, slab, plan_wg_tile, plan_wg_begin;
     uint32_t plan_tile_begin = 0xFFFFFFFFu, plan_tile_end = 0, plan_ranges = 0, plan_blocks = 0, plan_workgroups = 0;
-    DevBuf flag_tmp, flag_pre, flag_rec, flag_idx;  // sparse-loci path: the flagged entries, compact
+    DevBuf flag_tmp, flag_pre, flag_grp, flag_rec, flag_idx;  // sparse-loci path: the flagged entries, compact
     bool flags_ready = false;                                 // ... of the current packed pileup
     DevBuf own_acc, own_out;  // used by the one-shot entry point only
     DevBuf tile_ids;          // tile list of accumulate_list / max_of_tiles
@@ -689,8 +689,11 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
                 HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
                 list_stream = side->stream;
             }
-            HIP_TRY(secedo::build_flagged_lists(a.entry32, a.entry, ne, h->flag_tmp.p, h->flag_tmp.bytes,
-                                                h->flag_pre.as<uint32_t>(), h->flag_rec.as<uint4>(),
+            const size_t n_off = (size_t)h->pk.num_blocks * a.stride;
+            HIP_TRY(h->flag_grp.ensure(std::max<size_t>(n_off, 1) * 4));
+            HIP_TRY(secedo::build_flagged_lists(a.entry32, a.entry, ne, a.blk_off, n_off, h->flag_tmp.p,
+                                                h->flag_tmp.bytes, h->flag_pre.as<uint32_t>(),
+                                                h->flag_grp.as<uint32_t>(), h->flag_rec.as<uint4>(),
                                                 h->flag_idx.as<uint32_t>(), list_stream));
             if (side) {
                 HIP_TRY(hipEventRecord(side->join, side->stream));
@@ -698,7 +701,7 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
             }
             h->flags_ready = true;
         }
-        a.flag_pre = h->flag_pre.as<uint32_t>();
+        a.flag_grp = h->flag_grp.as<uint32_t>();
         a.flag_rec = h->flag_rec.as<uint4>();
         a.flag_idx = h->flag_idx.as<uint32_t>();
         {
@@ -838,11 +841,15 @@ int secedo_simmat_last_counts(secedo_simmat_t *h, uint64_t *updates, uint64_t *r
         unsigned long long st[16] = {0};
         HIP_TRY(hipMemcpy(st, h->counters.p, sizeof(st), hipMemcpyDeviceToHost));
         if (std::getenv("SECEDO_STAMPS_COUNTS")) {  // correct_tiles (-DSECEDO_STAMPS)
-            unsigned long long cf[4] = {0};
+            unsigned long long cf[11] = {0};
             HIP_TRY(hipMemcpy(cf, h->counters.as<unsigned long long>() + 82, sizeof(cf), hipMemcpyDeviceToHost));
             if (cf[0])
-                std::fprintf(stderr, "[stamps-correct] pair tests %llu, tail terms %llu, joint terms %llu, later-locus pairs %llu\n",
-                             cf[0], cf[1], cf[2], cf[3]);
+                std::fprintf(stderr, "[stamps-correct] pair tests %llu, tail terms %llu, joint terms %llu, later-locus pairs %llu | "
+                                     "per wave: pairs phase %.0f cycles (%.0f until the first q records are there), flush phase %.0f cycles, "
+                                     "flagged row entries %.0f; busiest lane: %.1f q iterations, %.0f cycles until their records are there\n",
+                             cf[0], cf[1], cf[2], cf[3], (double)cf[4] / (double)cf[6], (double)cf[8] / (double)cf[6],
+                             (double)cf[5] / (double)cf[6], (double)cf[7] / (double)cf[6], (double)cf[10] / (double)cf[6],
+                             (double)cf[9] / (double)cf[6]);
         }
         if (st[8] && std::getenv("SECEDO_STAMPS_COUNTS")) {  // accumulate_counts (-DSECEDO_STAMPS)
             const double w = (double)st[8];

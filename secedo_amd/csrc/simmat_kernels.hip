@@ -1085,24 +1085,23 @@ __global__ __launch_bounds__(256) void flagged_compact(const uint32_t *entry32, 
         }
 }
 
-// x_s, x_d over all loci two multi-locus reads share, if the locus of both entries is the first one they
-// share; false if an earlier locus owns the pair. The logic of pair_value_full / slow_pair. i1, i2: the
-// entries' places in the compact list (their entry indices are looked up only on the slow path).
-__device__ __forceinline__ bool joint_counts(const SlowPathArgs *sp, const uint32_t *flag_idx, const uint4 A1,
-                                             const uint4 A2, uint32_t i1, uint32_t i2, uint32_t *xs_out,
-                                             uint32_t *xd_out) {
-    if (A1.y & A2.y & 0xFFFFu) return false;  // they share an earlier locus
-    const bool same = (((A1.x ^ A2.x) >> 16) & 3u) == 0u;
-    if ((A1.x & A2.x & (META_PREV_OVF | META_NEXT_OVF)) == 0u) {
-        const uint32_t shared = (A1.y & A2.y) >> 16;
-        const uint32_t x = A1.z ^ A2.z;
-        const uint32_t diff = ((x & 0xFFFFu) | (x >> 16)) & shared;
-        const uint32_t nd = __popc(diff);
-        *xd_out = nd + (same ? 0u : 1u);
-        *xs_out = __popc(shared) - nd + (same ? 1u : 0u);
-        return true;
-    }
-    // a 16-locus window overflowed on the same side for both reads: merge-walk their entry lists
+// ... and per (block, locus) group the number of flagged entries before it
+__global__ __launch_bounds__(256) void flagged_groups(const uint32_t *blk_off, size_t n_off, const uint32_t *pre,
+                                                     uint32_t *grp) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_off; i += (size_t)gridDim.x * 256)
+        grp[i] = pre[blk_off[i]];
+}
+
+// x_s, x_d over all loci two multi-locus reads share, packed (values, not out-parameters: those would live
+// in scratch memory around the out-of-line call): kJointOwned if the locus of both entries is the first one
+// they share (else an earlier locus owns the pair) | x_s << 15 | x_d
+constexpr uint32_t kJointOwned = 1u << 31;
+__device__ __forceinline__ uint32_t joint_pack(bool owned, uint32_t xs, uint32_t xd) {
+    return (owned ? kJointOwned : 0u) | (xs << 15) | xd;
+}
+// a 16-locus window overflowed on the same side for both reads: merge-walk their entry lists (rare: out of line)
+__device__ __noinline__ uint32_t joint_counts_walk(const SlowPathArgs *sp, const uint32_t *flag_idx, uint32_t locus,
+                                                   uint32_t i1, uint32_t i2) {
     const uint32_t r1 = sp->entry_read[flag_idx[i1]], r2 = sp->entry_read[flag_idx[i2]];
     uint32_t j1 = sp->read_off[r1], e1 = sp->read_off[r1 + 1];
     uint32_t j2 = sp->read_off[r2], e2 = sp->read_off[r2 + 1];
@@ -1119,15 +1118,29 @@ __device__ __forceinline__ bool joint_counts(const SlowPathArgs *sp, const uint3
             ++j2;
         }
     }
-    *xs_out = xs;
-    *xd_out = xd;
-    return first == A1.w;
+    return joint_pack(first == locus, xs, xd);
+}
+
+// The logic of pair_value_full / slow_pair. i1, i2: the entries' places in the compact list (their entry
+// indices are looked up only on the slow path).
+__device__ __forceinline__ uint32_t joint_counts(const SlowPathArgs *sp, const uint32_t *flag_idx, const uint4 A1,
+                                                 const uint4 A2, uint32_t i1, uint32_t i2) {
+    if (A1.y & A2.y & 0xFFFFu) return 0u;  // they share an earlier locus
+    const bool same = (((A1.x ^ A2.x) >> 16) & 3u) == 0u;
+    if ((A1.x & A2.x & (META_PREV_OVF | META_NEXT_OVF)) == 0u) {
+        const uint32_t shared = (A1.y & A2.y) >> 16;
+        const uint32_t x = A1.z ^ A2.z;
+        const uint32_t diff = ((x & 0xFFFFu) | (x >> 16)) & shared;
+        const uint32_t nd = __popc(diff);
+        return joint_pack(true, __popc(shared) - nd + (same ? 1u : 0u), nd + (same ? 0u : 1u));
+    }
+    return joint_counts_walk(sp, flag_idx, A1.w, i1, i2);
 }
 
 struct CorrectArgs {
     const uint32_t *blk_off;   // num_blocks * stride (the packed pileup's group offsets)
     uint32_t stride;           // num_loci + 1
-    const uint32_t *flag_pre;  // entries + 1
+    const uint32_t *flag_grp;  // num_blocks * stride: flagged entries before each (block, locus) group
     const uint4 *flag_rec;     // the flagged entries' records, compact
     const uint32_t *flag_idx;  // ... and entry indices
     const SlowPathArgs *slow;
@@ -1139,6 +1152,7 @@ struct CorrectArgs {
     const uint32_t *tile_wg_begin;
     int64_t *acc;
     unsigned long long *counters;
+    uint32_t split;            // workgroups per tile
 };
 
 // One workgroup per tile (I, J) of the launch, after accumulate_counts. Two things in one pass over the tile:
@@ -1160,68 +1174,119 @@ template <int B, int THREADS>
 __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
     extern __shared__ unsigned long long corr[];  // B * B
     __shared__ long long part[2 * (THREADS / 64)];
+    // the correction D(x_s,x_d) - x_s D(1,0) - x_d D(0,1) itself for few shared loci (the usual case)
+    __shared__ long long scorr[SLUT_DIM * SLUT_DIM];
+    constexpr int U = 4;  // flagged entries p per thread in flight: their loads are issued together
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t t_local = blockIdx.x;
+    const uint32_t S = a.split, t_local = blockIdx.x / S, part_id = blockIdx.x % S;
     const uint32_t t = a.tile_ids ? a.tile_ids[t_local] : a.tile_begin + t_local;
     const uint32_t I = a.tile_row[t], J = a.tile_col[t];
     const bool diag = I == J;
     for (uint32_t i = tid; i < (uint32_t)(B * B); i += THREADS) corr[i] = 0ull;
-    __syncthreads();
     const long long d10 = a.lut[1 * LUT_DIM + 0], d01 = a.lut[0 * LUT_DIM + 1];
+    if (tid < (uint32_t)(SLUT_DIM * SLUT_DIM)) {
+        const uint32_t xs = tid / SLUT_DIM, xd = tid % SLUT_DIM;
+        scorr[tid] = a.lut[xs * LUT_DIM + xd] - (long long)xs * d10 - (long long)xd * d01;
+    }
+    __syncthreads();
     long long upd_delta = 0, pair_delta = 0;  // per lane
 #ifdef SECEDO_STAMPS
     unsigned long long dg_tests = 0, dg_tail = 0, dg_joint = 0, dg_later = 0;
+    long long dg_loads = 0, dg_qwait = 0, dg_qiter = 0;
+    uint32_t dg_sink = 0;
+    const long long dg_t0 = __builtin_readcyclecounter();
 #endif
     const size_t rowI = (size_t)I * a.stride, rowJ = (size_t)J * a.stride;
-    const uint32_t p0 = a.flag_pre[a.blk_off[rowI]], p1 = a.flag_pre[a.blk_off[rowI + a.stride - 1u]];
-    for (uint32_t p = p0 + tid; p < p1; p += THREADS) {
-        const uint4 A1 = a.flag_rec[p];
-        const size_t g = rowJ + A1.w;
-        const uint32_t c0 = a.blk_off[g], c1 = a.blk_off[g + 1];
-        if (c0 == c1) continue;
-        uint32_t q = a.flag_pre[c0];
-        const uint32_t q1 = a.flag_pre[c1];
-        if (diag) q = p + 1u;  // p lies in [pre[c0], pre[c1]) itself
-        const uint32_t row1 = (A1.x & 0xFFFFu) - I * B;
-        const bool multi1 = A1.y != 0u || (A1.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
-        for (; q < q1; ++q) {
-            const uint4 A2 = a.flag_rec[q];
-            const uint32_t row2 = (A2.x & 0xFFFFu) - J * B;
-            if (diag && row1 == row2) continue;  // same cell (:215)
+    const uint32_t p0 = a.flag_grp[rowI], p1 = a.flag_grp[rowI + a.stride - 1u];
+    for (uint32_t base = p0 + part_id * (uint32_t)(THREADS * U); base < p1; base += S * (uint32_t)(THREADS * U)) {
+        uint4 A1[U], A2[U];
+        uint32_t qa[U], qb[U];
 #ifdef SECEDO_STAMPS
-            ++dg_tests;
+        const long long dg_b0 = __builtin_readcyclecounter();
 #endif
-            const bool tails = (A1.x & A2.x & (1u << 18)) != 0u;  // both never flushed: no pair at all
-            const bool multi2 = A2.y != 0u || (A2.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
-            if (!tails && !(multi1 && multi2)) continue;
-            // (inside a diagonal tile either orientation is read back: the finalize kernels add both)
-            unsigned long long *cell = &corr[row1 * B + row2];
-            const bool same = (((A1.x ^ A2.x) >> 16) & 3u) == 0u;
-            if (tails) {
-                atomicAdd(cell, (unsigned long long)(-(same ? d10 : d01)));
-                --upd_delta;
-                --pair_delta;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = base + (uint32_t)u * THREADS + tid;
+            A1[u] = p < p1 ? a.flag_rec[p] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = base + (uint32_t)u * THREADS + tid;
+            const size_t g = rowJ + A1[u].w;
+            qa[u] = p < p1 ? a.flag_grp[g] : 0u;
+            qb[u] = p < p1 ? a.flag_grp[g + 1] : 0u;
+            if (diag) qa[u] = p + 1u;  // p lies in its own group: every pair once
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) A2[u] = qa[u] < qb[u] ? a.flag_rec[qa[u]] : make_uint4(0, 0, 0, 0);
+        // (advancing the q of all U entries together, U loads per round trip, was no faster on C3 and slower
+        // on C2: the rounds are set by the longest list among the lanes either way)
 #ifdef SECEDO_STAMPS
-                ++dg_tail;
+        dg_sink += A2[0].x + A2[U - 1].x;  // (the loads have arrived)
+        const long long dg_b1 = __builtin_readcyclecounter();
+        dg_loads += dg_b1 - dg_b0;
 #endif
-                continue;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = base + (uint32_t)u * THREADS + tid;
+            const uint4 P = A1[u];
+            const uint32_t row1 = (P.x & 0xFFFFu) - I * B;
+            const bool multi1 = P.y != 0u || (P.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
+            for (uint32_t q = qa[u]; q < qb[u]; ++q) {
+#ifdef SECEDO_STAMPS
+                const long long dg_q0 = __builtin_readcyclecounter();
+#endif
+                const uint4 Q = q == qa[u] ? A2[u] : a.flag_rec[q];
+                const uint32_t row2 = (Q.x & 0xFFFFu) - J * B;
+#ifdef SECEDO_STAMPS
+                dg_sink += row2;
+                __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                dg_qwait += __builtin_readcyclecounter() - dg_q0;
+                ++dg_qiter;
+#endif
+                if (diag && row1 == row2) continue;  // same cell (:215)
+#ifdef SECEDO_STAMPS
+                ++dg_tests;
+#endif
+                const bool tails = (P.x & Q.x & (1u << 18)) != 0u;  // both never flushed: no pair at all
+                const bool multi2 = Q.y != 0u || (Q.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
+                if (!tails && !(multi1 && multi2)) continue;
+                // (inside a diagonal tile either orientation is read back: the finalize kernels add both)
+                unsigned long long *cell = &corr[row1 * B + row2];
+                const bool same = (((P.x ^ Q.x) >> 16) & 3u) == 0u;
+                if (tails) {
+                    atomicAdd(cell, (unsigned long long)(-(same ? d10 : d01)));
+                    --upd_delta;
+                    --pair_delta;
+#ifdef SECEDO_STAMPS
+                    ++dg_tail;
+#endif
+                    continue;
+                }
+                // (the order of the two entries does not matter to joint_counts)
+                const uint32_t jc = joint_counts(a.slow, a.flag_idx, P, Q, p, q);
+                const uint32_t xs = (jc >> 15) & 0xFFFFu, xd = jc & 0x7FFFu;
+                if ((jc & kJointOwned) == 0u) {
+                    --pair_delta;  // counted at their first shared locus
+#ifdef SECEDO_STAMPS
+                    ++dg_later;
+#endif
+                    continue;
+                }
+                if (xs + xd < 2u) continue;  // this locus only: the plain term is the whole term
+                long long term;
+                if (xs < (uint32_t)SLUT_DIM && xd < (uint32_t)SLUT_DIM) {
+                    term = scorr[xs * SLUT_DIM + xd];
+                } else {
+                    const long long joint = (xs < (uint32_t)LUT_DIM && xd < (uint32_t)LUT_DIM)
+                            ? a.lut[xs * LUT_DIM + xd] : llr_fixed_device(a.slow, xs, xd);
+                    term = joint - (long long)xs * d10 - (long long)xd * d01;
+                }
+                atomicAdd(cell, (unsigned long long)term);
+#ifdef SECEDO_STAMPS
+                ++dg_joint;
+#endif
             }
-            uint32_t xs = 0, xd = 0;
-            // (the order of the two entries does not matter to joint_counts)
-            if (!joint_counts(a.slow, a.flag_idx, A1, A2, p, q, &xs, &xd)) {
-                --pair_delta;  // counted at their first shared locus
-#ifdef SECEDO_STAMPS
-                ++dg_later;
-#endif
-                continue;
-            }
-            if (xs + xd < 2u) continue;  // this locus only: the plain term is the whole term
-            const long long joint = (xs < (uint32_t)LUT_DIM && xd < (uint32_t)LUT_DIM)
-                    ? a.lut[xs * LUT_DIM + xd] : llr_fixed_device(a.slow, xs, xd);
-            atomicAdd(cell, (unsigned long long)(joint - (long long)xs * d10 - (long long)xd * d01));
-#ifdef SECEDO_STAMPS
-            ++dg_joint;
-#endif
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -1239,12 +1304,20 @@ __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
         dg_joint += __shfl_down(dg_joint, off);
         dg_later += __shfl_down(dg_later, off);
     }
-    if (lane == 0u) {
-        atomicAdd(&a.counters[82], dg_tests);
-        atomicAdd(&a.counters[83], dg_tail);
-        atomicAdd(&a.counters[84], dg_joint);
-        atomicAdd(&a.counters[85], dg_later);
+    for (int off = 32; off > 0; off >>= 1) {  // the busiest lane stands for the wave
+        dg_qwait = max(dg_qwait, (long long)__shfl_down(dg_qwait, off));
+        dg_qiter = max(dg_qiter, (long long)__shfl_down(dg_qiter, off));
     }
+    __shared__ unsigned long long dg_part[4];
+    if (tid < 4u) dg_part[tid] = 0ull;
+    __syncthreads();
+    if (lane == 0u) {
+        atomicAdd(&dg_part[0], dg_tests);
+        atomicAdd(&dg_part[1], dg_tail);
+        atomicAdd(&dg_part[2], dg_joint);
+        atomicAdd(&dg_part[3], dg_later);
+    }
+    const long long dg_t1 = __builtin_readcyclecounter();
 #endif
     __syncthreads();
     if (tid == 0u) {
@@ -1256,20 +1329,60 @@ __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
         if (u) atomicAdd(&a.counters[0], (unsigned long long)u);
         if (q) atomicAdd(&a.counters[1], (unsigned long long)q);
     }
-    // the count tiles of the pair kernel's workgroups of this tile + the corrections -> acc
+    // the count tiles of the pair kernel's workgroups of this tile + the corrections -> acc. (A tile shared
+    // by S workgroups -- launches of few tiles -- adds with atomics, each workgroup its own corrections and
+    // every S-th row of the count tiles.)
     const uint32_t w0 = a.tile_wg_begin[t_local], w1 = a.tile_wg_begin[t_local + 1];
     long long *dst = reinterpret_cast<long long *>(a.acc) + (size_t)t * B * B;
-    for (uint32_t c = tid; c < (uint32_t)(B * B); c += THREADS) {
-        const uint32_t *s = reinterpret_cast<const uint32_t *>(a.slab) + c;
-        uint32_t n_same = 0, n_diff = 0;
-        for (uint32_t w = w0; w < w1; ++w) {
-            const uint32_t v = s[(size_t)w * B * B];
-            n_same += v & 0xFFFFu;
-            n_diff += v >> 16;
+    // (a thread has F cells in flight: their loads are issued together, the tile is two round trips to HBM)
+    constexpr int F = (B * B / THREADS) < 8 ? (B * B / THREADS) : 8;
+    static_assert((B * B) % (THREADS * F) == 0, "whole batches");
+    const uint32_t *slab32 = reinterpret_cast<const uint32_t *>(a.slab);
+    for (uint32_t c0 = tid; c0 < (uint32_t)(B * B); c0 += THREADS * F) {
+        uint32_t n_same[F], n_diff[F];
+        long long old[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            n_same[f] = 0;
+            n_diff[f] = 0;
+            old[f] = S == 1u ? dst[c0 + f * THREADS] : 0ll;
         }
-        const long long sum = (long long)n_same * d10 + (long long)n_diff * d01 + (long long)corr[c];
-        if (sum) dst[c] += sum;
+        for (uint32_t w = w0; w < w1; ++w) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const uint32_t c = c0 + f * THREADS;
+                if (S == 1u || (c / THREADS) % S == part_id) {
+                    const uint32_t v = slab32[(size_t)w * B * B + c];
+                    n_same[f] += v & 0xFFFFu;
+                    n_diff[f] += v >> 16;
+                }
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const uint32_t c = c0 + f * THREADS;
+            const long long sum = (long long)corr[c] + (long long)n_same[f] * d10 + (long long)n_diff[f] * d01;
+            if (sum) {
+                if (S == 1u) dst[c] = old[f] + sum;
+                else atomicAdd(reinterpret_cast<unsigned long long *>(&dst[c]), (unsigned long long)sum);
+            }
+        }
     }
+#ifdef SECEDO_STAMPS
+    if (tid == 0u) {  // (one wave per workgroup is timed)
+        atomicAdd(&a.counters[82], dg_part[0]);
+        atomicAdd(&a.counters[83], dg_part[1]);
+        atomicAdd(&a.counters[84], dg_part[2]);
+        atomicAdd(&a.counters[85], dg_part[3]);
+        atomicAdd(&a.counters[86], (unsigned long long)(dg_t1 - dg_t0));
+        atomicAdd(&a.counters[87], (unsigned long long)(__builtin_readcyclecounter() - dg_t1));
+        atomicAdd(&a.counters[88], 1ull);
+        atomicAdd(&a.counters[89], (unsigned long long)(p1 - p0));
+        atomicAdd(&a.counters[90], (unsigned long long)dg_loads + (dg_sink == 0xFFFFFFFFu ? 1ull : 0ull));
+        atomicAdd(&a.counters[91], (unsigned long long)dg_qwait);
+        atomicAdd(&a.counters[92], (unsigned long long)dg_qiter);
+    }
+#endif
 }
 
 // acc[tile] += sum over the tile's workgroups of their slab (count slabs are converted with the two
@@ -1438,7 +1551,7 @@ hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t 
     CorrectArgs c;
     c.blk_off = args.blk_off;
     c.stride = args.stride;
-    c.flag_pre = args.flag_pre;
+    c.flag_grp = args.flag_grp;
     c.flag_rec = args.flag_rec;
     c.flag_idx = args.flag_idx;
     c.slow = args.slow;
@@ -1461,7 +1574,9 @@ hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t 
         if (e != hipSuccess) return e;
         corr_device = dev;
     }
-    hipLaunchKernelGGL(corr, dim3(args.n_tiles), dim3(CT), corr_lds, stream, c);
+    // (few tiles: several workgroups each, two rounds of the chip at most)
+    c.split = std::max(1u, std::min(8u, 512u / std::max(args.n_tiles, 1u)));
+    hipLaunchKernelGGL(corr, dim3(args.n_tiles * c.split), dim3(CT), corr_lds, stream, c);
     return hipGetLastError();
 }
 
@@ -1486,8 +1601,9 @@ size_t flagged_scan_bytes(uint32_t n_entries) {
     return bytes;
 }
 
-hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint32_t n_entries, void *scan_tmp,
-                               size_t scan_tmp_bytes, uint32_t *pre, uint4 *rec, uint32_t *idx, hipStream_t stream) {
+hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint32_t n_entries,
+                               const uint32_t *blk_off, size_t n_off, void *scan_tmp, size_t scan_tmp_bytes,
+                               uint32_t *pre, uint32_t *grp, uint4 *rec, uint32_t *idx, hipStream_t stream) {
     hipcub::CountingInputIterator<uint32_t> ids(0u);
     hipcub::TransformInputIterator<uint32_t, FlaggedOp, hipcub::CountingInputIterator<uint32_t>> in(
             ids, FlaggedOp{entry32, n_entries});
@@ -1496,6 +1612,10 @@ hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint
     if (n_entries) {
         const uint32_t blocks = (uint32_t)std::min<size_t>(((size_t)n_entries + 255) / 256, 256 * 32);
         hipLaunchKernelGGL(flagged_compact, dim3(blocks), dim3(256), 0, stream, entry32, entry, n_entries, pre, rec, idx);
+    }
+    if (n_off) {
+        const uint32_t blocks = (uint32_t)std::min<size_t>((n_off + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(flagged_groups, dim3(blocks), dim3(256), 0, stream, blk_off, n_off, pre, grp);
     }
     return hipGetLastError();
 }

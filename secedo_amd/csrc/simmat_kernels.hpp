@@ -65,7 +65,7 @@ struct AccumulateArgs {
     void *slab;                // one B*B tile (u32 counts or int64) per workgroup of the launch
     unsigned long long *counters;  // [0] incidences examined, [1] read pairs accumulated
     // the sparse-loci path (accumulate_counts + correct_tiles): the flagged entries, compact (build_flagged_lists)
-    const uint32_t *flag_pre = nullptr;     // entries + 1: flagged entries before each entry
+    const uint32_t *flag_grp = nullptr;     // num_blocks * stride: flagged entries before each (block, locus) group
     const uint4 *flag_rec = nullptr;        // their full entries ...
     const uint32_t *flag_idx = nullptr;     // ... and entry indices
     bool sparse_blocks = false;             // fewer than ~2.5 entries per (cell block, locus): groups of two
@@ -75,12 +75,14 @@ struct AccumulateArgs {
 // selects the flattening kernel accumulate_tiles instead, for A/B measurements)
 bool counts_path_enabled();
 // The entries whose read is flagged (never flushed, or covering further loci), compacted in entry order --
-// which is (cell block, locus) order -- for correct_tiles: pre[n_entries + 1] (exclusive prefix of the flag),
-// rec[] / idx[] = the flagged entries' records and indices (room for n_entries each). scan_tmp: at least
-// flagged_scan_bytes(n_entries). Depends on the packed pileup only.
+// which is (cell block, locus) order -- for correct_tiles: pre[n_entries + 1] (exclusive prefix of the flag,
+// scratch), grp[n_off] = pre at the n_off group offsets blk_off[], rec[] / idx[] = the flagged entries' records
+// and indices (room for n_entries each). scan_tmp: at least flagged_scan_bytes(n_entries). Depends on the packed
+// pileup only.
 size_t flagged_scan_bytes(uint32_t n_entries);
-hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint32_t n_entries, void *scan_tmp,
-                               size_t scan_tmp_bytes, uint32_t *pre, uint4 *rec, uint32_t *idx, hipStream_t stream);
+hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint32_t n_entries,
+                               const uint32_t *blk_off, size_t n_off, void *scan_tmp, size_t scan_tmp_bytes,
+                               uint32_t *pre, uint32_t *grp, uint4 *rec, uint32_t *idx, hipStream_t stream);
 
 StageGeometry stage_geometry(uint32_t block_cells);
 
