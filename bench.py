@@ -265,7 +265,7 @@ def main():
     for name, fn in (("pack_ms", repack), ("finalize_ms", refinalize)):
         ts = []
         if name == "finalize_ms":
-            plan.accumulate(acc, *rates, *my_tiles)
+            plan.accumulate(acc, *rates, *my_tiles, overwrite=True)
         for _ in range(5):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -280,7 +280,7 @@ def main():
     for _ in range(min(args.steps, 10)):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        plan.accumulate(acc, *rates, lo, hi)
+        plan.accumulate(acc, *rates, lo, hi, overwrite=True)
         b.record()
         evs.append((a, b))
     torch.cuda.synchronize()

@@ -152,6 +152,12 @@ int secedo_simmat_zero_acc(secedo_simmat_t *handle, int64_t *d_acc, void *stream
 int secedo_simmat_accumulate(secedo_simmat_t *handle, double mutation_rate, double homozygous_rate,
                              double seq_error_rate, uint32_t tile_begin, uint32_t tile_end,
                              int64_t *d_acc, void *stream);
+/* accumulate() into tiles that need not be zeroed first: acc[tile] = the tile's sum for the tiles of the
+ * launch, whatever they held (the reference's matrix starts from zero, similarity_matrix.cpp:306-307; the
+ * additive form above is for shards that are summed). Saves the pass that zeroes and the read of the zeroes. */
+int secedo_simmat_assign(secedo_simmat_t *handle, double mutation_rate, double homozygous_rate,
+                         double seq_error_rate, uint32_t tile_begin, uint32_t tile_end, int64_t *d_acc,
+                         void *stream);
 int secedo_simmat_finalize(secedo_simmat_t *handle, int normalization, const int64_t *d_acc,
                            double *d_out, void *stream);
 /* A rank that keeps its row block of the matrix without ever receiving other ranks' tiles (BASELINE
@@ -168,6 +174,9 @@ int secedo_simmat_tiles_of_rows(const secedo_simmat_t *handle, uint32_t row_begi
 int secedo_simmat_accumulate_list(secedo_simmat_t *handle, double mutation_rate, double homozygous_rate,
                                   double seq_error_rate, const uint32_t *tile_ids, uint32_t n_tile_ids,
                                   int64_t *d_acc, void *stream);
+int secedo_simmat_assign_list(secedo_simmat_t *handle, double mutation_rate, double homozygous_rate,
+                              double seq_error_rate, const uint32_t *tile_ids, uint32_t n_tile_ids,
+                              int64_t *d_acc, void *stream);
 int secedo_simmat_max_of_tiles(secedo_simmat_t *handle, const int64_t *d_acc, const uint32_t *tile_ids,
                                uint32_t n_tile_ids, double *max_value, void *stream);
 int secedo_simmat_finalize_rows_max(secedo_simmat_t *handle, int normalization, const int64_t *d_acc,

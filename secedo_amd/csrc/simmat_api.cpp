@@ -492,8 +492,10 @@ int secedo_simmat_zero_acc(secedo_simmat_t *h, int64_t *d_acc, void *stream) {
 
 
 // tiles [tile_begin, tile_end) when list == nullptr, else the n_list tiles of `list` (global indices)
+// overwrite: acc[tiles of the launch] = result instead of +=
 static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double theta, uint32_t tile_begin,
-                           uint32_t tile_end, const uint32_t *list, uint32_t n_list, int64_t *d_acc, void *stream) {
+                           uint32_t tile_end, const uint32_t *list, uint32_t n_list, int64_t *d_acc, void *stream,
+                           bool overwrite = false) {
     if (!h || !d_acc) return fail(SECEDO_E_INVALID_ARG, "null argument");
     if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
     if (!list && (tile_begin > tile_end || tile_end > h->num_tiles))
@@ -564,6 +566,15 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
 
     if (h->pk.num_entries == 0) {
         // nothing to add (a rank whose shard is empty): the table and the scale above are all finalize needs
+        if (overwrite) {  // ... and the tiles of the launch are zero
+            const size_t b2 = (size_t)h->pk.block_cells * h->pk.block_cells;
+            if (list) {
+                for (uint32_t k = 0; k < n_list; ++k)
+                    HIP_TRY(hipMemsetAsync(d_acc + (size_t)list[k] * b2, 0, b2 * sizeof(int64_t), s));
+            } else {
+                HIP_TRY(hipMemsetAsync(d_acc + (size_t)tile_begin * b2, 0, (size_t)(tile_end - tile_begin) * b2 * sizeof(int64_t), s));
+            }
+        }
         HIP_TRY(hipMemsetAsync(h->counters.p, 0, 16 * sizeof(unsigned long long), s));
         HIP_TRY(hipEventRecord(h->ev_begin, s));
         HIP_TRY(hipEventRecord(h->ev_end, s));
@@ -657,6 +668,7 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
     a.lut = h->lut.as<long long>();
     a.slow = h->slow_args.as<secedo::SlowPathArgs>();
     a.acc = d_acc;
+    a.overwrite = overwrite;
     a.counters = h->counters.as<unsigned long long>();
 
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, 96 * sizeof(unsigned long long), s));
@@ -724,6 +736,18 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
 int secedo_simmat_accumulate(secedo_simmat_t *h, double eps, double hr, double theta, uint32_t tile_begin,
                              uint32_t tile_end, int64_t *d_acc, void *stream) {
     return accumulate_impl(h, eps, hr, theta, tile_begin, tile_end, nullptr, 0, d_acc, stream);
+}
+
+int secedo_simmat_assign(secedo_simmat_t *h, double eps, double hr, double theta, uint32_t tile_begin,
+                         uint32_t tile_end, int64_t *d_acc, void *stream) {
+    return accumulate_impl(h, eps, hr, theta, tile_begin, tile_end, nullptr, 0, d_acc, stream, true);
+}
+
+int secedo_simmat_assign_list(secedo_simmat_t *h, double eps, double hr, double theta, const uint32_t *tile_ids,
+                              uint32_t n_tile_ids, int64_t *d_acc, void *stream) {
+    if (!tile_ids && n_tile_ids) return fail(SECEDO_E_INVALID_ARG, "tile_ids is null");
+    static const uint32_t none = 0;
+    return accumulate_impl(h, eps, hr, theta, 0, 0, tile_ids ? tile_ids : &none, n_tile_ids, d_acc, stream, true);
 }
 
 int secedo_simmat_accumulate_list(secedo_simmat_t *h, double eps, double hr, double theta, const uint32_t *tile_ids,
@@ -930,10 +954,8 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
     HIP_TRY(h->own_acc.ensure(secedo_simmat_acc_elems(h) * sizeof(int64_t)));
     const size_t out_bytes = static_cast<size_t>(num_cells) * num_cells * sizeof(double);
     HIP_TRY(h->own_out.ensure(out_bytes));
-    rc = secedo_simmat_zero_acc(h, h->own_acc.as<int64_t>(), nullptr);
-    if (rc != SECEDO_OK) return rc;
-    rc = secedo_simmat_accumulate(h, mutation_rate, homozygous_rate, seq_error_rate, 0,
-                                  secedo_simmat_num_tiles(h), h->own_acc.as<int64_t>(), nullptr);
+    rc = secedo_simmat_assign(h, mutation_rate, homozygous_rate, seq_error_rate, 0, secedo_simmat_num_tiles(h),
+                              h->own_acc.as<int64_t>(), nullptr);
     if (rc != SECEDO_OK) return rc;
     rc = secedo_simmat_finalize(h, normalization, h->own_acc.as<int64_t>(), h->own_out.as<double>(), nullptr);
     if (rc != SECEDO_OK) return rc;

@@ -69,6 +69,7 @@ struct AccumulateArgs {
     const uint4 *flag_rec = nullptr;        // their full entries ...
     const uint32_t *flag_idx = nullptr;     // ... and entry indices
     bool sparse_blocks = false;             // fewer than ~2.5 entries per (cell block, locus): groups of two
+    bool overwrite = false;                 // acc[tiles of the launch] = result (no need to zero them first)
 };
 
 // true when the count-tile variants run accumulate_counts + correct_tiles (the default; SECEDO_PAIR_MODE=0

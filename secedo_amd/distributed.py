@@ -47,8 +47,7 @@ def sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate
     assert acc.numel() == per * world * b2, "acc must be padded with new_acc(pad_tiles_to=world)"
     lo, hi = tile_range(plan.num_tiles, rank, world)
     mine = acc[rank * per * b2:(rank + 1) * per * b2]
-    mine.zero_()
-    plan.accumulate(acc, mutation_rate, homozygous_rate, seq_error_rate, lo, hi)
+    plan.accumulate(acc, mutation_rate, homozygous_rate, seq_error_rate, lo, hi, overwrite=True)
     if world > 1:
         if acc.is_cuda and dist.get_backend(group) != "nccl":
             # rehearsal backends (gloo) move host memory: stage the slices through the CPU
@@ -116,14 +115,13 @@ def agree_on_shard_geometry(plan, prepare, world, device="cpu", group=None):
 
 def chromosome_sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate, world, group=None):
     """`plan` holds this rank's chromosomes (chromosome_shard; the same block_cells and pair bound on every
-    rank: agree_on_shard_geometry): accumulate all tiles over them into the zeroed `acc`, then sum the
+    rank: agree_on_shard_geometry): compute all tiles over them into `acc` (overwritten), then sum the
     accumulators of all ranks. A rank with an empty shard still calls accumulate (it sets up the table and
     the scale that finalize needs)."""
     import torch.distributed as dist
 
     n = plan.acc_elems
-    acc[:n].zero_()
-    plan.accumulate(acc, mutation_rate, homozygous_rate, seq_error_rate)
+    plan.accumulate(acc, mutation_rate, homozygous_rate, seq_error_rate, overwrite=True)
     if world > 1:
         if acc.is_cuda and dist.get_backend(group) != "nccl":
             summed = acc[:n].cpu()  # rehearsal backends (gloo) move host memory
@@ -151,14 +149,13 @@ def sharded_rows(plan, acc, mutation_rate, homozygous_rate, seq_error_rate, rank
     accumulates every tile that touches its rows (an off-diagonal tile is computed by the two ranks that
     own its row block and its column block: twice the pair work in total, no tile ever travels), the
     ranks agree on the maximum that ADD_MIN / SCALE_MAX_1 need with one scalar all-reduce, and each
-    normalises its rows (cut on cell-block boundaries). `acc` from plan.new_acc(), zeroed here.
+    normalises its rows (cut on cell-block boundaries). `acc` from plan.new_acc(); the listed tiles are overwritten.
     Returns (rows tensor, row_begin)."""
     import torch
     import torch.distributed as dist
     lo, hi = row_range(plan.num_cells, rank, world, plan.block_cells)
     ids = plan.tiles_of_rows(lo, hi)
-    acc.zero_()
-    plan.accumulate_list(acc, mutation_rate, homozygous_rate, seq_error_rate, ids)
+    plan.accumulate_list(acc, mutation_rate, homozygous_rate, seq_error_rate, ids, overwrite=True)
     local_max = plan.max_of_tiles(acc, ids)
     if world > 1:
         t = torch.tensor([local_max], dtype=torch.float64,

@@ -245,12 +245,14 @@ class SimilarityMatrixPlan:
         _lib.check(_lib.lib().secedo_simmat_zero_acc(self._h, C.c_void_p(acc.data_ptr()), self._stream()))
 
     def accumulate(self, acc, mutation_rate, homozygous_rate, seq_error_rate, tile_begin=0,
-                   tile_end=None):
+                   tile_end=None, overwrite=False):
+        """acc[tile] += the tile's sums for tiles [tile_begin, tile_end); overwrite=True stores them instead
+        (secedo_simmat_assign): the tiles need not be zeroed first."""
         tile_end = self.num_tiles if tile_end is None else tile_end
         assert acc.dtype == self._torch.int64 and acc.is_contiguous() and acc.numel() >= self.acc_elems
-        _lib.check(_lib.lib().secedo_simmat_accumulate(
-            self._h, mutation_rate, homozygous_rate, seq_error_rate, tile_begin, tile_end,
-            C.c_void_p(acc.data_ptr()), self._stream()))
+        fn = _lib.lib().secedo_simmat_assign if overwrite else _lib.lib().secedo_simmat_accumulate
+        _lib.check(fn(self._h, mutation_rate, homozygous_rate, seq_error_rate, tile_begin, tile_end,
+                      C.c_void_p(acc.data_ptr()), self._stream()))
 
     def finalize(self, acc, normalization="ADD_MIN", out=None):
         norm = to_enum(normalization)
@@ -286,11 +288,11 @@ class SimilarityMatrixPlan:
         _lib.check(_lib.lib().secedo_simmat_tiles_of_rows(self._h, row_begin, row_end, _lib.ptr(ids), C.byref(n)))
         return ids
 
-    def accumulate_list(self, acc, mutation_rate, homozygous_rate, seq_error_rate, tile_ids):
+    def accumulate_list(self, acc, mutation_rate, homozygous_rate, seq_error_rate, tile_ids, overwrite=False):
         ids = np.ascontiguousarray(tile_ids, dtype=np.uint32)
-        _lib.check(_lib.lib().secedo_simmat_accumulate_list(
-            self._h, mutation_rate, homozygous_rate, seq_error_rate, _lib.ptr(ids), len(ids),
-            C.c_void_p(acc.data_ptr()), self._stream()))
+        fn = _lib.lib().secedo_simmat_assign_list if overwrite else _lib.lib().secedo_simmat_accumulate_list
+        _lib.check(fn(self._h, mutation_rate, homozygous_rate, seq_error_rate, _lib.ptr(ids), len(ids),
+                      C.c_void_p(acc.data_ptr()), self._stream()))
 
     def max_of_tiles(self, acc, tile_ids) -> float:
         ids = np.ascontiguousarray(tile_ids, dtype=np.uint32)

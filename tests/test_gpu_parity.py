@@ -152,6 +152,39 @@ def test_tile_ranges_compose_bitwise():
 
 
 @pytest.mark.parametrize("clustered,block", [(True, 64), (False, 128), (False, 64)])
+def test_assign_overwrites_whatever_the_tiles_held(clustered, block):
+    """secedo_simmat_assign / assign_list: the tiles of the launch end up as after accumulate() into zeroes,
+    whatever they held before, and the other tiles are not touched (all three tile variants; a range of few
+    tiles -- several workgroups per tile -- a range of many, and a list)."""
+    import torch
+    from secedo_amd.synth import synth_pileup
+    n = 700
+    p = synth_pileup(n, 6000, 2, 300 if clustered else 20000, 0.15 if clustered else 0.4, seed=5)
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        plan.prepare(p, n, 1000, None, 4, block_cells=block)
+        nt = plan.num_tiles
+        b2 = plan.block_cells ** 2
+        want = plan.new_acc()
+        plan.accumulate(want, 0.01, 0.5, 0.01)
+        junk = 0x0123456789ABCDEF
+        for lo, hi in ((0, nt), (1, min(nt, 3)), (nt // 2, nt)):
+            got = torch.full_like(want, junk)
+            plan.accumulate(got, 0.01, 0.5, 0.01, lo, hi, overwrite=True)
+            torch.cuda.synchronize()
+            assert torch.equal(got[lo * b2:hi * b2], want[lo * b2:hi * b2])
+            assert bool((got[:lo * b2] == junk).all()) and bool((got[hi * b2:] == junk).all())
+        ids = np.arange(nt, dtype=np.uint32)[::3]
+        got = torch.full_like(want, junk)
+        plan.accumulate_list(got, 0.01, 0.5, 0.01, ids, overwrite=True)
+        torch.cuda.synchronize()
+        listed = torch.zeros(nt, dtype=torch.bool)
+        listed[torch.from_numpy(ids.astype(np.int64))] = True
+        g, w = got[:nt * b2].view(nt, b2).cpu(), want[:nt * b2].view(nt, b2).cpu()
+        assert torch.equal(g[listed], w[listed])
+        assert bool((g[~listed] == junk).all())
+
+
+@pytest.mark.parametrize("clustered,block", [(True, 64), (False, 128), (False, 64)])
 def test_chunks_cut_inside_locus_ranges(clustered, block):
     """Few tiles and many locus ranges: every tile is shared by tens of workgroups whose shares of the row
     entries begin and end inside a range (all three tile variants; exact counters catch a pair counted
