@@ -350,8 +350,8 @@ def main():
             # vector-instruction issue (profiles/r02_pmc_C3.txt).
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "accumulate_counts (pair kernel; with reduce_slabs and, beside it on a second "
-                                   "stream, correct_flagged: the kernels of one accumulate)", "kernel_ms": kern_ms,
+                         "kernel": "accumulate_counts (pair kernel) + correct_tiles (flagged reads, slab reduction): "
+                                   "the kernels of one accumulate", "kernel_ms": kern_ms,
                          "kernel_ms_last_timed_step": best["last_ms"],
                          "algorithmic_bytes": b_alg,
                          "hbm_frac_measured": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,

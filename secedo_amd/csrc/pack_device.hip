@@ -1031,7 +1031,7 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
             bases |= (uint32_t)((read_base[j] >> 1) & 1u) << (16 + dist - 1);
         }
         // the 16-byte record and the read index serve the flagged entries only: pairs of two multi-locus
-        // reads, and (correct_flagged) pairs of two reads that were never flushed
+        // reads, and (correct_tiles) pairs of two reads that were never flushed
         if (multi || tail) {
             entry[d] = make_uint4(meta, masks, bases, l);
             entry_read[d] = r;  // (read only for pairs of two multi-locus reads)

@@ -690,7 +690,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
 
 
 // ------------------------------------------------------------------------------------------------
-// accumulate_counts + correct_flagged: the sparse-loci path (count tile; what C2, C3 and C5 run).
+// accumulate_counts + correct_tiles: the sparse-loci path (count tile; what C2, C3 and C5 run).
 //
 // accumulate_counts has the decomposition of accumulate_tiles -- a workgroup owns one B x B tile for a share
 // of its row-side entries and walks the locus ranges that share touches, the column side of a range staged
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
 //     holds up the short majority.
 //   * WIDE ITEMS (c >= 32, deep loci) are paired by the whole wave, 64 column entries at a time.
 //
-// What the flags mean is settled afterwards by correct_flagged, per locus, over the (few) flagged entries
+// What the flags mean is settled afterwards by correct_tiles, per tile, over the (few) flagged entries
 // only: a pair of two never-flushed reads is taken out again (:407-408), and a pair of two multi-locus
 // reads that share n >= 2 loci gets D(x_s, x_d) - x_s D(1,0) - x_d D(0,1) added once, at its first shared
 // locus -- all in the integer fixed point of the accumulator, so the sum is bit for bit what the joint
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
         for (uint32_t i = tid; i < B * B; i += THREADS) out[i] = tile32[(i / B) * ROW_WORDS + (i % B)];  // dense rows
     }
     // work counter: wave reduction, then one atomic pair per workgroup (see accumulate_tiles); every
-    // incidence counts as an update and as a read pair here, correct_flagged takes back what is neither
+    // incidence counts as an update and as a read pair here, correct_tiles takes back what is neither
     for (int off = 32; off > 0; off >>= 1) n_updates += __shfl_down(n_updates, off);
     unsigned long long *red = reinterpret_cast<unsigned long long *>(sJ);
     if (lane == 0u) red[tid >> 6] = n_updates;

@@ -14,7 +14,7 @@ for row in csv.DictReader(open(sys.argv[1])):
     acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
     n[(k, row["Counter_Name"])] += 1
 for k, d in acc.items():
-    if "accumulate" not in k and "correct_flagged" not in k: continue
+    if "accumulate" not in k and "correct_" not in k: continue
     print(k)
     for c, v in sorted(d.items()):
         print("   %-28s per-dispatch %.4g" % (c, v / n[(k, c)]))

@@ -4,7 +4,7 @@
 #   1. the driver's own command, `python bench.py` (C3 = 8000 cells x 100K loci)
 #   2. rocprofv3 --kernel-trace --stats over the same command (program directly after --)
 #   3. FETCH_SIZE / WRITE_SIZE passes over it (separate --pmc runs) + the calibration of both counters
-#   4. SQ / LDS counters of accumulate_tiles
+#   4. SQ / LDS counters of the accumulate kernels (accumulate_counts, correct_tiles)
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT/gpurun_out/r02

@@ -28,8 +28,8 @@ pick = lambda d, name: next(sum(v) / len(v) for k, v in d.items() if name in k)
 f4, f16, w16 = pick(cal_f, "read4") / GIB_KIB, pick(cal_f, "read16") / GIB_KIB, pick(cal_w, "write16") / GIB_KIB
 fetch = per_kernel("pmc_FETCH_SIZE", "FETCH_SIZE")
 write = per_kernel("pmc_WRITE_SIZE", "WRITE_SIZE")
-# the kernels of one accumulate: the pair kernel (dominant), the slab reduction, the per-locus correction
-names = [k for k in fetch if any(s in k for s in ("accumulate_counts", "accumulate_tiles", "reduce_slabs", "correct_flagged"))]
+# the kernels of one accumulate: the pair kernel (dominant), the per-tile correction + slab reduction
+names = [k for k in fetch if any(s in k for s in ("accumulate_counts", "accumulate_tiles", "reduce_slabs", "correct_tiles", "correct_flagged"))]
 name = next(k for k in names if "accumulate_" in k)
 avg = lambda d, k: sum(d[k]) / len(d[k])
 fk, wk = avg(fetch, name), avg(write, name)
