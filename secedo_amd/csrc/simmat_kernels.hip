@@ -737,11 +737,11 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
     constexpr int OPT = (CAPL + 1 + THREADS - 1) / THREADS;  // staged offsets per thread
     constexpr int RING = COUNTS_RING;
 
-    // LDS: [ tile | sJ CAPJ u16 | sOff CAPL+2 u16 | per wave: ring RING items ]
+    // LDS: [ tile | sJ CAPJ u32 (col32_of: column byte offset | base << 16) | sOff CAPL+2 u16 | per wave: ring ]
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t *tile32 = reinterpret_cast<uint32_t *>(lds_raw);
-    uint16_t *sJ = reinterpret_cast<uint16_t *>(lds_raw + TILE_BYTES);
-    uint16_t *sOff = sJ + CAPJ;
+    uint32_t *sJ = reinterpret_cast<uint32_t *>(lds_raw + TILE_BYTES);
+    uint16_t *sOff = reinterpret_cast<uint16_t *>(sJ + CAPJ);
     uint32_t *ring = reinterpret_cast<uint32_t *>(sOff + CAPL + 2) + (threadIdx.x >> 6) * RING;
 
     const uint32_t t_local = a.wg_tile[blockIdx.x];
@@ -787,7 +787,6 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
     unsigned long long n_updates = 0;  // lane 0 of each wave carries the wave's count
     uint32_t upd_w = 0;                // this wave's pairs in the current range (wave-uniform)
     uint32_t ring_head = 0, ring_tail = 0;  // wave-uniform, free-running
-    const unsigned char *sJb = reinterpret_cast<const unsigned char *>(sJ);
 
     // the next range, in flight in registers while the current one is paired
     uint32_t pJ[JPT], pI[JPT], pO[OPT];
@@ -820,7 +819,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
         // offset tid * 4 is loop-invariant, k * THREADS * 4 goes in the scalar offset).
         if (n_staged) {
             const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<uint32_t *>(a.entry32 + n_jb), 0, (int)((n_je - n_jb) * 4u), 0x00020000);
+                    const_cast<uint32_t *>(a.col32 + n_jb), 0, (int)((n_je - n_jb) * 4u), 0x00020000);
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<uint32_t *>(offJ + n_la), 0, (int)((n_lb - n_la + 1u) * 4u), 0x00020000);
 #pragma unroll
@@ -859,14 +858,16 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
     // spill, 9 % more vector instructions -- hence one instance with a wave-uniform flag.)
     {
         const bool DIAG = diag;
-        // one (row entry, column entry) incidence per lane of `in`
+        // one (row entry, column entry) incidence per lane of `in`. w = col32_of(column entry): the address is
+        // row + its low half, the base test its third byte against the row entry's base -- with sub-dword
+        // operand selects three vector instructions and the ds_add
         auto pair_slot = [&](uint32_t rec9, uint32_t row_byte, uint32_t w, unsigned long long in) {
-            const uint32_t x = rec9 ^ w;
-            if (DIAG) in &= __ballot((x & C_CELL) != 0u);  // same cell (:215)
+            if (DIAG) in &= __ballot((w & 0xFFFFu) != ((rec9 & C_CELL) << 2));  // same cell (:215)
             upd_w += (uint32_t)__popcll(in);
-            const uint32_t addr = row_byte + ((w & C_CELL) << 2);
+            const uint32_t addr = row_byte + (w & 0xFFFFu);
             if (__builtin_amdgcn_inverse_ballot_w64(in))
-                atomicAdd(reinterpret_cast<uint32_t *>(lds_raw + addr), (x & (3u << C_BASE_SHIFT)) ? 0x10000u : 1u);
+                atomicAdd(reinterpret_cast<uint32_t *>(lds_raw + addr),
+                          (w >> 16) != (rec9 >> C_BASE_SHIFT) ? 0x10000u : 1u);
         };
 
         // 64 items, each against its first four column entries; items with more go to the ring
@@ -874,11 +875,12 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
             const uint32_t c = item >> IT_C_SHIFT;
             const uint32_t rec9 = item & IT_REC_MASK;
             const uint32_t row_byte = (item & C_CELL) * (ROW_WORDS * 4u);
-            const unsigned char *p = sJb + ((item >> IT_J_SHIFT) & IT_J_MASK) * 2u;
-            // lanes with fewer than four read on inside the staging area: harmless, masked by `in`
+            const uint32_t *p = sJ + ((item >> IT_J_SHIFT) & IT_J_MASK);
+            // lanes with fewer than GROUP read on inside the staging area (or the offsets behind it): harmless,
+            // masked by `in`
             uint32_t w[GROUP];
 #pragma unroll
-            for (int u = 0; u < GROUP; ++u) w[u] = *reinterpret_cast<const uint16_t *>(p + 2 * u);
+            for (int u = 0; u < GROUP; ++u) w[u] = p[u];
             unsigned long long in[GROUP];
 #pragma unroll
             for (int u = 0; u < GROUP; ++u) in[u] = __ballot(c > (uint32_t)u);
@@ -917,7 +919,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
                 // entries and OPT * THREADS offsets, so every store is inside them, and nothing reads those slots)
                 static_assert(JPT * THREADS <= CAPJ && OPT * THREADS <= CAPL + 2, "unconditional staging stores");
 #pragma unroll
-                for (int k = 0; k < JPT; ++k) sJ[tid + k * THREADS] = (uint16_t)pJ[k];
+                for (int k = 0; k < JPT; ++k) sJ[tid + k * THREADS] = pJ[k];
 #pragma unroll
                 for (int k = 0; k < OPT; ++k) sOff[tid + k * THREADS] = (uint16_t)(pO[k] - jb);
             }
@@ -968,7 +970,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
                             for (uint32_t base = 0; base < cw; base += 64u) {
                                 const uint32_t jj = j0w + base + lane;
                                 const unsigned long long in = __ballot(base + lane < cw);
-                                const uint32_t w = sJ[min(jj, (uint32_t)CAPJ - 1u)];
+                                const uint32_t w = sJ[min(jj, (uint32_t)CAPJ - 1u)];  // (col32 form)
                                 pair_slot(recw & IT_REC_MASK, row_byte, w, in);
                             }
                         }
@@ -1533,7 +1535,7 @@ hipError_t launch_acc(const AccumulateArgs &args, uint32_t grid, hipStream_t str
 
 template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
 hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t stream, const SideStream *side) {
-    constexpr size_t lds = ((size_t)B * (B + 1) * 4 + 15) / 16 * 16 + (size_t)CAPJ * 2 + ((size_t)CAPL + 2) * 2
+    constexpr size_t lds = ((size_t)B * (B + 1) * 4 + 15) / 16 * 16 + (size_t)CAPJ * 4 + ((size_t)CAPL + 2) * 2
             + (size_t)(THREADS / 64) * (size_t)COUNTS_RING * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((CAPL + 2) % 4 == 0 && CAPJ % 8 == 0, "alignment of the LDS carve-up");
