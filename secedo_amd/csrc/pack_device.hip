@@ -714,87 +714,100 @@ __global__ void k_keys2(Raw in, const uint32_t *sval, const unsigned long long *
 }
 
 // counting path, kept entries by (cell block, locus). The entries of a locus are adjacent in the
-// pileup, so one wave per locus counts them per cell block in LDS and writes the locus' column of
-// the (block, locus) histogram with plain stores -- global atomics would all hit the handful of
-// addresses of the loci in flight.
+// pileup, so a wave counts a locus' entries per cell block in LDS -- global atomics would all hit the
+// handful of addresses of the loci in flight.
 // Single-entry fast path (m_idx != null): the S entries' slots are made here -- (block, cell) from the group
 // map, validated as k_keys2 does for the M entries -- since this is the first pass over the pileup order
 // after the appearance ranks exist.
-__global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, unsigned long long *entry_kc,
+// A workgroup takes TL consecutive loci at a time (TL a power of two, <= 64, nb * (TL + 1) words of LDS): its
+// waves count a locus each into hist[block][locus in tile], and the tile leaves as rows of TL consecutive
+// loci per block -- coalesced, where a wave writing its locus' column touched nb different cache lines for
+// 4 bytes each (6.3 M scattered stores on C3). Rows are TL + 1 words apart: the entries of one locus go to
+// many blocks and a stride of TL would put them all on one bank.
+__global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, uint32_t TL, unsigned long long *entry_kc,
                                                  const uint32_t *m_idx, const uint32_t *arank, uint32_t num_cells,
                                                  uint32_t B, uint32_t *blk_cnt, Scalars *sc) {
-    extern __shared__ uint32_t lds_hist[];
-    uint32_t *hist = lds_hist + (threadIdx.x >> 6) * nb;
-    const uint32_t lane = threadIdx.x & 63u, L = in.n_loci;
-    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
-    for (uint32_t l = wave; l < L; l += n_waves) {
-        for (uint32_t b = lane; b < nb; b += 64u) hist[b] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
-        for (uint32_t e = e0 + lane; e < e1; e += 64u) {
-            if (m_idx && m_idx[e + 1] == m_idx[e]) {
-                const uint32_t ib = in.id_base(e);
-                const uint32_t group = ib >> 2;
-                uint32_t cell = 0;
-                if (group >= in.n_groups) {
-                    sc->error = 1;
-                } else {
-                    cell = in.g2p[group];
-                    if (cell >= num_cells) {
-                        sc->error = 2;
-                        cell = 0;
+    extern __shared__ uint32_t lds_hist[];  // nb * (TL + 1)
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, L = in.n_loci, TLP = TL + 1u;
+    const uint32_t n_tiles = (L + TL - 1u) / TL;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t l0 = tile * TL, n_l = min(TL, L - l0);
+        for (uint32_t i = threadIdx.x; i < nb * TLP; i += TPB) lds_hist[i] = 0;
+        __syncthreads();
+        for (uint32_t j = wv; j < n_l; j += TPB / 64) {
+            const uint32_t l = l0 + j;
+            const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
+            for (uint32_t e = e0 + lane; e < e1; e += 64u) {
+                if (m_idx && m_idx[e + 1] == m_idx[e]) {
+                    const uint32_t ib = in.id_base(e);
+                    const uint32_t group = ib >> 2;
+                    uint32_t cell = 0;
+                    if (group >= in.n_groups) {
+                        sc->error = 1;
+                    } else {
+                        cell = in.g2p[group];
+                        if (cell >= num_cells) {
+                            sc->error = 2;
+                            cell = 0;
+                        }
                     }
+                    const uint32_t blk = cell / B, cib = cell - blk * B;
+                    entry_kc[e] = ((unsigned long long)(((ib & 3u) << kSingleBaseShift) | (blk << kCibBits) | cib) << 32)
+                            | kSingle | arank[e];
+                    atomicAdd(&lds_hist[blk * TLP + j], 1u);
+                    continue;
                 }
-                const uint32_t blk = cell / B, cib = cell - blk * B;
-                entry_kc[e] = ((unsigned long long)(((ib & 3u) << kSingleBaseShift) | (blk << kCibBits) | cib) << 32)
-                        | kSingle | arank[e];
-                atomicAdd(&hist[blk], 1u);
-                continue;
+                const unsigned long long kc = entry_kc[e];
+                if ((uint32_t)kc != kNoEntry) atomicAdd(&lds_hist[((uint32_t)(kc >> 32) >> kCibBits) * TLP + j], 1u);
             }
-            const unsigned long long kc = entry_kc[e];
-            if ((uint32_t)kc != kNoEntry) atomicAdd(&hist[(uint32_t)(kc >> 32) >> kCibBits], 1u);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t b = lane; b < nb; b += 64u) {
-            blk_cnt[(size_t)b * (L + 1) + l] = hist[b];
-            if (l == L - 1) blk_cnt[(size_t)b * (L + 1) + L] = 0;  // the closing slot of the block's row
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nb * TL; i += TPB) {
+            const uint32_t b = i / TL, j = i & (TL - 1u);
+            if (j < n_l) {
+                blk_cnt[(size_t)b * (L + 1) + l0 + j] = lds_hist[b * TLP + j];
+                if (l0 + j == L - 1) blk_cnt[(size_t)b * (L + 1) + L] = 0;  // the closing slot of the block's row
+            }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
 }
 
-// ... and places them: position = group offset + LDS cursor (arbitrary order inside the group).
-// grouped[pos] = cell-in-block << 32 | k, the final order inside a group being (cell, k)
-__global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, const unsigned long long *entry_kc,
+// ... and places them: position = group offset + LDS cursor (arbitrary order inside the group); the same
+// tiles of loci, the offsets loaded as rows. grouped[pos] = (cell in block | locus << 7) << 32 | k
+__global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, uint32_t TL, const unsigned long long *entry_kc,
                                                   const uint32_t *blk_off, const uint32_t *rbeg,
                                                   const uint32_t *flushed, unsigned long long *grouped) {
-    extern __shared__ uint32_t lds_hist[];
-    uint32_t *cursor = lds_hist + (threadIdx.x >> 6) * nb;
-    const uint32_t lane = threadIdx.x & 63u, L = in.n_loci;
-    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
-    for (uint32_t l = wave; l < L; l += n_waves) {
-        for (uint32_t b = lane; b < nb; b += 64u) cursor[b] = blk_off[(size_t)b * (L + 1) + l];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
-        const uint32_t chr = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
-        const uint32_t rb = rbeg[chr], fl_chr = flushed[chr];
-        for (uint32_t e = e0 + lane; e < e1; e += 64u) {
-            const unsigned long long kc = entry_kc[e];
-            uint32_t k = (uint32_t)kc;
-            if (k == kNoEntry) continue;
-            uint32_t cc = (uint32_t)(kc >> 32);
-            if (k & kSingle) {  // rank -> tail flag (as emit_record tests it for an M entry); base beside it
-                k = kSingle | ((k & ~kSingle) - rb >= fl_chr ? kSingleTail : 0u) | (cc >> kSingleBaseShift);
-                cc &= (1u << kSingleBaseShift) - 1u;
-            }
-            const uint32_t pos = atomicAdd(&cursor[cc >> kCibBits], 1u);
-            // cell in block | locus << 7 above k (k_entry_records; the radix path never comes here)
-            grouped[pos] = ((unsigned long long)((cc & ((1u << kCibBits) - 1u)) | (l << kCibBits)) << 32) | k;
+    extern __shared__ uint32_t lds_hist[];  // cursors, nb * (TL + 1)
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, L = in.n_loci, TLP = TL + 1u;
+    const uint32_t n_tiles = (L + TL - 1u) / TL;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t l0 = tile * TL, n_l = min(TL, L - l0);
+        for (uint32_t i = threadIdx.x; i < nb * TL; i += TPB) {
+            const uint32_t b = i / TL, j = i & (TL - 1u);
+            if (j < n_l) lds_hist[b * TLP + j] = blk_off[(size_t)b * (L + 1) + l0 + j];
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        for (uint32_t j = wv; j < n_l; j += TPB / 64) {
+            const uint32_t l = l0 + j;
+            const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
+            const uint32_t chr = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
+            const uint32_t rb = rbeg[chr], fl_chr = flushed[chr];
+            for (uint32_t e = e0 + lane; e < e1; e += 64u) {
+                const unsigned long long kc = entry_kc[e];
+                uint32_t k = (uint32_t)kc;
+                if (k == kNoEntry) continue;
+                uint32_t cc = (uint32_t)(kc >> 32);
+                if (k & kSingle) {  // rank -> tail flag (as emit_record tests it for an M entry); base beside it
+                    k = kSingle | ((k & ~kSingle) - rb >= fl_chr ? kSingleTail : 0u) | (cc >> kSingleBaseShift);
+                    cc &= (1u << kSingleBaseShift) - 1u;
+                }
+                const uint32_t pos = atomicAdd(&lds_hist[(cc >> kCibBits) * TLP + j], 1u);
+                // cell in block | locus << 7 above k (k_entry_records; the radix path never comes here)
+                grouped[pos] = ((unsigned long long)((cc & ((1u << kCibBits) - 1u)) | (l << kCibBits)) << 32) | k;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1630,9 +1643,12 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         const std::string err = cut_ranges_on_side();
         if (!err.empty()) return err;
     } else {
-        const uint32_t locus_grid = std::min<uint32_t>(blocks_for((uint64_t)L * 64), 8192);
-        const size_t lds = (size_t)(TPB / 64) * nb * 4;
-        hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_kc,
+        // tiles of TL consecutive loci per workgroup: nb * (TL + 1) words of LDS, 32 KiB at most (nb <= 1024)
+        uint32_t TL = 64;
+        while (TL > 1 && (size_t)nb * (TL + 1) * 4 > 32768) TL >>= 1;
+        const uint32_t locus_grid = std::min<uint32_t>((L + TL - 1) / TL, 8192);
+        const size_t lds = (size_t)nb * (TL + 1) * 4;
+        hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, TL, entry_kc,
                            split_singles ? m_idx : nullptr, arank, num_cells, B, blk_cnt, sc);
         trace.mark("k_bin_hist launched");
         cub_cap = S[CUB].bytes;
@@ -1643,8 +1659,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         if (n_kept) {
             unsigned long long *grouped = key_b;  // the sorted entry keys are dead after k_dup_rule
             HIP_OK(hipStreamWaitEvent(stream, pk.ev_flush, 0));  // the S entries' tail flags
-            hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, entry_kc, blk_off, rbeg,
-                               flushed, grouped);
+            hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, TL, entry_kc, blk_off,
+                               rbeg, flushed, grouped);
         }
     }
     // the locus ranges were cut for both sets of limits on the side stream (after the flush chain): pick

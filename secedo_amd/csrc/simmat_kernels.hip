@@ -870,17 +870,20 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
                           (w >> 16) != (rec9 >> C_BASE_SHIFT) ? 0x10000u : 1u);
         };
 
-        // 64 items, each against its first four column entries; items with more go to the ring
-        auto group4 = [&](uint32_t item) {
-            const uint32_t c = item >> IT_C_SHIFT;
-            const uint32_t rec9 = item & IT_REC_MASK;
-            const uint32_t row_byte = (item & C_CELL) * (ROW_WORDS * 4u);
+        // 64 items, each against its first GROUP column entries; items with more go to the ring.
+        // group_load reads the column entries, group_pair does the rest: the primary batches issue the reads
+        // of the next item before they pair the current one.
+        auto group_load = [&](uint32_t item, uint32_t (&w)[GROUP]) {
             const uint32_t *p = sJ + ((item >> IT_J_SHIFT) & IT_J_MASK);
             // lanes with fewer than GROUP read on inside the staging area (or the offsets behind it): harmless,
             // masked by `in`
-            uint32_t w[GROUP];
 #pragma unroll
             for (int u = 0; u < GROUP; ++u) w[u] = p[u];
+        };
+        auto group_pair = [&](uint32_t item, const uint32_t (&w)[GROUP]) {
+            const uint32_t c = item >> IT_C_SHIFT;
+            const uint32_t rec9 = item & IT_REC_MASK;
+            const uint32_t row_byte = (item & C_CELL) * (ROW_WORDS * 4u);
             unsigned long long in[GROUP];
 #pragma unroll
             for (int u = 0; u < GROUP; ++u) in[u] = __ballot(c > (uint32_t)u);
@@ -895,6 +898,11 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
                 }
                 ring_tail += (uint32_t)__popcll(more);
             }
+        };
+        auto group4 = [&](uint32_t item) {
+            uint32_t w[GROUP];
+            group_load(item, w);
+            group_pair(item, w);
         };
         // one batch from the ring (up to 64 items)
         auto drain_one = [&]() {
@@ -979,11 +987,18 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
                 }
                 if (r + 1 < r_end) prefetch(r + 1);  // pJ / pO are free again: the next range's column side
                 STAMP(s3);
+                {
+                    uint32_t wc[GROUP], wn[GROUP];
+                    group_load(item[0], wc);
 #pragma unroll
-                for (int k = 0; k < JPT; ++k) {
-                    // room for 64 more continuations (a drained batch may push up to 64 itself)
-                    while (ring_tail - ring_head > (uint32_t)(RING - 64)) drain_one();
-                    group4(item[k]);
+                    for (int k = 0; k < JPT; ++k) {
+                        if (k + 1 < JPT) group_load(item[k + 1], wn);
+                        // room for 64 more continuations (a drained batch may push up to 64 itself)
+                        while (ring_tail - ring_head > (uint32_t)(RING - 64)) drain_one();
+                        group_pair(item[k], wc);
+#pragma unroll
+                        for (int u = 0; u < GROUP; ++u) wc[u] = wn[u];
+                    }
                 }
                 if (r + 1 < r_end) prefetch_rows();
                 STAMP(s4);
