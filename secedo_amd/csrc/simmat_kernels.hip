@@ -1000,6 +1000,8 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
                         for (int u = 0; u < GROUP; ++u) wc[u] = wn[u];
                     }
                 }
+                // (the row side right after the column side, its registers being free once the items are built, was
+                // measured slower: C3 2.84 against 2.77 ms, C5 28.5 against 26.5)
                 if (r + 1 < r_end) prefetch_rows();
                 STAMP(s4);
 #ifdef SECEDO_STAMPS
