@@ -721,7 +721,7 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         {
             const double per_block_locus = h->pk.num_loci && h->pk.num_blocks
                     ? (double)h->pk.num_entries / h->pk.num_loci / h->pk.num_blocks : 0.0;
-            a.sparse_blocks = per_block_locus < 2.5;
+            a.group_hint = per_block_locus < 2.5 ? 2 : per_block_locus < 3.2 ? 3 : 4;
         }
     }
     HIP_TRY(hipEventRecord(h->ev_begin, s));

@@ -720,9 +720,10 @@ constexpr uint32_t IT_J_SHIFT = 9, IT_C_SHIFT = 24, IT_J_MASK = 0x1FFFu, IT_WIDE
 constexpr uint32_t IT_REC_MASK = 0x1FFu;  // cell (7 bits) | base (2 bits)
 
 // GROUP: column entries an item is paired with per pass. Measured on one MI355X (accumulate phase, ms):
-//   C3 (3.8 entries per cell block and locus): 4.87 / 4.49 / 4.38 / 5.62 for GROUP 1 / 2 / 3 / 4
-//   C5 (1.3):                                 38.6 / 38.1 / 38.9 / 46.5
-// -- empty slots cost more than trips through the ring: 3 by default, 2 below 2.5 entries per block and locus.
+//   C3 (3.8 entries per cell block and locus): - / 3.31 / 3.13 / 3.02 for GROUP 1 / 2 / 3 / 4
+//   C5 (1.3):                                 31.4 / 30.6 / 31.6 / -
+// (with seven vector instructions per slot, before col32, the empty slots of GROUP 4 cost more than the trips
+// through the ring: 4.87 / 4.49 / 4.38 / 5.62 on C3.) 4 by default, 2 below 2.5 entries per block and locus.
 template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
 __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArgs a) {
     static_assert(CAPJ <= 8192, "13 bits of column index in an item");
@@ -1692,9 +1693,11 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
             if (g == 1) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 1>(args, grid, stream, side);
             if (g == 3) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 3>(args, grid, stream, side);
             if (g == 4) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 4>(args, grid, stream, side);
-            if (g == 2 || (g == 0 && args.sparse_blocks))
+            if (g == 2 || (g == 0 && args.group_hint == 2))
                 return launch_counts<128, 1024, kCapJ128C, kCapL128C, 2>(args, grid, stream, side);
-            return launch_counts<128, 1024, kCapJ128C, kCapL128C, 3>(args, grid, stream, side);
+            if (g == 0 && args.group_hint == 3)
+                return launch_counts<128, 1024, kCapJ128C, kCapL128C, 3>(args, grid, stream, side);
+            return launch_counts<128, 1024, kCapJ128C, kCapL128C, 4>(args, grid, stream, side);
         }
         if (count_tile) return launch_acc<128, 1024, kCapJ128C, kCapL128C, 1024, false, true>(args, grid, stream);
         return launch_acc<128, 1024, kCapJ128, kCapL128, 512, false, false>(args, grid, stream);

@@ -69,7 +69,7 @@ struct AccumulateArgs {
     const uint32_t *flag_grp = nullptr;     // num_blocks * stride: flagged entries before each (block, locus) group
     const uint4 *flag_rec = nullptr;        // their full entries ...
     const uint32_t *flag_idx = nullptr;     // ... and entry indices
-    bool sparse_blocks = false;             // fewer than ~2.5 entries per (cell block, locus): groups of two
+    int group_hint = 4;                     // GROUP of accumulate_counts by the entries per (cell block, locus)
     bool overwrite = false;                 // acc[tiles of the launch] = result (no need to zero them first)
 };
 
