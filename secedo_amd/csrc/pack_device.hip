@@ -1159,27 +1159,58 @@ __global__ __launch_bounds__(TPB_REC) void k_entry_records(const unsigned long l
     if (threadIdx.x == 0 && d0 < n) first_cell = block_of(d0) * B;
     __syncthreads();
     const uint32_t lmask = (1u << lbits) - 1u;
-    for (uint32_t p = d0 + threadIdx.x; p < d1; p += TPB_REC) {
-        const unsigned long long mine = grouped[p];
-        const uint32_t k = (uint32_t)mine, cib = (uint32_t)(mine >> 32) & ((1u << kCibBits) - 1u);
-        const uint32_t l = (uint32_t)(mine >> (32 + kCibBits)) & lmask;
-        const uint32_t blk = block_of(p);
-        const size_t g = (size_t)blk * (L + 1) + l;
-        const uint32_t b = blk_off[g], len = blk_off[g + 1] - b;
-        uint32_t same = 1;
-        if (len > kRankScanLimit) {
-            sc->regroup = 1;
-        } else if (len > 1) {
-            same = 0;
-            for (uint32_t q = b; q < b + len; ++q)
-                same += ((uint32_t)(grouped[q] >> 32) & ((1u << kCibBits) - 1u)) == cib ? 1u : 0u;
+    // A thread has U entries in flight: every step of the chain entry -> group offsets / locus tables -> group
+    // members -> chromosome tables is issued for all of them before the first result is used (one entry at a
+    // time, a thread walked five dependent round trips per entry: 0.36 ms on C3).
+    constexpr int U = 4;
+    for (uint32_t base = d0; base < d1; base += TPB_REC * U) {
+        unsigned long long mine[U];
+        uint32_t blk[U], gb[U], ge[U], chr[U], lrel[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = base + (uint32_t)u * TPB_REC + threadIdx.x;
+            mine[u] = p < d1 ? grouped[p] : 0ull;
         }
-        const uint32_t cell = blk * B + cib;
-        const uint32_t chr = t.locus_chr[l];
-        emit_record(t, p, k, cib, cell, l, t.locus_rel[l], t.rbeg[chr], t.flushed[chr]);
-        const uint32_t rel = cell - first_cell;
-        if (rel < SLOTS) atomicAdd(&sq[rel], (unsigned long long)same);
-        else atomicAdd(&per_cell_sq[cell], (unsigned long long)same);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = base + (uint32_t)u * TPB_REC + threadIdx.x;
+            const uint32_t l = (uint32_t)(mine[u] >> (32 + kCibBits)) & lmask;
+            blk[u] = p < d1 ? block_of(p) : 0u;
+            const size_t g = (size_t)blk[u] * (L + 1) + l;
+            gb[u] = blk_off[g];
+            ge[u] = blk_off[g + 1];
+            chr[u] = t.locus_chr[l];
+            lrel[u] = t.locus_rel[l];
+        }
+        uint32_t rb[U], fl[U], same[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = base + (uint32_t)u * TPB_REC + threadIdx.x;
+            rb[u] = t.rbeg[chr[u]];
+            fl[u] = t.flushed[chr[u]];
+            const uint32_t cib = (uint32_t)(mine[u] >> 32) & ((1u << kCibBits) - 1u);
+            const uint32_t len = ge[u] - gb[u];
+            same[u] = 1;
+            if (p < d1 && len > kRankScanLimit) {
+                sc->regroup = 1;
+            } else if (p < d1 && len > 1) {
+                same[u] = 0;
+                for (uint32_t q = gb[u]; q < ge[u]; ++q)
+                    same[u] += ((uint32_t)(grouped[q] >> 32) & ((1u << kCibBits) - 1u)) == cib ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = base + (uint32_t)u * TPB_REC + threadIdx.x;
+            if (p >= d1) continue;
+            const uint32_t k = (uint32_t)mine[u], cib = (uint32_t)(mine[u] >> 32) & ((1u << kCibBits) - 1u);
+            const uint32_t l = (uint32_t)(mine[u] >> (32 + kCibBits)) & lmask;
+            const uint32_t cell = blk[u] * B + cib;
+            emit_record(t, p, k, cib, cell, l, lrel[u], rb[u], fl[u]);
+            const uint32_t rel = cell - first_cell;
+            if (rel < SLOTS) atomicAdd(&sq[rel], (unsigned long long)same[u]);
+            else atomicAdd(&per_cell_sq[cell], (unsigned long long)same[u]);
+        }
     }
     __syncthreads();
     if (d0 < n)
