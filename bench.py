@@ -209,6 +209,9 @@ def main():
         def step():
             if not args.packed_resident:
                 plan.prepare_resident(resident, n_cells, mfl, threads, block_cells)
+            if world == 1:
+                plan.assign_finalize(acc, *rates, norm, out)  # one rank: every tile, then the normalisation
+                return
             if by_chromosome:
                 sd.chromosome_sharded_accumulate(plan, acc, *rates, world)
             else:

@@ -160,6 +160,12 @@ int secedo_simmat_assign(secedo_simmat_t *handle, double mutation_rate, double h
                          void *stream);
 int secedo_simmat_finalize(secedo_simmat_t *handle, int normalization, const int64_t *d_acc,
                            double *d_out, void *stream);
+/* assign(all tiles) + finalize in one call, the single-GPU form of the reference function after prepare():
+ * the maximum that ADD_MIN / SCALE_MAX_1 need (similarity_matrix.cpp:275-278, :286-289) is taken while the tiles are
+ * stored, which saves finalize its pass over the accumulator. */
+int secedo_simmat_assign_finalize(secedo_simmat_t *handle, double mutation_rate, double homozygous_rate,
+                                  double seq_error_rate, int normalization, int64_t *d_acc, double *d_out,
+                                  void *stream);
 /* A rank that keeps its row block of the matrix without ever receiving other ranks' tiles (BASELINE
  * config 5, no all-gather) accumulates every tile that touches its rows itself -- each off-diagonal
  * tile is then computed by two ranks, and nothing but one scalar is exchanged:

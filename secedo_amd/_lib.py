@@ -85,6 +85,7 @@ SIGNATURES = {
     "secedo_simmat_tiles_of_rows": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, C.POINTER(C.c_uint32)]),
     "secedo_simmat_assign": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32, _vp, _vp]),
     "secedo_simmat_assign_list": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, _vp, C.c_uint32, _vp, _vp]),
+    "secedo_simmat_assign_finalize": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp]),
     "secedo_simmat_accumulate_list": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, _vp, C.c_uint32, _vp, _vp]),
     "secedo_simmat_max_of_tiles": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_double), _vp]),
     "secedo_simmat_finalize_rows_max": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_double, _vp, _vp]),

@@ -496,7 +496,8 @@ int secedo_simmat_zero_acc(secedo_simmat_t *h, int64_t *d_acc, void *stream) {
 // overwrite: acc[tiles of the launch] = result instead of +=
 static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double theta, uint32_t tile_begin,
                            uint32_t tile_end, const uint32_t *list, uint32_t n_list, int64_t *d_acc, void *stream,
-                           bool overwrite = false) {
+                           bool overwrite = false, bool *max_done = nullptr) {
+    if (max_done) *max_done = false;
     if (!h || !d_acc) return fail(SECEDO_E_INVALID_ARG, "null argument");
     if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
     if (!list && (tile_begin > tile_end || tile_end > h->num_tiles))
@@ -671,6 +672,14 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
     a.slow = h->slow_args.as<secedo::SlowPathArgs>();
     a.acc = d_acc;
     a.overwrite = overwrite;
+    // the maximum finalize needs, on the way (assign_finalize: all tiles, stored, one workgroup per tile)
+    if (max_done && overwrite && !list && tile_begin == 0 && tile_end == h->num_tiles && h->pk.count_tile
+        && !h->pk.stage_masks && secedo::counts_path_enabled() && secedo::counts_split(n_tiles) == 1) {
+        HIP_TRY(hipMemsetAsync(h->max_bits.p, 0, sizeof(unsigned long long), s));
+        a.max_bits = h->max_bits.as<unsigned long long>();
+        a.max_scale = std::ldexp(1.0, -h->scale_log2);
+        *max_done = true;
+    }
     a.counters = h->counters.as<unsigned long long>();
 
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, 96 * sizeof(unsigned long long), s));
@@ -823,7 +832,7 @@ int secedo_simmat_finalize_rows_max(secedo_simmat_t *h, int normalization, const
 }
 
 static int finalize_mode(secedo_simmat_t *h, int mode, const int64_t *d_acc, uint32_t row_begin, uint32_t row_end,
-                         double *d_out, void *stream) {
+                         double *d_out, void *stream, bool keep_max = false) {
     if (!h || !d_acc || !d_out) return fail(SECEDO_E_INVALID_ARG, "null argument");
     if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
     if (!h->have_lut) return fail(SECEDO_E_STATE, "accumulate was not called");
@@ -832,8 +841,20 @@ static int finalize_mode(secedo_simmat_t *h, int mode, const int64_t *d_acc, uin
     HIP_TRY(secedo::launch_finalize(d_acc, h->tile_row.as<uint16_t>(), h->tile_col.as<uint16_t>(), h->num_tiles,
                                     h->pk.num_cells, h->pk.block_cells, h->scale_log2, mode,
                                     h->max_bits.as<unsigned long long>(), row_begin, row_end, d_out,
-                                    static_cast<hipStream_t>(stream)));
+                                    static_cast<hipStream_t>(stream), keep_max));
     return SECEDO_OK;
+}
+
+int secedo_simmat_assign_finalize(secedo_simmat_t *h, double eps, double hr, double theta, int normalization,
+                                  int64_t *d_acc, double *d_out, void *stream) {
+    if (normalization < 0 || normalization > 2)
+        return fail(SECEDO_E_INVALID_NORMALIZATION, "Invalid normalization: " + std::to_string(normalization));
+    if (!h || !d_acc || !d_out) return fail(SECEDO_E_INVALID_ARG, "null argument");
+    bool max_done = false;
+    const int rc = accumulate_impl(h, eps, hr, theta, 0, h->prepared ? h->num_tiles : 0, nullptr, 0, d_acc, stream, true,
+                                   (normalization == 0 || normalization == 2) ? &max_done : nullptr);
+    if (rc != SECEDO_OK) return rc;
+    return finalize_mode(h, normalization, d_acc, 0, h->pk.num_cells, d_out, stream, max_done);
 }
 
 int secedo_simmat_finalize(secedo_simmat_t *h, int normalization, const int64_t *d_acc, double *d_out,
@@ -956,10 +977,8 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
     HIP_TRY(h->own_acc.ensure(secedo_simmat_acc_elems(h) * sizeof(int64_t)));
     const size_t out_bytes = static_cast<size_t>(num_cells) * num_cells * sizeof(double);
     HIP_TRY(h->own_out.ensure(out_bytes));
-    rc = secedo_simmat_assign(h, mutation_rate, homozygous_rate, seq_error_rate, 0, secedo_simmat_num_tiles(h),
-                              h->own_acc.as<int64_t>(), nullptr);
-    if (rc != SECEDO_OK) return rc;
-    rc = secedo_simmat_finalize(h, normalization, h->own_acc.as<int64_t>(), h->own_out.as<double>(), nullptr);
+    rc = secedo_simmat_assign_finalize(h, mutation_rate, homozygous_rate, seq_error_rate, normalization,
+                                       h->own_acc.as<int64_t>(), h->own_out.as<double>(), nullptr);
     if (rc != SECEDO_OK) return rc;
     HIP_TRY(hipMemcpy(out, h->own_out.p, out_bytes, hipMemcpyDeviceToHost));
     guard.ok = true;

@@ -20,6 +20,8 @@
 
 namespace secedo {
 
+uint32_t counts_split(uint32_t n_tiles);
+
 namespace {
 
 constexpr uint32_t META_PREV_OVF = 1u << 19;
@@ -1176,6 +1178,8 @@ struct CorrectArgs {
     unsigned long long *counters;
     uint32_t split;            // workgroups per tile
     uint32_t overwrite;        // acc[tile] = result instead of += (split == 1; the launcher zeroes otherwise)
+    unsigned long long *max_bits;  // when non-null (split == 1): atomicMax of max(0, max D) over the tile, as
+    double max_scale;              // reduce_max would find it in the stored tile (D = value * max_scale)
 };
 
 // One workgroup per tile (I, J) of the launch, after accumulate_counts. Two things in one pass over the tile:
@@ -1358,6 +1362,7 @@ __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
     const uint32_t w0 = a.tile_wg_begin[t_local], w1 = a.tile_wg_begin[t_local + 1];
     long long *dst = reinterpret_cast<long long *>(a.acc) + (size_t)t * B * B;
     // (a thread has F cells in flight: their loads are issued together, the tile is two round trips to HBM)
+    long long best = 0;  // max(0, max D) over the tile, in accumulator units
     constexpr int F = (B * B / THREADS) < 8 ? (B * B / THREADS) : 8;
     static_assert((B * B) % (THREADS * F) == 0, "whole batches");
     const uint32_t *slab32 = reinterpret_cast<const uint32_t *>(a.slab);
@@ -1387,9 +1392,31 @@ __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
             const long long sum = (long long)corr[c] + (long long)n_same[f] * d10 + (long long)n_diff[f] * d01;
             if (S == 1u) {
                 if (sum || a.overwrite) dst[c] = old[f] + sum;
+                if (a.max_bits) {
+                    if (diag) corr[c] = (unsigned long long)(old[f] + sum);  // (paired with its mirror below)
+                    else best = max(best, old[f] + sum);
+                }
             } else if (sum) {
                 atomicAdd(reinterpret_cast<unsigned long long *>(&dst[c]), (unsigned long long)sum);
             }
+        }
+    }
+    if (a.max_bits) {  // (wave-uniform) the maximum finalize needs, while the tile is at hand
+        if (diag) {    // a diagonal tile holds each pair in either orientation
+            __syncthreads();
+            for (uint32_t c = tid; c < (uint32_t)(B * B); c += THREADS) {
+                const uint32_t r = c / B, col = c % B;
+                if (r < col) best = max(best, (long long)corr[c] + (long long)corr[col * B + r]);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) best = max(best, (long long)__shfl_down(best, off));
+        __syncthreads();  // (part[] was read above)
+        if (lane == 0u) part[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0u) {
+            for (int w = 1; w < THREADS / 64; ++w) best = max(best, part[w]);
+            // (double)int64 * 2^-k is monotone, so the max of the integers gives the max of the doubles
+            atomicMax(a.max_bits, (unsigned long long)__double_as_longlong((double)best * a.max_scale));
         }
     }
 #ifdef SECEDO_STAMPS
@@ -1602,9 +1629,11 @@ hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t 
     }
     // (few tiles: several workgroups each, two rounds of the chip at most; they add with atomics, into zeroes
     // when the launch is to overwrite -- a contiguous tile range then)
-    c.split = std::max(1u, std::min(8u, 512u / std::max(args.n_tiles, 1u)));
+    c.split = counts_split(args.n_tiles);
     if (args.overwrite && args.tile_ids) c.split = 1;
     c.overwrite = (args.overwrite && c.split == 1u) ? 1u : 0u;
+    c.max_bits = c.split == 1u ? args.max_bits : nullptr;
+    c.max_scale = args.max_scale;
     if (args.overwrite && c.split > 1u) {
         e = hipMemsetAsync(args.acc + (size_t)args.tile_begin * B * B, 0, (size_t)args.n_tiles * B * B * 8, stream);
         if (e != hipSuccess) return e;
@@ -1631,6 +1660,8 @@ int pair_mode() {
 }  // namespace
 
 bool counts_path_enabled() { return pair_mode() != 0; }
+
+uint32_t counts_split(uint32_t n_tiles) { return std::max(1u, std::min(8u, 512u / std::max(n_tiles, 1u))); }
 
 size_t flagged_scan_bytes(uint32_t n_entries) {
     size_t bytes = 0;

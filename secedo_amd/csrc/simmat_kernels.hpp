@@ -71,11 +71,17 @@ struct AccumulateArgs {
     const uint32_t *flag_idx = nullptr;     // ... and entry indices
     int group_hint = 4;                     // GROUP of accumulate_counts by the entries per (cell block, locus)
     bool overwrite = false;                 // acc[tiles of the launch] = result (no need to zero them first)
+    // counts path, one workgroup per tile (counts_split(n_tiles) == 1), all tiles in one launch: max(0, max D) of
+    // the stored tiles by atomicMax, as launch_tile_max leaves it (zeroed by the caller)
+    unsigned long long *max_bits = nullptr;
+    double max_scale = 0.0;
 };
 
 // true when the count-tile variants run accumulate_counts + correct_tiles (the default; SECEDO_PAIR_MODE=0
 // selects the flattening kernel accumulate_tiles instead, for A/B measurements)
 bool counts_path_enabled();
+// workgroups per tile of correct_tiles for a launch of n_tiles
+uint32_t counts_split(uint32_t n_tiles);
 // The entries whose read is flagged (never flushed, or covering further loci), compacted in entry order --
 // which is (cell block, locus) order -- for correct_tiles: pre[n_entries + 1] (exclusive prefix of the flag,
 // scratch), grp[n_off] = pre at the n_off group offsets blk_off[], rec[] / idx[] = the flagged entries' records

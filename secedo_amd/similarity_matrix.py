@@ -254,6 +254,20 @@ class SimilarityMatrixPlan:
         _lib.check(fn(self._h, mutation_rate, homozygous_rate, seq_error_rate, tile_begin, tile_end,
                       C.c_void_p(acc.data_ptr()), self._stream()))
 
+    def assign_finalize(self, acc, mutation_rate, homozygous_rate, seq_error_rate, normalization="ADD_MIN", out=None):
+        """All tiles stored into `acc` (no zeroing needed) and normalised into `out`, one call: the single-GPU
+        form of the reference function after prepare (secedo_simmat_assign_finalize)."""
+        norm = to_enum(normalization)
+        if out is None:
+            out = self._torch.empty((self.num_cells, self.num_cells), dtype=self._torch.float64,
+                                    device="cuda:%d" % self.device)
+        assert acc.dtype == self._torch.int64 and acc.is_contiguous() and acc.numel() >= self.acc_elems
+        assert out.dtype == self._torch.float64 and out.is_contiguous()
+        _lib.check(_lib.lib().secedo_simmat_assign_finalize(
+            self._h, mutation_rate, homozygous_rate, seq_error_rate, norm, C.c_void_p(acc.data_ptr()),
+            C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
     def finalize(self, acc, normalization="ADD_MIN", out=None):
         norm = to_enum(normalization)
         if out is None:

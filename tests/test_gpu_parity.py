@@ -184,6 +184,26 @@ def test_assign_overwrites_whatever_the_tiles_held(clustered, block):
         assert bool((g[~listed] == junk).all())
 
 
+@pytest.mark.parametrize("norm", ["ADD_MIN", "EXPONENTIATE", "SCALE_MAX_1"])
+@pytest.mark.parametrize("n,block", [(3000, 128), (2300, 64), (300, 128)])
+def test_assign_finalize_equals_the_two_calls(n, block, norm):
+    """secedo_simmat_assign_finalize (the maximum taken while the tiles are stored: more than 256 tiles of the
+    count path; otherwise finalize's own pass) gives bit for bit the matrix of assign + finalize."""
+    import torch
+    from secedo_amd.synth import synth_pileup
+    p = synth_pileup(n, 3000, 2, 20000, 0.4, seed=11)
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        plan.prepare(p, n, 1000, None, 4, block_cells=block)
+        a = plan.new_acc()
+        plan.accumulate(a, 0.01, 0.5, 0.01, overwrite=True)
+        want = plan.finalize(a, norm)
+        b = torch.full_like(a, 77)
+        got = plan.assign_finalize(b, 0.01, 0.5, 0.01, norm)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("clustered,block", [(True, 64), (False, 128), (False, 64)])
 def test_chunks_cut_inside_locus_ranges(clustered, block):
     """Few tiles and many locus ranges: every tile is shared by tens of workgroups whose shares of the row
