@@ -48,6 +48,8 @@ def sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate
     lo, hi = tile_range(plan.num_tiles, rank, world)
     mine = acc[rank * per * b2:(rank + 1) * per * b2]
     plan.accumulate(acc, mutation_rate, homozygous_rate, seq_error_rate, lo, hi, overwrite=True)
+    if hi - lo < per:
+        acc[hi * b2:(rank + 1) * per * b2].zero_()  # the padding tiles of the last ranks' slices
     if world > 1:
         if acc.is_cuda and dist.get_backend(group) != "nccl":
             # rehearsal backends (gloo) move host memory: stage the slices through the CPU

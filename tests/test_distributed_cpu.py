@@ -32,10 +32,13 @@ class FakePlan:
     def __init__(self, num_tiles, block_cells):
         self.num_tiles, self.block_cells = num_tiles, block_cells
 
-    def accumulate(self, acc, eps, h, theta, lo, hi):
+    def accumulate(self, acc, eps, h, theta, lo, hi, overwrite=False):
         b2 = self.block_cells ** 2
         for t in range(lo, hi):
-            acc[t * b2:(t + 1) * b2] += t + 1
+            if overwrite:
+                acc[t * b2:(t + 1) * b2] = t + 1
+            else:
+                acc[t * b2:(t + 1) * b2] += t + 1
 
 
 def _worker(rank, world, port, num_tiles, out):
@@ -121,13 +124,16 @@ def test_chromosome_shards_sum_to_the_whole_matrix():
 
 
 class FakeShardPlan:
-    """accumulate() adds rank + 1 to every element: the all-reduce must leave 1 + 2 + ... + world."""
+    """accumulate() gives rank + 1 in every element: the all-reduce must leave 1 + 2 + ... + world."""
 
     def __init__(self, rank, n):
         self.rank, self.acc_elems, self.num_entries = rank, n, 1
 
-    def accumulate(self, acc, eps, h, theta):
-        acc[:self.acc_elems] += self.rank + 1
+    def accumulate(self, acc, eps, h, theta, overwrite=False):
+        if overwrite:
+            acc[:self.acc_elems] = self.rank + 1
+        else:
+            acc[:self.acc_elems] += self.rank + 1
 
 
 def _shard_worker(rank, world, port, out):
