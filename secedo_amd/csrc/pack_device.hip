@@ -406,27 +406,30 @@ struct MultiOnly {  // histogram of the ids that occur more than once (input of 
         return h > 1u ? h : 0u;
     }
 };
-// marks in pileup order (input of the appearance-rank scan): an S entry is the first entry of its read; an
-// M entry has its mark from k_dup_mark
-struct MarkOf {
-    const uint32_t *m_idx, *mark_m;
-    uint32_t n;
-    __device__ __forceinline__ uint32_t operator()(uint32_t e) const {
-        if (e >= n) return 0u;
-        const uint32_t j = m_idx[e];
-        return m_idx[e + 1] != j ? mark_m[j] : 1u;
-    }
+// Appearance rank of a pileup entry = marked entries before it. Single-entry fast path: every S entry is
+// marked, so rank(e) = e - (unmarked M entries before e) = e - unm[m_idx[e]], with unm the exclusive prefix of
+// (1 - mark) over the M entries only -- a scan over 5 % of the pileup (C3) instead of one over all of it.
+// Otherwise the ranks are an array (the scan over the marks).
+struct Ranks {
+    const uint32_t *m_idx, *unm;  // fast path (unm != null)
+    const uint32_t *arank;        // or the array
+    __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return unm ? e - unm[m_idx[e]] : arank[e]; }
+};
+struct UnmarkedM {  // input of the scan that gives unm
+    const uint32_t *mark_m;
+    uint32_t n_m;
+    __device__ __forceinline__ uint32_t operator()(uint32_t j) const { return j < n_m ? 1u - mark_m[j] : 0u; }
 };
 // appearance ranks of the M entries (k_read_info reads the rank of a read's first entry), the number of reads
-__global__ void k_arank_m(const uint32_t *arank, const uint32_t *m_entry, uint32_t n_m, uint32_t n, uint32_t *arank_m,
+__global__ void k_arank_m(const uint32_t *unm, const uint32_t *m_entry, uint32_t n_m, uint32_t n, uint32_t *arank_m,
                           Scalars *sc) {
-    for (uint32_t j = blockIdx.x * TPB + threadIdx.x; j < n_m; j += gridDim.x * TPB) arank_m[j] = arank[m_entry[j]];
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc->reads_total = arank[n];
+    for (uint32_t j = blockIdx.x * TPB + threadIdx.x; j < n_m; j += gridDim.x * TPB) arank_m[j] = m_entry[j] - unm[j];
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->reads_total = n - unm[n_m];
 }
 // per chromosome the first appearance rank
-__global__ void k_rbeg(Raw in, const uint32_t *arank, uint32_t *rbeg) {
+__global__ void k_rbeg(Raw in, Ranks rank, uint32_t *rbeg) {
     for (uint32_t c = blockIdx.x * TPB + threadIdx.x; c <= in.n_chr; c += gridDim.x * TPB)
-        rbeg[c] = arank[(uint32_t)in.locus_entry_off[in.chr_locus_off[c]]];
+        rbeg[c] = rank((uint32_t)in.locus_entry_off[in.chr_locus_off[c]]);
 }
 // Input of the one scan over the sorted order: low word = first entry of a read (head of a run of
 // equal keys), high word = the entry survives the duplicate rule. The inclusive sums give, per
@@ -546,8 +549,7 @@ __global__ __launch_bounds__(TPB) void k_read_info(Raw in, const unsigned long l
 // starts at the position of its first entry, and `arank` counts the first entries in pileup order, so the
 // reads that started at or before a locus are the ranks up to the end of that locus: a search over the
 // chromosome's positions instead of a table of start positions per read.
-__global__ void k_completed(Raw in, const uint32_t *arank, const uint32_t *rbeg, uint32_t mfl, uint32_t *cnt,
-                            Scalars *sc) {
+__global__ void k_completed(Raw in, Ranks rank, const uint32_t *rbeg, uint32_t mfl, uint32_t *cnt, Scalars *sc) {
     for (uint32_t l = blockIdx.x * TPB + threadIdx.x; l < in.n_loci; l += gridDim.x * TPB) {
         const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
         const uint32_t pos = in.locus_pos[l], l0 = in.chr_locus_off[c];
@@ -556,7 +558,7 @@ __global__ void k_completed(Raw in, const uint32_t *arank, const uint32_t *rbeg,
         uint32_t done = 0;
         if (pos >= mfl && in.locus_pos[l0] <= pos - mfl) {
             const uint32_t lp = l0 + last_le<uint32_t>(in.locus_pos + l0, l - l0 + 1, pos - mfl);
-            done = arank[(uint32_t)in.locus_entry_off[lp + 1]] - rbeg[c];
+            done = rank((uint32_t)in.locus_entry_off[lp + 1]) - rbeg[c];
         }
         cnt[l] = done;
     }
@@ -725,7 +727,7 @@ __global__ void k_keys2(Raw in, const uint32_t *sval, const unsigned long long *
 // 4 bytes each (6.3 M scattered stores on C3). Rows are TL + 1 words apart: the entries of one locus go to
 // many blocks and a stride of TL would put them all on one bank.
 __global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, uint32_t TL, unsigned long long *entry_kc,
-                                                 const uint32_t *m_idx, const uint32_t *arank, uint32_t num_cells,
+                                                 const uint32_t *m_idx, const uint32_t *unm, uint32_t num_cells,
                                                  uint32_t B, uint32_t *blk_cnt, Scalars *sc) {
     extern __shared__ uint32_t lds_hist[];  // nb * (TL + 1)
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, L = in.n_loci, TLP = TL + 1u;
@@ -738,7 +740,8 @@ __global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, uint32_t 
             const uint32_t l = l0 + j;
             const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
             for (uint32_t e = e0 + lane; e < e1; e += 64u) {
-                if (m_idx && m_idx[e + 1] == m_idx[e]) {
+                const uint32_t mj = m_idx ? m_idx[e] : 0u;
+                if (m_idx && m_idx[e + 1] == mj) {
                     const uint32_t ib = in.id_base(e);
                     const uint32_t group = ib >> 2;
                     uint32_t cell = 0;
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, uint32_t 
                     }
                     const uint32_t blk = cell / B, cib = cell - blk * B;
                     entry_kc[e] = ((unsigned long long)(((ib & 3u) << kSingleBaseShift) | (blk << kCibBits) | cib) << 32)
-                            | kSingle | arank[e];
+                            | kSingle | (e - unm[mj]);  // (its appearance rank: Ranks)
                     atomicAdd(&lds_hist[blk * TLP + j], 1u);
                     continue;
                 }
@@ -1482,6 +1485,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     // side stream, next to the grouping of the kept entries.
     // (`sub` / n_m: the entries that go through the read assembly -- all of them, or with the single-entry
     // fast path those of the ids that occur more than once; marks and ranks are always those of the whole pileup)
+    const Ranks ranks{split_singles ? m_idx : nullptr, split_singles ? arank : nullptr, arank};
     auto build_reads = [&]() -> std::string {
         uint32_t *mark_sub = split_singles ? S[MARK_M].as<uint32_t>() : mark;
         if (n_m) {
@@ -1494,21 +1498,19 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             HIP_OK(hipcub::DeviceScan::InclusiveSum(cub_tmp, cub_cap, flags, incl, (int)n_m, stream));
         }
         cub_cap = S[CUB].bytes;
-        if (split_singles) {
-            hipcub::CountingInputIterator<uint32_t> entries(0u);
-            hipcub::TransformInputIterator<uint32_t, MarkOf, hipcub::CountingInputIterator<uint32_t>> marks(
-                    entries, MarkOf{m_idx, mark_sub, E});
-            HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, marks, arank, (int)E + 1, stream));
-        } else {
-            HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, mark, arank, (int)E + 1, stream));
-        }
         const uint32_t *arank_sub = arank;
-        if (split_singles) {
+        if (split_singles) {  // (the ranks' array holds the n_m + 1 prefix sums `unm` instead: struct Ranks)
+            hipcub::CountingInputIterator<uint32_t> entries(0u);
+            hipcub::TransformInputIterator<uint32_t, UnmarkedM, hipcub::CountingInputIterator<uint32_t>> unmarked(
+                    entries, UnmarkedM{mark_sub, n_m});
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, unmarked, arank, (int)n_m + 1, stream));
             uint32_t *arank_m = S[ARANK_M].as<uint32_t>();
             hipLaunchKernelGGL(k_arank_m, dim3(blocks_for(std::max(n_m, 1u))), dim3(TPB), 0, stream, arank, m_entry, n_m,
                                E, arank_m, sc);
             arank_sub = arank_m;
-            hipLaunchKernelGGL(k_rbeg, dim3(1), dim3(TPB), 0, stream, raw, arank, rbeg);
+            hipLaunchKernelGGL(k_rbeg, dim3(1), dim3(TPB), 0, stream, raw, ranks, rbeg);
+        } else {
+            HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, mark, arank, (int)E + 1, stream));
         }
         if (n_m) {
             hipLaunchKernelGGL(k_runs_csr, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, incl, sval, sloc, n_m,
@@ -1519,7 +1521,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         }
         HIP_OK(hipEventRecord(pk.ev_fork, stream));
         HIP_OK(hipStreamWaitEvent(pk.side, pk.ev_fork, 0));
-        hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, pk.side, raw, arank, rbeg, mfl, cnt, sc);
+        hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, pk.side, raw, ranks, rbeg, mfl, cnt, sc);
         hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, pk.side, raw, cnt, 4u * num_threads, sc, flushed,
                            flush_loci, flush_count);
         HIP_OK(hipEventRecord(pk.ev_flush, pk.side));
