@@ -778,11 +778,17 @@ __global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, uint32_t 
 
 // ... and places them: position = group offset + LDS cursor (arbitrary order inside the group); the same
 // tiles of loci, the offsets loaded as rows. grouped[pos] = (cell in block | locus << 7) << 32 | k
+// It also finds the loci at which some cell has more than one kept entry (a bitmap over the cells per wave,
+// bm_words words each; 0: no room, every locus is flagged): only there does k_entry_records have to count the
+// entries of the same cell for the pair bound -- on sparse loci that scan of every group was 40 % of its time.
 __global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, uint32_t TL, const unsigned long long *entry_kc,
                                                   const uint32_t *blk_off, const uint32_t *rbeg,
-                                                  const uint32_t *flushed, unsigned long long *grouped) {
-    extern __shared__ uint32_t lds_hist[];  // cursors, nb * (TL + 1)
+                                                  const uint32_t *flushed, uint32_t B, uint32_t bm_words,
+                                                  unsigned long long *grouped, uint8_t *dupflag) {
+    extern __shared__ uint32_t lds_hist[];  // cursors, nb * (TL + 1); then the waves' cell bitmaps
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, L = in.n_loci, TLP = TL + 1u;
+    uint32_t *bm = lds_hist + nb * TLP + wv * bm_words;
+    for (uint32_t i = lane; i < bm_words; i += 64u) bm[i] = 0;
     const uint32_t n_tiles = (L + TL - 1u) / TL;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint32_t l0 = tile * TL, n_l = min(TL, L - l0);
@@ -796,6 +802,7 @@ __global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, uint32_t
             const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
             const uint32_t chr = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
             const uint32_t rb = rbeg[chr], fl_chr = flushed[chr];
+            bool twice = bm_words == 0u;
             for (uint32_t e = e0 + lane; e < e1; e += 64u) {
                 const unsigned long long kc = entry_kc[e];
                 uint32_t k = (uint32_t)kc;
@@ -805,9 +812,23 @@ __global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, uint32_t
                     k = kSingle | ((k & ~kSingle) - rb >= fl_chr ? kSingleTail : 0u) | (cc >> kSingleBaseShift);
                     cc &= (1u << kSingleBaseShift) - 1u;
                 }
+                if (bm_words) {
+                    const uint32_t cell = (cc >> kCibBits) * B + (cc & ((1u << kCibBits) - 1u));
+                    const uint32_t bit = 1u << (cell & 31u);
+                    twice |= (atomicOr(&bm[cell >> 5], bit) & bit) != 0u;
+                }
                 const uint32_t pos = atomicAdd(&lds_hist[(cc >> kCibBits) * TLP + j], 1u);
                 // cell in block | locus << 7 above k (k_entry_records; the radix path never comes here)
                 grouped[pos] = ((unsigned long long)((cc & ((1u << kCibBits) - 1u)) | (l << kCibBits)) << 32) | k;
+            }
+            const bool any_twice = __ballot(twice) != 0ull;
+            if (lane == 0u) dupflag[l] = any_twice ? 1 : 0;
+            if (bm_words) {  // the next locus starts from an empty bitmap
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i = lane; i < bm_words; i += 64u) bm[i] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
         __syncthreads();
@@ -1079,6 +1100,7 @@ struct RecordTables {  // by value: what a record needs beside the group's own e
     const uint32_t *rbeg, *flushed, *locus_chr, *locus_rel;
     uint4 *entry;
     uint32_t *entry32, *col32, *mask32, *entry_read;
+    const uint8_t *dupflag;  // per locus (k_entry_records)
 };
 
 __device__ __forceinline__ void emit_record(const RecordTables &t, uint32_t d, uint32_t k, uint32_t cib, uint32_t cell,
@@ -1168,7 +1190,7 @@ __global__ __launch_bounds__(TPB_REC) void k_entry_records(const unsigned long l
     constexpr int U = 4;
     for (uint32_t base = d0; base < d1; base += TPB_REC * U) {
         unsigned long long mine[U];
-        uint32_t blk[U], gb[U], ge[U], chr[U], lrel[U];
+        uint32_t blk[U], gb[U], ge[U], chr[U], lrel[U], dup[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t p = base + (uint32_t)u * TPB_REC + threadIdx.x;
@@ -1184,6 +1206,7 @@ __global__ __launch_bounds__(TPB_REC) void k_entry_records(const unsigned long l
             ge[u] = blk_off[g + 1];
             chr[u] = t.locus_chr[l];
             lrel[u] = t.locus_rel[l];
+            dup[u] = t.dupflag[l];  // some cell has two kept entries at this locus (k_bin_place): count them
         }
         uint32_t rb[U], fl[U], same[U];
 #pragma unroll
@@ -1196,7 +1219,7 @@ __global__ __launch_bounds__(TPB_REC) void k_entry_records(const unsigned long l
             same[u] = 1;
             if (p < d1 && len > kRankScanLimit) {
                 sc->regroup = 1;
-            } else if (p < d1 && len > 1) {
+            } else if (p < d1 && len > 1 && dup[u]) {
                 same[u] = 0;
                 for (uint32_t q = gb[u]; q < ge[u]; ++q)
                     same[u] += ((uint32_t)(grouped[q] >> 32) & ((1u << kCibBits) - 1u)) == cib ? 1u : 0u;
@@ -1276,7 +1299,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     // worst-case block count (64-cell blocks) for buffers sized before the tile size is chosen
     const size_t n_off_max = (size_t)((num_cells + 63) / 64) * ((size_t)L + 1);
     enum { KEY_A, KEY_B, VAL_A, VAL_B, ELOC, WORK_A, WORK_B, RUNS, CUB, TMP, MISC, BIN, ENTRY_KC,
-           M_IDX, M_ENTRY, RID_M, IDB_M, ELOC_M, DENSE_M, MARK_M, ARANK_M };
+           M_IDX, M_ENTRY, RID_M, IDB_M, ELOC_M, DENSE_M, MARK_M, ARANK_M, DUPF };
     auto &S = pk.scratch;
     // the counting scheme for read ids needs a table over the id space
     const size_t id_space_cap = std::min<size_t>((size_t)kIdSpaceFactor * E + 1024, (size_t)1 << 30);
@@ -1626,6 +1649,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *blk_cnt = S[KEY_A].as<uint32_t>() + 2 * ((size_t)E + 1);  // behind the marks and ranks
     // counting path: per pileup entry its k and cell (entry -> locus and the per-read scratch are dead)
     unsigned long long *entry_kc = force_radix ? nullptr : S[ENTRY_KC].as<unsigned long long>();
+    HIP_OK(S[DUPF].ensure((size_t)L + 16));
+    uint8_t *dupflag = S[DUPF].as<uint8_t>();  // per locus: some cell has two kept entries there (k_bin_place)
     // The pair bound decides the tile variant, and the tile variant the staging limits of the locus ranges;
     // the bound comes out of the grouping below, the ranges need only the offsets: they are cut for both
     // sets of limits on the side stream while the grouping runs (k_ranges_segment), and picked afterwards.
@@ -1692,8 +1717,11 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         if (n_kept) {
             unsigned long long *grouped = key_b;  // the sorted entry keys are dead after k_dup_rule
             HIP_OK(hipStreamWaitEvent(stream, pk.ev_flush, 0));  // the S entries' tail flags
-            hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, TL, entry_kc, blk_off,
-                               rbeg, flushed, grouped);
+            // (a bitmap over the cells per wave beside the cursors, if 48 KiB of LDS hold both)
+            uint32_t bm_words = (nb * B + 31) / 32;
+            if (lds + (size_t)(TPB / 64) * bm_words * 4 > 49152) bm_words = 0;
+            hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds + (size_t)(TPB / 64) * bm_words * 4, stream,
+                               raw, nb, TL, entry_kc, blk_off, rbeg, flushed, B, bm_words, grouped, dupflag);
         }
     }
     // the locus ranges were cut for both sets of limits on the side stream (after the flush chain): pick
@@ -1724,7 +1752,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
                                sc, locus_chr, locus_rel);
             const RecordTables tables{t_read, read_off, read_locus, read_base, krank, kflags, rbeg, flushed, locus_chr,
                                       locus_rel, pk.entry.as<uint4>(), pk.entry32.as<uint32_t>(),
-                                      pk.col32.as<uint32_t>(), pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr, pk.entry_read.as<uint32_t>()};
+                                      pk.col32.as<uint32_t>(), pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr,
+                                      pk.entry_read.as<uint32_t>(), dupflag};
             const unsigned long long *grouped = key_b;
             hipLaunchKernelGGL(k_entry_records, dim3(std::min<uint32_t>(1u << 16, (n_kept + 4095) / 4096)), dim3(TPB_REC),
                                0, stream, grouped, blk_off, n_kept, nb, L, B, lbits, tables, per_cell_sq, sc);
