@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the HIP runtime aborts the process on a queue error without a word unless its error log is on
+os.environ.setdefault("AMD_LOG_LEVEL", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
