@@ -1266,9 +1266,14 @@ __global__ __launch_bounds__(TPB) void k_fix_locus_rel(const uint32_t *blk_off, 
                                                       const uint32_t *locus_rel, uint32_t *entry32) {
     const uint32_t n_groups = nb * (L + 1);
     for (uint32_t g = blockIdx.x * TPB + threadIdx.x; g < n_groups; g += gridDim.x * TPB) {
+        const uint32_t l = g % (L + 1);
+        // (the closing slot of a block's row is no group -- and behind the last one blk_off ends: its successor
+        // is whatever the allocation held, which a fresh handle showed as a memory fault in
+        // test_very_deep_loci_unstaged_ranges)
+        if (l == L) continue;
         const uint32_t b = blk_off[g], e = blk_off[g + 1];
         if (b == e) continue;
-        const uint32_t lrel = locus_rel[g % (L + 1)] << 16;
+        const uint32_t lrel = locus_rel[l] << 16;
         for (uint32_t d = b; d < e; ++d) entry32[d] = (entry32[d] & 0xFFFFu) | lrel;
     }
 }

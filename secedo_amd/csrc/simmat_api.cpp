@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -969,18 +970,31 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
         bool ok = false;
         ~Guard() { one_shot_release(device, h, ok); }
     } guard{h, device};
+    static const bool trace = std::getenv("SECEDO_ONE_SHOT_TRACE") != nullptr;  // phase times on stderr
+    using clock = std::chrono::steady_clock;
+    auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = clock::now();
     rc = secedo_simmat_set_pileup(h, chr_locus_off, n_chr, locus_pos, locus_entry_off, read_ids,
                                   id_base16, id_base32, group_id_to_pos, n_groups);
     if (rc != SECEDO_OK) return rc;
     rc = secedo_simmat_prepare(h, num_cells, max_fragment_length, num_threads, 0, nullptr);
     if (rc != SECEDO_OK) return rc;
+    const auto t1 = clock::now();
     HIP_TRY(h->own_acc.ensure(secedo_simmat_acc_elems(h) * sizeof(int64_t)));
     const size_t out_bytes = static_cast<size_t>(num_cells) * num_cells * sizeof(double);
     HIP_TRY(h->own_out.ensure(out_bytes));
     rc = secedo_simmat_assign_finalize(h, mutation_rate, homozygous_rate, seq_error_rate, normalization,
                                        h->own_acc.as<int64_t>(), h->own_out.as<double>(), nullptr);
     if (rc != SECEDO_OK) return rc;
+    if (trace) HIP_TRY(hipDeviceSynchronize());
+    const auto t2 = clock::now();
+    // (pageable destination: 12-20 GB/s for the 512 MB of C3, the longest phase of a one-shot call; four
+    // threads with a pinned buffer and a stream each were no faster -- the second hop into fresh pages is the
+    // limit, not the staging)
     HIP_TRY(hipMemcpy(out, h->own_out.p, out_bytes, hipMemcpyDeviceToHost));
+    if (trace)
+        std::fprintf(stderr, "[one-shot] upload + packing %.2f ms, matrix %.2f ms, copy to the host %.2f ms\n", ms(t0, t1),
+                     ms(t1, t2), ms(t2, clock::now()));
     guard.ok = true;
     return SECEDO_OK;
 }

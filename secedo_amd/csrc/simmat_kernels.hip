@@ -1627,8 +1627,8 @@ hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t 
         if (e != hipSuccess) return e;
         corr_device = dev;
     }
-    // (few tiles: several workgroups each, two rounds of the chip at most; they add with atomics, into zeroes
-    // when the launch is to overwrite -- a contiguous tile range then)
+    // (few tiles: several workgroups each; they add with atomics, into zeroes when the launch is to overwrite
+    // -- a contiguous tile range then)
     c.split = counts_split(args.n_tiles);
     if (args.overwrite && args.tile_ids) c.split = 1;
     c.overwrite = (args.overwrite && c.split == 1u) ? 1u : 0u;
@@ -1661,7 +1661,8 @@ int pair_mode() {
 
 bool counts_path_enabled() { return pair_mode() != 0; }
 
-uint32_t counts_split(uint32_t n_tiles) { return std::max(1u, std::min(8u, 512u / std::max(n_tiles, 1u))); }
+// (few tiles: several workgroups each, as many as fit one round of the chip's 256 CUs)
+uint32_t counts_split(uint32_t n_tiles) { return std::max(1u, std::min(8u, 256u / std::max(n_tiles, 1u))); }
 
 size_t flagged_scan_bytes(uint32_t n_entries) {
     size_t bytes = 0;

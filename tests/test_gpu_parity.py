@@ -187,7 +187,7 @@ def test_assign_overwrites_whatever_the_tiles_held(clustered, block):
 @pytest.mark.parametrize("norm", ["ADD_MIN", "EXPONENTIATE", "SCALE_MAX_1"])
 @pytest.mark.parametrize("n,block", [(3000, 128), (2300, 64), (300, 128)])
 def test_assign_finalize_equals_the_two_calls(n, block, norm):
-    """secedo_simmat_assign_finalize (the maximum taken while the tiles are stored: more than 256 tiles of the
+    """secedo_simmat_assign_finalize (the maximum taken while the tiles are stored: more than 128 tiles of the
     count path; otherwise finalize's own pass) gives bit for bit the matrix of assign + finalize."""
     import torch
     from secedo_amd.synth import synth_pileup
