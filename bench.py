@@ -358,7 +358,8 @@ def main():
                          "kernel_ms_last_timed_step": best["last_ms"],
                          "algorithmic_bytes": b_alg,
                          "hbm_frac_measured": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                         "limiter": "VALU issue and LDS atomics, about 60 % busy each (profiles/r02_pmc_C3.txt)",
+                         "limiter": "vector-instruction issue (about 60 % of the SIMD cycles) and the LDS pipeline (about 40 %) "
+                                    "with 4 waves per SIMD (profiles/r02_pmc_C3.txt)",
                          "whole_step": {"algorithmic_bytes": b_alg_step,
                                         "achieved": b_alg_step / step_s / 1e9,
                                         "frac": b_alg_step / step_s / 1e9 / HBM_PEAK_GBPS / world}},
