@@ -42,7 +42,18 @@ namespace {
 
 using secedo::spectral::kBlockWidth;
 constexpr uint32_t BW = kBlockWidth;
-constexpr uint32_t kCycleBlocks = 6;  // Krylov blocks per restart cycle: a 192-dimensional projection
+// Krylov blocks per restart cycle, set per solve (cycle_blocks): a larger space needs fewer matrix passes in
+// all (N = 8000: 132 / 112 / 104 block products with 6 / 7 / 8 blocks) but its Rayleigh-Ritz problem on the host
+// grows with the cube -- measured best: 6 below 2000 rows (17.8 / 19.5 / 22.8 ms at N = 1000), 7 up to 12000
+// (70.6 / 60.6 / 63.5 ms at N = 8000), 8 beyond (137 / 127 / 118 ms at N = 16000).
+thread_local uint32_t kCycleBlocks = 6;
+uint32_t cycle_blocks(uint32_t n) {
+    if (const char *e = std::getenv("SECEDO_SPECTRAL_BLOCKS")) {
+        const int v = std::atoi(e);
+        if (v >= 3 && v <= 12) return (uint32_t)v;
+    }
+    return n < 2000u ? 6u : n < 12000u ? 7u : 8u;
+}
 
 struct Buf {
     void *p = nullptr;
@@ -173,6 +184,7 @@ int solve(int device_id, const double *d_rows, uint32_t row_begin, uint32_t n_ro
     const double tol_values = std::max(tol, 1e-6);
 
     Solver sv;
+    kCycleBlocks = cycle_blocks(n);
     int rc = sv.setup(d_rows, row_begin, n_rows, n, allreduce, allreduce_ctx, stream);
     if (rc) return rc;
     if ((rc = sv.scales())) return rc;
