@@ -65,8 +65,12 @@ for it in range(N):
     finally:
         ob.set_exact_binomials(False)
         ob.set_direct_llr_sum(False)
-    heavy = counts_ref[1] / max(1.0, n * (n - 1) / 2) > 1e4
-    tol_ref = 5e-8 if heavy else TOL
+    per_pair = counts_ref[1] / max(1.0, n * (n - 1) / 2)
+    heavy = per_pair > 1e4
+    # (from ~1e4 pairs per cell pair on the reference's two sums and their final subtraction lose digits; from
+    # ~1e7 on the pair bound lowers the fixed-point scale of the accumulator as well: DESIGN.md section 4)
+    tol_ref = 1e-6 if per_pair > 1e7 else 5e-8 if heavy else TOL
+    tol_direct = 2e-8 if per_pair > 1e7 else TOL
     problems = []
     try:
         with secedo_amd.SimilarityMatrixPlan(0) as plan:
@@ -84,7 +88,7 @@ for it in range(N):
                 problems.append("assign_finalize != finalize")
         if counts != counts_ref:
             problems.append("counters %r != %r" % (counts, counts_ref))
-        if gu.normwise_err(got_raw, raw_direct) > TOL:
+        if gu.normwise_err(got_raw, raw_direct) > tol_direct:
             problems.append("raw vs direct sums %.3g" % gu.normwise_err(got_raw, raw_direct))
         if gu.normwise_err(got_raw, raw) > tol_ref:
             problems.append("raw vs reference arithmetic %.3g" % gu.normwise_err(got_raw, raw))
