@@ -39,6 +39,17 @@ DevicePacked::~DevicePacked() {
     if (mailbox) (void)hipHostFree(mailbox);
 }
 
+// SECEDO_POISON (a debugging aid): 1 fills every new allocation with 0xA5 bytes, 2 also refills the packing's
+// scratch and outputs at the start of every prepare -- a kernel that reads a word nobody wrote then reads
+// 0xA5A5A5A5 every time instead of whatever the allocation happened to hold (tools/poison_run.sh).
+int poison_level() {
+    static const int level = [] {
+        const char *e = std::getenv("SECEDO_POISON");
+        return e ? std::atoi(e) : 0;
+    }();
+    return level;
+}
+
 hipError_t DeviceArena::ensure(size_t n) {
     if (n <= bytes && p) return hipSuccess;
     if (p) (void)hipFree(p);
@@ -47,6 +58,7 @@ hipError_t DeviceArena::ensure(size_t n) {
     const size_t want = n ? n + n / 8 + 256 : 256;  // head room: sizes vary a little from call to call
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) bytes = want;
+    if (e == hipSuccess && poison_level() >= 1) e = hipMemset(p, 0xA5, want);
     return e;
 }
 
@@ -1824,6 +1836,16 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
     bool no_assumptions = false;
     std::string err;
     for (int attempt = 0; attempt < 3; ++attempt) {
+        if (poison_level() >= 2) {  // debugging aid: nothing may depend on what the buffers held
+            if (hipStreamSynchronize(stream) != hipSuccess || (out->side && hipStreamSynchronize(out->side) != hipSuccess))
+                return "poison: synchronise failed";
+            DeviceArena *outputs[] = {&out->blk_off, &out->entry32, &out->col32, &out->mask32, &out->entry,
+                                      &out->entry_read, &out->range_off, &out->read_off, &out->read_locus, &out->read_base};
+            for (DeviceArena *a : outputs)
+                if (a->p && hipMemset(a->p, 0xA5, a->bytes) != hipSuccess) return "poison: memset failed";
+            for (DeviceArena &a : out->scratch)
+                if (a.p && hipMemset(a.p, 0xA5, a.bytes) != hipSuccess) return "poison: memset failed";
+        }
         err = pack_attempt(in, num_cells, mfl, num_threads, block_cells, geometry, allow_count_tile, force_radix,
                            no_assumptions, stream, out, need_host, &retry);
         if (!err.empty() || retry == kNoRetry) break;

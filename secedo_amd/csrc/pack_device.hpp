@@ -32,6 +32,8 @@ struct DeviceFlatPileup {
 };
 
 // Growable device allocation owned by the caller (simmat_api.cpp's handle)
+int poison_level();  // SECEDO_POISON, a debugging aid (pack_device.hip)
+
 struct DeviceArena {
     void *p = nullptr;
     size_t bytes = 0;

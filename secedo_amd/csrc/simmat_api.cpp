@@ -60,6 +60,7 @@ struct DevBuf {
         release();
         hipError_t e = hipMalloc(&p, n ? n : 16);
         if (e == hipSuccess) bytes = n ? n : 16;
+        if (e == hipSuccess && secedo::poison_level() >= 1) e = hipMemset(p, 0xA5, bytes);
         return e;
     }
     template <class T>

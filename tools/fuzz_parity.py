@@ -68,10 +68,13 @@ for it in range(N):
     per_pair = counts_ref[1] / max(1.0, n * (n - 1) / 2)
     heavy = per_pair > 1e4
     # (from ~1e4 pairs per cell pair on the reference's two sums and their final subtraction lose digits; from
-    # ~1e7 on the pair bound lowers the fixed-point scale of the accumulator as well: DESIGN.md section 4)
-    tol_ref = 1e-6 if per_pair > 1e7 else 5e-8 if heavy else TOL
-    tol_direct = 2e-8 if per_pair > 1e7 else TOL
+    # ~1e6 on the pair bound lowers the fixed-point scale of the accumulator as well -- 2^37 at 2.5e6 pairs, where
+    # the same table entry is added millions of times and the sums cancel to 1e-3 of their terms: DESIGN.md
+    # section 4)
+    tol_ref = 1e-6 if per_pair > 1e6 else 5e-8 if heavy else TOL
+    tol_direct = 2e-8 if per_pair > 1e6 else TOL
     problems = []
+    fixed_point = ""
     try:
         with secedo_amd.SimilarityMatrixPlan(0) as plan:
             plan.prepare(p, n, mfl, g2p, T, block_cells=block)
@@ -80,6 +83,7 @@ for it in range(N):
             got = plan.finalize(acc, norm).cpu().numpy()
             got_raw = plan.finalize_raw(acc).cpu().numpy()
             counts = plan.last_counts()
+            fixed_point = "scale 2^%d, pair bound %d, %.3g pairs per cell pair" % (plan.scale_log2, plan.pair_bound, per_pair)
             acc2 = torch.full_like(acc, 12345)
             got2 = plan.assign_finalize(acc2, 0.01, 0.5, 0.02, norm).cpu().numpy()
             if not torch.equal(acc[:plan.acc_elems], acc2[:plan.acc_elems]):
@@ -101,7 +105,7 @@ for it in range(N):
         problems.append("exception %r" % (exc,))
     if problems:
         fails += 1
-        print("FAIL", ctx, problems, flush=True)
+        print("FAIL", ctx, problems, fixed_point, flush=True)
     elif it % 20 == 0:
         print("ok up to", it, "(%.0f s)" % (time.time() - t_start), ctx, flush=True)
 print("fuzz: %d configurations, %d failures, %.0f s" % (N, fails, time.time() - t_start), flush=True)
