@@ -1414,7 +1414,11 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         const char *e = std::getenv("SECEDO_PACK_SPLIT");
         return !(e && std::atoi(e) == 0);
     }();
-    const bool split_singles = counting && split_allowed;
+    if (!pk.split_pays && ++pk.calls_without_split >= 16) {  // (pileups change: look again now and then)
+        pk.split_pays = true;
+        pk.calls_without_split = 0;
+    }
+    bool split_singles = counting && split_allowed && pk.split_pays;
     Raw sub = raw;
     const uint32_t *sub_eloc = eloc;
     uint32_t n_m = E;
@@ -1451,6 +1455,17 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
                 return std::string();
             }
             n_m = hsc.n_multi_id;
+            if ((uint64_t)n_m * 2 > E) {  // clustered loci: (nearly) every read has several entries, no short cut
+                split_singles = false;
+                pk.split_pays = false;
+                pk.calls_without_split = 0;
+                n_m = E;
+                m_idx = nullptr;
+                m_entry = nullptr;
+            }
+        }
+        if (split_singles) {
+            uint32_t *dense_m = S[DENSE_M].as<uint32_t>();
             sub = raw;
             sub.read_ids = S[RID_M].as<uint32_t>();
             sub.id_base16 = nullptr;

@@ -54,6 +54,10 @@ struct DevicePacked {
     bool count_tile = false;
     uint32_t cap_entries = 0, cap_loci = 0;
     uint64_t id_space_hint = 0;  // size of the read-id space of the previous call (0: unknown): saves a read-back
+    // the single-entry fast path pays when most reads have one entry: a call that finds more than half of the
+    // entries in multi-entry reads finishes without it, and the handle's next calls do not try (every 16th does)
+    bool split_pays = true;
+    uint32_t calls_without_split = 0;
     // side stream for the branch of the pipeline nothing else waits for until the final gather
     // (completed counts + flush chain); created on first use
     hipStream_t side = nullptr;
