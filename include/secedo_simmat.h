@@ -206,6 +206,9 @@ int secedo_simmat_last_counts(secedo_simmat_t *handle, uint64_t *updates, uint64
 /* Device time of the accumulate kernel of the last accumulate() call, measured with hipEvents
  * on the stream it ran on. Synchronises on the end event. */
 int secedo_simmat_last_accumulate_ms(secedo_simmat_t *handle, float *ms);
+/* ... and of its dominant kernel by itself when the sparse-loci kernels ran (accumulate_counts, from the start
+ * of the accumulate to the launch that follows it); SECEDO_E_STATE otherwise. */
+int secedo_simmat_last_pair_kernel_ms(secedo_simmat_t *handle, float *ms);
 
 /* log-likelihood ratio D(x_s, x_d) = log P(x_s,x_d | different) - log P(x_s,x_d | same) as the
  * device tables hold it (host-only, no device): for x_s + x_d <= 64 what the reference's nested sums

@@ -109,7 +109,8 @@ struct secedo_simmat {
     secedo::LlrTable table;
     secedo::SlowPathArgs slow_host;
 
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_mid = nullptr;
+    bool timed_mid = false;
     bool timed = false;
     secedo::SideStream side;  // the flagged entries' lists are built beside accumulate_counts (created on first use)
 };
@@ -224,6 +225,7 @@ int secedo_simmat_create(secedo_simmat_t **handle, int device_id) {
     h->device = device_id;
     hipError_t e = hipEventCreate(&h->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_end);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_mid);
     if (e != hipSuccess) {
         delete h;
         return hip_fail(e, "hipEventCreate");
@@ -237,6 +239,7 @@ void secedo_simmat_destroy(secedo_simmat_t *h) {
     (void)hipSetDevice(h->device);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->side.fork) (void)hipEventDestroy(h->side.fork);
     if (h->side.join) (void)hipEventDestroy(h->side.join);
     if (h->side.stream) (void)hipStreamDestroy(h->side.stream);
@@ -740,7 +743,10 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
     const bool count_tile = h->pk.count_tile;
     HIP_TRY(h->slab.ensure(secedo::accumulate_slab_bytes(h->pk.block_cells, count_tile, a.n_workgroups)));
     a.slab = h->slab.p;
-    HIP_TRY(secedo::launch_accumulate(a, h->pk.block_cells, h->pk.stage_masks, count_tile, n_tiles, s, side));
+    h->timed_mid = count_tile && !h->pk.stage_masks && secedo::counts_path_enabled();
+    HIP_TRY(secedo::launch_accumulate(a, h->pk.block_cells, h->pk.stage_masks, count_tile, n_tiles, s, side,
+                                      h->timed_mid ? h->ev_mid : nullptr));
+    h->timed_mid = h->timed_mid && n_tiles > 0;
     HIP_TRY(hipEventRecord(h->ev_end, s));
     h->timed = true;
     return SECEDO_OK;
@@ -945,6 +951,15 @@ int secedo_simmat_last_accumulate_ms(secedo_simmat_t *h, float *ms) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventSynchronize(h->ev_end));
     HIP_TRY(hipEventElapsedTime(ms, h->ev_begin, h->ev_end));
+    return SECEDO_OK;
+}
+
+int secedo_simmat_last_pair_kernel_ms(secedo_simmat_t *h, float *ms) {
+    if (!h || !ms) return fail(SECEDO_E_INVALID_ARG, "null argument");
+    if (!h->timed || !h->timed_mid) return fail(SECEDO_E_STATE, "the last accumulate did not run the sparse-loci kernels");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventSynchronize(h->ev_mid));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev_begin, h->ev_mid));
     return SECEDO_OK;
 }
 

@@ -1579,7 +1579,8 @@ hipError_t launch_acc(const AccumulateArgs &args, uint32_t grid, hipStream_t str
 }
 
 template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
-hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t stream, const SideStream *side) {
+hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t stream, const SideStream *side,
+                         hipEvent_t mid) {
     constexpr size_t lds = ((size_t)B * (B + 1) * 4 + 15) / 16 * 16 + (size_t)CAPJ * 4 + ((size_t)CAPL + 2) * 2
             + (size_t)(THREADS / 64) * (size_t)COUNTS_RING * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -1596,6 +1597,7 @@ hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t 
         configured_device = dev;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
+    if (mid && (e = hipEventRecord(mid, stream)) != hipSuccess) return e;
     // What the flags of the reads mean, and the count tiles' way into the accumulator: one workgroup per tile.
     // The flagged entries' lists may still be in the making on the side stream (build_flagged_lists).
     if (side && side->stream) {
@@ -1703,7 +1705,8 @@ StageGeometry stage_geometry(uint32_t block_cells) {
 }
 
 hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, bool stage_masks,
-                             bool count_tile, uint32_t n_tiles, hipStream_t stream, const SideStream *side) {
+                             bool count_tile, uint32_t n_tiles, hipStream_t stream, const SideStream *side,
+                             hipEvent_t mid) {
     if (n_tiles == 0) return hipSuccess;
     const uint32_t grid = args.n_workgroups;
     const bool counts_path = count_tile && !stage_masks && pair_mode() != 0;
@@ -1722,20 +1725,20 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
         // the 128 KiB int64 tile leaves no room for the window masks: joint terms go through HBM
         if (count_tile && pair_mode() != 0) {
             static const int g = [] { const char *e = std::getenv("SECEDO_GROUP"); return e ? std::atoi(e) : 0; }();
-            if (g == 1) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 1>(args, grid, stream, side);
-            if (g == 3) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 3>(args, grid, stream, side);
-            if (g == 4) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 4>(args, grid, stream, side);
+            if (g == 1) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 1>(args, grid, stream, side, mid);
+            if (g == 3) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 3>(args, grid, stream, side, mid);
+            if (g == 4) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 4>(args, grid, stream, side, mid);
             if (g == 2 || (g == 0 && args.group_hint == 2))
-                return launch_counts<128, 1024, kCapJ128C, kCapL128C, 2>(args, grid, stream, side);
+                return launch_counts<128, 1024, kCapJ128C, kCapL128C, 2>(args, grid, stream, side, mid);
             if (g == 0 && args.group_hint == 3)
-                return launch_counts<128, 1024, kCapJ128C, kCapL128C, 3>(args, grid, stream, side);
-            return launch_counts<128, 1024, kCapJ128C, kCapL128C, 4>(args, grid, stream, side);
+                return launch_counts<128, 1024, kCapJ128C, kCapL128C, 3>(args, grid, stream, side, mid);
+            return launch_counts<128, 1024, kCapJ128C, kCapL128C, 4>(args, grid, stream, side, mid);
         }
         if (count_tile) return launch_acc<128, 1024, kCapJ128C, kCapL128C, 1024, false, true>(args, grid, stream);
         return launch_acc<128, 1024, kCapJ128, kCapL128, 512, false, false>(args, grid, stream);
     }
     if (stage_masks) return launch_acc<64, 512, kCapJ64M, kCapL64M, 1024, true, false>(args, grid, stream);
-    if (count_tile && pair_mode() != 0) return launch_counts<64, 512, kCapJ64C, kCapL64C, 4>(args, grid, stream, side);
+    if (count_tile && pair_mode() != 0) return launch_counts<64, 512, kCapJ64C, kCapL64C, 4>(args, grid, stream, side, mid);
     if (count_tile) return launch_acc<64, 256, kCapJ64C, kCapL64C, 1024, false, true>(args, grid, stream);
     return launch_acc<64, 256, kCapJ64, kCapL64, 1024, false, false>(args, grid, stream);
 }

@@ -105,8 +105,11 @@ struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
+// mid: when non-null, recorded on `stream` between the pair kernel and what follows it (the duration of the
+// dominant kernel by itself: secedo_simmat_last_pair_kernel_ms)
 hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, bool stage_masks,
-                             bool count_tile, uint32_t n_tiles, hipStream_t stream, const SideStream *side = nullptr);
+                             bool count_tile, uint32_t n_tiles, hipStream_t stream, const SideStream *side = nullptr,
+                             hipEvent_t mid = nullptr);
 
 // mode 0..2 = SECEDO_NORM_*, 3 = raw D
 hipError_t launch_finalize(const int64_t *acc, const uint16_t *tile_row, const uint16_t *tile_col, uint32_t n_tiles,

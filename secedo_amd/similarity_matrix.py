@@ -341,6 +341,13 @@ class SimilarityMatrixPlan:
         _lib.check(_lib.lib().secedo_simmat_last_counts(self._h, C.byref(u), C.byref(r)))
         return int(u.value), int(r.value)
 
+    def last_pair_kernel_ms(self):
+        """Device time of accumulate_counts in the last accumulate (None when another kernel variant ran)."""
+        ms = C.c_float(0.0)
+        if _lib.lib().secedo_simmat_last_pair_kernel_ms(self._h, C.byref(ms)) != 0:
+            return None
+        return float(ms.value)
+
     def last_accumulate_ms(self) -> float:
         ms = C.c_float()
         _lib.check(_lib.lib().secedo_simmat_last_accumulate_ms(self._h, C.byref(ms)))
