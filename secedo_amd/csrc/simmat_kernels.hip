@@ -1203,7 +1203,7 @@ __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
     __shared__ long long part[2 * (THREADS / 64)];
     // the correction D(x_s,x_d) - x_s D(1,0) - x_d D(0,1) itself for few shared loci (the usual case)
     __shared__ long long scorr[SLUT_DIM * SLUT_DIM];
-    constexpr int U = 4;  // flagged entries p per thread in flight: their loads are issued together
+    constexpr int U = 6;  // flagged entries p per thread in flight: their loads are issued together
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t S = a.split, t_local = blockIdx.x / S, part_id = blockIdx.x % S;
     const uint32_t t = a.tile_ids ? a.tile_ids[t_local] : a.tile_begin + t_local;
@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
     const size_t rowI = (size_t)I * a.stride, rowJ = (size_t)J * a.stride;
     const uint32_t p0 = a.flag_grp[rowI], p1 = a.flag_grp[rowI + a.stride - 1u];
     for (uint32_t base = p0 + part_id * (uint32_t)(THREADS * U); base < p1; base += S * (uint32_t)(THREADS * U)) {
-        uint4 A1[U], A2[U];
+        uint4 A1[U];
         uint32_t qa[U], qb[U];
 #ifdef SECEDO_STAMPS
         const long long dg_b0 = __builtin_readcyclecounter();
@@ -1244,12 +1244,11 @@ __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
             qb[u] = p < p1 ? a.flag_grp[g + 1] : 0u;
             if (diag) qa[u] = p + 1u;  // p lies in its own group: every pair once
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) A2[u] = qa[u] < qb[u] ? a.flag_rec[qa[u]] : make_uint4(0, 0, 0, 0);
-        // (advancing the q of all U entries together, U loads per round trip, was no faster on C3 and slower
-        // on C2: the rounds are set by the longest list among the lanes either way)
+        // (six entries in flight and no prefetch of the first q record: 103 VGPRs; with the prefetch four fit,
+        // and eight spill. Advancing the q of all entries together, U loads per round trip, was no faster on C3
+        // and slower on C2: the rounds are set by the longest list among the lanes either way.)
 #ifdef SECEDO_STAMPS
-        dg_sink += A2[0].x + A2[U - 1].x;  // (the loads have arrived)
+        dg_sink += qa[0] + qb[U - 1];  // (the loads have arrived)
         const long long dg_b1 = __builtin_readcyclecounter();
         dg_loads += dg_b1 - dg_b0;
 #endif
@@ -1263,7 +1262,7 @@ __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
 #ifdef SECEDO_STAMPS
                 const long long dg_q0 = __builtin_readcyclecounter();
 #endif
-                const uint4 Q = q == qa[u] ? A2[u] : a.flag_rec[q];
+                const uint4 Q = a.flag_rec[q];
                 const uint32_t row2 = (Q.x & 0xFFFFu) - J * B;
 #ifdef SECEDO_STAMPS
                 dg_sink += row2;
