@@ -1644,10 +1644,13 @@ hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t 
 }
 
 // acc[tile] = 0 for the listed tiles (16 bytes per thread)
-__global__ __launch_bounds__(256) void zero_tiles(long long *acc, const uint32_t *tile_ids, uint32_t tile_elems) {
-    ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(acc + (size_t)tile_ids[blockIdx.y] * tile_elems);
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < tile_elems / 2; i += gridDim.x * 256)
-        dst[i] = make_ulonglong2(0ull, 0ull);
+__global__ __launch_bounds__(256) void zero_tiles(long long *acc, const uint32_t *tile_ids, uint32_t n_tiles,
+                                                 uint32_t tile_elems) {
+    for (uint32_t t = blockIdx.y; t < n_tiles; t += gridDim.y) {
+        ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(acc + (size_t)tile_ids[t] * tile_elems);
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < tile_elems / 2; i += gridDim.x * 256)
+            dst[i] = make_ulonglong2(0ull, 0ull);
+    }
 }
 
 int pair_mode() {
@@ -1712,8 +1715,8 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
     if (args.overwrite && !counts_path) {  // (accumulate_counts + correct_tiles store the tiles themselves)
         const uint32_t tile_elems = block_cells * block_cells;
         if (args.tile_ids) {
-            hipLaunchKernelGGL(zero_tiles, dim3(8, n_tiles), dim3(256), 0, stream, reinterpret_cast<long long *>(args.acc),
-                               args.tile_ids, tile_elems);
+            hipLaunchKernelGGL(zero_tiles, dim3(8, std::min(n_tiles, 65535u)), dim3(256), 0, stream,
+                               reinterpret_cast<long long *>(args.acc), args.tile_ids, n_tiles, tile_elems);
         } else {
             const hipError_t e = hipMemsetAsync(args.acc + (size_t)args.tile_begin * tile_elems, 0,
                                                 (size_t)n_tiles * tile_elems * 8, stream);
