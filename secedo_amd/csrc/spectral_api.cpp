@@ -77,7 +77,7 @@ struct Solver {
     const double *A = nullptr;  // rows [row_begin, row_begin + n_rows) of the matrix
     secedo_allreduce_sum_fn allreduce = nullptr;
     void *allreduce_ctx = nullptr;
-    Buf s, root, sums, Q, W, W2, Z, P, Ypart, Gp, G, Gall, M, Rfirst, Rblk, alive_dev;
+    Buf s, root, sums, Q, W, W2, Wtmp, Z, P, Ypart, Gp, G, Gall, M, Rfirst, Rblk, alive_dev;
     size_t blk_stride = 0;
 
     int setup(const double *d_rows, uint32_t row_begin_, uint32_t n_rows_, uint32_t n_, secedo_allreduce_sum_fn fn,
@@ -98,6 +98,7 @@ struct Solver {
         SP_TRY(Q.alloc((kCycleBlocks + 1) * blk_stride * 8));
         SP_TRY(W.alloc(blk_stride * 8));
         SP_TRY(W2.alloc(blk_stride * 8));
+        SP_TRY(Wtmp.alloc(blk_stride * 8));
         SP_TRY(Z.alloc(((size_t)pad16(n) + 64) * BW * 8));
         SP_TRY(P.alloc((size_t)product_segments(n, n_rows) * pad16(n) * BW * 8));
         SP_TRY(Gp.alloc((size_t)gram_chunks(n) * (kCycleBlocks + 1) * BW * BW * 8));
@@ -131,7 +132,10 @@ struct Solver {
     // y = T x
     int product(const double *x, double *y) {
         using namespace secedo::spectral;
-        SP_TRY(product_partial(A, n, row_begin, n_rows, s.d(), x, Z.d(), P.d(), Ypart.d(), stream));
+        // (one rank: the segments' sum and the finishing step in one kernel)
+        SP_TRY(product_partial(A, n, row_begin, n_rows, s.d(), x, Z.d(), P.d(), allreduce ? Ypart.d() : nullptr,
+                               allreduce ? nullptr : y, stream));
+        if (!allreduce) return SECEDO_OK;
         const int rc = reduce_ranks(Ypart.d(), blk_stride);
         if (rc) return rc;
         SP_TRY(product_finish(n, s.d(), x, Ypart.d(), y, stream));
@@ -141,7 +145,7 @@ struct Solver {
         SP_TRY(hipMemcpyAsync(M.d(), m.data(), m.size() * 8, hipMemcpyHostToDevice, stream));
         return SECEDO_OK;
     }
-    // Q[blk] = orthonormalised src (Cholesky QR, twice; src is overwritten). Nothing comes back to the
+    // Q[blk] = orthonormalised src (Cholesky QR, twice, through Wtmp; src keeps its contents). Nothing comes back to the
     // host here: R with src = Q[blk] R goes to Rblk[blk] and the surviving columns to alive_dev[blk], which
     // the cycle reads once, with the Gram-Schmidt coefficients.
     int orthonormalise(double *src, uint32_t blk) {
@@ -151,11 +155,11 @@ struct Solver {
         uint32_t *alive = static_cast<uint32_t *>(alive_dev.p) + (size_t)blk * BW;
         SP_TRY(gram(n, src, blk_stride, 1, src, Gp.d(), G.d(), stream));
         SP_TRY(cholesky_drop(G.d(), nullptr, M.d(), Rfirst.d(), nullptr, stream));
-        SP_TRY(block_combine(n, src, blk_stride, 1, M.d(), 1.0, 0.0, dst, stream));
-        SP_TRY(gram(n, dst, blk_stride, 1, dst, Gp.d(), G.d(), stream));
+        double *tmp = Wtmp.d();
+        SP_TRY(block_combine(n, src, blk_stride, 1, M.d(), 1.0, 0.0, tmp, stream));
+        SP_TRY(gram(n, tmp, blk_stride, 1, tmp, Gp.d(), G.d(), stream));
         SP_TRY(cholesky_drop(G.d(), Rfirst.d(), M.d(), R, alive, stream));
-        SP_TRY(block_combine(n, dst, blk_stride, 1, M.d(), 1.0, 0.0, src, stream));
-        SP_TRY(hipMemcpyAsync(dst, src, blk_stride * 8, hipMemcpyDeviceToDevice, stream));
+        SP_TRY(block_combine(n, tmp, blk_stride, 1, M.d(), 1.0, 0.0, dst, stream));
         return SECEDO_OK;
     }
 };

@@ -172,14 +172,16 @@ __global__ __launch_bounds__(256) void k_product_partial(const double *A_rows, u
     }
 }
 
-// Ypart[i][c] = sum_seg P[seg][i][c], segments added in order
+// Ypart[i][c] = sum_seg P[seg][i][c], segments added in order; or, when there is nothing to add from other
+// ranks (Y != null), the finished product at once: Y[i][c] = (X[i][c] + s[i] * sum) / 2 (k_product_finish)
 __global__ __launch_bounds__(256) void k_product_reduce(uint32_t n, uint32_t n_seg, uint32_t n_pad16, const double *P,
-                                                       double *Ypart) {
+                                                       double *Ypart, const double *s, const double *X, double *Y) {
     const size_t total = (size_t)n * BW;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         double sum = 0.0;
         for (uint32_t g = 0; g < n_seg; ++g) sum += P[(size_t)g * n_pad16 * BW + idx];
-        Ypart[idx] = sum;
+        if (Y) Y[idx] = 0.5 * (X[idx] + s[idx / BW] * sum);
+        else Ypart[idx] = sum;
     }
 }
 
@@ -415,7 +417,8 @@ uint32_t product_segments(uint32_t n, uint32_t n_rows) {
 }
 
 hipError_t product_partial(const double *A_rows, uint32_t n, uint32_t row_begin, uint32_t n_rows, const double *s,
-                           const double *X, double *Z, double *P, double *Ypart, hipStream_t stream) {
+                           const double *X, double *Z, double *P, double *Ypart, double *Y_finished,
+                           hipStream_t stream) {
     const uint32_t nz = pad16(n) + kProdRows, n16 = pad16(n), n_seg = product_segments(n, n_rows);
     const uint32_t seg_rows = ((n_rows + n_seg - 1u) / n_seg + kProdRows - 1u) / kProdRows * kProdRows;
     hipLaunchKernelGGL(k_scale_rows, dim3(grid_for((size_t)nz * BW)), dim3(256), 0, stream, n, nz, s, X, Z);
@@ -423,7 +426,7 @@ hipError_t product_partial(const double *A_rows, uint32_t n, uint32_t row_begin,
         hipLaunchKernelGGL(k_product_partial, dim3((n16 + 127u) / 128u, n_seg), dim3(256), 0, stream, A_rows, n, row_begin,
                            n_rows, Z, seg_rows, n16, P);
     hipLaunchKernelGGL(k_product_reduce, dim3(grid_for((size_t)n * BW)), dim3(256), 0, stream, n, n_rows ? n_seg : 0u,
-                       n16, P, Ypart);
+                       n16, P, Ypart, s, X, Y_finished);
     return hipGetLastError();
 }
 

@@ -33,9 +33,11 @@ inline uint32_t pad16(uint32_t n) { return (n + 15u) / 16u * 16u; }
 // of the symmetric A can add their parts in between:
 //   product_partial  Ypart = sum over the local rows j of (s[j] X[j]) A[j][:]      (n x 32)
 //   product_finish   Y = (X + s o Ysum) / 2, Ysum = the sum of all ranks' Ypart
-// Z ((pad16(n) + 64) x 32) and P (segments x pad16(n) x 32) are scratch.
+// Z ((pad16(n) + 64) x 32) and P (segments x pad16(n) x 32) are scratch. A single rank passes Y_finished
+// (and no Ypart): the last kernel of product_partial then finishes the product itself.
 hipError_t product_partial(const double *A_rows, uint32_t n, uint32_t row_begin, uint32_t n_rows, const double *s,
-                           const double *X, double *Z, double *P, double *Ypart, hipStream_t stream);
+                           const double *X, double *Z, double *P, double *Ypart, double *Y_finished,
+                           hipStream_t stream);
 hipError_t product_finish(uint32_t n, const double *s, const double *X, const double *Ysum, double *Y,
                           hipStream_t stream);
 
