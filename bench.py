@@ -20,6 +20,14 @@ With N > 1 both ways of sharing the matrix are timed, K steps each:
   * chromosomes: every rank packs and accumulates only its chromosomes, for all tiles, one all-reduce
     (sum) of the accumulator.
 `value` is the faster of the two (named in config.parallelism); both are in `partitionings`.
+`--workload C5 --gpus N` times BASELINE configs[4] as written instead: the matrix kept sharded by rows (no
+all-gather) and fed to the distributed spectral step, both phases reported.
+The K-step block is timed `--repeats` times (5): the line carries the median block, all blocks and the spread.
+After the timed region the last output is held against the compiled reference's sampled entries where a digest
+exists (C3, C2): `parity_checked`.
+`roofline` is stated against the limit that binds the dominant kernel: LDS atomics at random addresses (peak
+measured by tools/lds_atomic_bench on the same box); the HBM figures (measured traffic, and SURVEY 8d's
+algorithmic-bytes accounting under `b_alg`) are beside it.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -35,6 +43,42 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_ROUND = "r03"   # profiles/<round>_*.json: the counter-derived inputs of the roofline record
+
+
+def lds_atomic_peak():
+    """Peak of the instruction the pair kernel is bound by -- random-address ds_add_u32 -- in 1e9 atomics/s for
+    the whole chip: measured live by tools/lds_atomic_bench.bin (a child process, < 1 s; built by make) where it
+    runs, else the committed measurement. -> (peak, source, whole record)"""
+    exe = os.path.join(ROOT, "tools", "lds_atomic_bench.bin")
+    try:
+        r = subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=120)
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        return rec["peak_random_gatomic_per_s"], "tools/lds_atomic_bench.bin --json, this run", rec
+    except (OSError, subprocess.SubprocessError, ValueError, IndexError, KeyError):
+        pass
+    try:
+        with open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_lds_atomic_peak.json")) as fh:
+            rec = json.load(fh)
+        return rec["peak_random_gatomic_per_s"], "profiles/%s_lds_atomic_peak.json" % PROFILE_ROUND, rec
+    except (OSError, ValueError, KeyError):
+        return None, None, None
+
+
+def reference_digest(workload, clustered, n_entries, rates, mfl, threads):
+    """Sampled entries of the COMPILED REFERENCE's output for this workload (tests/golden/c?_reference_digest.npz,
+    written by oracle/gen_golden.py from oracle/_ref in the build container), if the parameters are the digest's."""
+    import numpy as np
+    if clustered or workload not in ("C2", "C3"):
+        return None
+    try:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "%s_reference_digest.npz" % workload.lower()))
+    except OSError:
+        return None
+    want = [mfl, rates[0], rates[1], rates[2], threads, 0]
+    if int(z["n_entries"]) != n_entries or [float(v) for v in z["params"][1:]] != [float(v) for v in want]:
+        return None
+    return z
 
 
 def cpu_baseline(p, n_cells, mfl, rates, threads, budget_updates):
@@ -85,6 +129,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step block is timed this many times; the line reports the median block and the spread")
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--clustered", action="store_true", help="gap_max=300 variant (~2.8 loci/read)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,6 +140,9 @@ def parse_args(argv=None):
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--only", default="both", choices=["both", "tiles", "chromosomes"],
                     help="N > 1: time only one of the two partitionings")
+    ap.add_argument("--gathered", action="store_true",
+                    help="N > 1 with --workload C5: gather the matrix like C3 instead of BASELINE configs[4] "
+                         "(sharded rows + distributed spectral step)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: start the ranks, rendezvous (gloo), shard the "
                          "pileup both ways, exchange the shard sizes, print them -- no HIP call anywhere")
@@ -222,13 +271,22 @@ def main():
             step()
         sync()
         local_updates, local_pairs = plan.last_counts()  # exact integer work counters of one pass
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        elapsed = time.perf_counter() - t0
+        # EXACTLY K steps between barrier + synchronize on both sides, `--repeats` times over; the reported block
+        # is the median one (max over ranks of each block first), the others give the spread
+        blocks = []
+        for _ in range(max(1, args.repeats)):
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            sync()
+            blocks.append(time.perf_counter() - t0)
         last_ms = plan.last_accumulate_ms()  # HIP events recorded by the library on the launch stream
+        bt = torch.tensor(blocks, dtype=torch.float64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+        blocks = sorted(float(v) for v in bt)
+        elapsed = blocks[len(blocks) // 2]
 
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         own = by_chromosome or rank == 0
@@ -239,9 +297,104 @@ def main():
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         updates, pairs, kept_entries, reads = (int(v.item()) for v in cnt)
         return dict(by_chromosome=by_chromosome, plan=plan, resident=resident, acc=acc, my_tiles=my_tiles,
-                    block_cells=block_cells, elapsed=float(t.item()), updates=updates, pairs=pairs,
+                    block_cells=block_cells, elapsed=float(t.item()), blocks=blocks, updates=updates, pairs=pairs,
                     kept_entries=kept_entries, reads=reads, local_updates=local_updates, last_ms=last_ms,
                     prepare_s=prepare_s)
+
+    def run_config5():
+        """BASELINE.json configs[4] as written: the matrix kept sharded by rows (NO all-gather: every rank
+        accumulates the tiles that touch its rows, one scalar max-reduce, each normalises its row block) and fed
+        to the distributed spectral step (row-block products, one all-reduce of N x 32 fp64 per product)."""
+        plan = secedo_amd.SimilarityMatrixPlan(local_rank)
+        resident = plan.upload(p, None, n_cells)
+        t0 = time.perf_counter()
+        plan.prepare_resident(resident, n_cells, mfl, threads)
+        torch.cuda.synchronize()
+        prepare_s = time.perf_counter() - t0
+        acc = plan.new_acc()
+        lo, hi = sd.row_range(n_cells, rank, world, plan.block_cells)
+        ids = plan.tiles_of_rows(lo, hi)
+        # exact work counters of the whole matrix: every tile counted once, by the rank that owns its row block
+        nb = -(-n_cells // plan.block_cells)
+        t_row = np.concatenate([np.full(nb - i, i, dtype=np.int64) for i in range(nb)])
+        own = ids[(t_row[ids] * plan.block_cells >= lo) & (t_row[ids] * plan.block_cells < hi)]
+        plan.accumulate_list(acc, *rates, own, overwrite=True)
+        torch.cuda.synchronize()
+        own_updates, own_pairs = plan.last_counts() if len(own) else (0, 0)
+        state = {}
+
+        def matrix_step():
+            if not args.packed_resident:
+                plan.prepare_resident(resident, n_cells, mfl, threads)
+            state["rows"], state["lo"] = sd.sharded_rows(plan, acc, *rates, rank, world, norm)
+
+        def spectral_step():
+            state["eig"] = sd.sharded_eigenpairs(state["rows"], state["lo"], n_cells)
+
+        def step():
+            matrix_step()
+            spectral_step()
+
+        for _ in range(args.warmup):
+            step()
+        blocks = []
+        for _ in range(max(1, args.repeats)):
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            sync()
+            blocks.append(time.perf_counter() - t0)
+        phases = {}
+        for name, fn in (("matrix_sharded_rows_ms", matrix_step), ("spectral_sharded_ms", spectral_step)):
+            ts = []
+            for _ in range(3):
+                sync()
+                t0 = time.perf_counter()
+                fn()
+                sync()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            phases[name] = sorted(ts)[1]
+        bt = torch.tensor(blocks + [phases["matrix_sharded_rows_ms"], phases["spectral_sharded_ms"]],
+                          dtype=torch.float64, device=red_dev)
+        cnt = torch.tensor([own_updates, own_pairs, len(ids)], dtype=torch.int64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        blocks = sorted(float(v) for v in bt[:-2])
+        elapsed = blocks[len(blocks) // 2]
+        if rank == 0:
+            vals, _, info = state["eig"]
+            step_s = elapsed / args.steps
+            updates = int(cnt[0].item())
+            print(json.dumps({
+                "metric": "cell-pair x locus updates/sec (similarity matrix)", "value": updates / step_s,
+                "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "int64", "data": "synthetic (SYNTH-v1, seed 42)",
+                "config": {"workload": "%s: %d cells x %d loci, matrix kept sharded by rows (no all-gather) + distributed "
+                                       "spectral step (BASELINE configs[4])" % (args.workload, n_cells, n_loci),
+                           "updates_per_step": updates, "read_pairs_per_step": int(cnt[1].item()),
+                           "tiles": plan.num_tiles, "tiles_accumulated_over_all_ranks": int(cnt[2].item()),
+                           "block_cells": plan.block_cells, "normalization": norm,
+                           "parallelism": "row blocks/%d: tiles touching own rows + scalar max all-reduce; spectral: "
+                                          "row-block products + all-reduce of N x 32 fp64" % world,
+                           "backend": backend_name, "world_size": world, "rccl_world_size": pg_world},
+                "block_ms": [b / args.steps * 1e3 for b in blocks],
+                "spread": (blocks[-1] - blocks[0]) / elapsed if elapsed else None,
+                "phase_ms": {"matrix_sharded_rows": float(bt[-2].item()), "spectral_sharded": float(bt[-1].item())},
+                "spectral": {"smallest_eigenvalues": [float(v) for v in vals[:4]], **info},
+                "first_prepare_s": prepare_s, "step_includes_packing": not args.packed_resident,
+                "roofline": None, "cpu_baseline": None,
+            }), flush=True)
+
+    backend_name = "none" if world == 1 else ("RCCL (nccl)" if args.backend == "nccl" else args.backend)
+    pg_world = dist.get_world_size() if world > 1 else 1   # read back from the process group, not from argv
+    if world > 1 and args.workload == "C5" and not args.gathered:
+        run_config5()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     modes = []
     if world == 1:
@@ -255,6 +408,23 @@ def main():
     plan, acc, resident = best["plan"], best["acc"], best["resident"]
     by_chromosome, block_cells, my_tiles = best["by_chromosome"], best["block_cells"], best["my_tiles"]
     elapsed, updates = best["elapsed"], best["updates"]
+
+    # parity of the LAST TIMED OUTPUT (outside the timed region): `out` still holds what the last timed step of
+    # the last partitioning wrote; held against the compiled reference's sampled entries where a digest exists
+    parity = None
+    digest = reference_digest(args.workload, args.clustered, int(p.n_entries), rates, mfl, threads) if rank == 0 else None
+    if digest is not None:
+        ii = torch.from_numpy(digest["sample_i"].astype(np.int64)).to(out.device)
+        jj = torch.from_numpy(digest["sample_j"].astype(np.int64)).to(out.device)
+        err = np.abs(out[ii, jj].cpu().numpy() - digest["sample_v"])
+        ref_max = float(digest["max_abs"])
+        parity = {"checked": True, "against": "compiled reference (oracle/_ref), tests/golden/%s_reference_digest.npz"
+                                              % args.workload.lower(),
+                  "samples": int(len(err)), "normwise_err": float(err.max() / ref_max), "tolerance": 1e-9,
+                  "max_abs_matches": bool(abs(float(out.abs().max()) - ref_max) <= 1e-9 * ref_max),
+                  "symmetric": bool(torch.equal(out, out.T)), "zero_diagonal": not bool(torch.any(torch.diagonal(out)))}
+        parity["ok"] = bool(parity["normwise_err"] <= 1e-9 and parity["max_abs_matches"] and parity["symmetric"]
+                            and parity["zero_diagonal"])
 
     # phase times of one step of the reported partitioning, events on the launch stream (torch's current one)
     phase = {}
@@ -279,39 +449,81 @@ def main():
         phase[name] = sorted(ts)[len(ts) // 2]
     # per-launch kernel time over K launches with events on the launch stream
     lo, hi = my_tiles
-    evs = []
+    evs, pair_samples = [], []
     for _ in range(min(args.steps, 10)):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         plan.accumulate(acc, *rates, lo, hi, overwrite=True)
         b.record()
         evs.append((a, b))
+        pm = plan.last_pair_kernel_ms()  # the pair kernel alone in this launch (HIP events of the library)
+        if pm:
+            pair_samples.append(pm)
     torch.cuda.synchronize()
     ev_ms = sorted(a.elapsed_time(b) for a, b in evs)
     kern_ms = ev_ms[len(ev_ms) // 2]
-    pair_ms = plan.last_pair_kernel_ms()  # accumulate_counts alone in the last of these launches (HIP events)
+    pair_ms = sorted(pair_samples)[len(pair_samples) // 2] if pair_samples else None
 
     if rank == 0:
-        # HBM bytes per accumulate launch from separate rocprofv3 --pmc passes over this same command
-        # (tools/collect_traffic.sh -> profiles/r02_traffic.json; FETCH_SIZE doubled as the microarch guide
-        # prescribes for gfx950); null when no pass was taken for this workload
-        traffic = traffic_src = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
-                t = json.load(fh).get(args.workload if not args.clustered and world == 1 else "")
-            if t:
-                traffic = t["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r02_traffic.json (%s)" % t.get("source", "rocprofv3 --pmc")
-        except (OSError, ValueError, KeyError):
-            traffic = None
+        # counter-derived inputs: HBM bytes per launch (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
+        # this same command, calibrated as the microarch guide prescribes) and the SQ counters of the pair kernel
+        key = args.workload if world == 1 else ""
+        key += "_clustered" if args.clustered and key else ""
+        traffic_rec = counters = None
+        for name in ("traffic", "counters"):
+            try:
+                with open(os.path.join(ROOT, "profiles", "%s_%s.json" % (PROFILE_ROUND, name))) as fh:
+                    rec = json.load(fh).get(key)
+            except (OSError, ValueError):
+                rec = None
+            if name == "traffic":
+                traffic_rec = rec
+            else:
+                counters = rec
         E, L, N = plan.num_entries, plan.num_loci, n_cells
         local_updates = best["local_updates"]
         # this rank's launch: its tiles of the whole pileup, or all tiles of its chromosomes
         b_alg = (16 * local_updates + 6 * E + 4 * L + 16 * N * N if by_chromosome
                  else 16 * local_updates + 6 * E / world + 4 * L + 16 * N * N / world)
         b_alg_step = 16 * updates + 6 * best["kept_entries"] + 4 * n_loci + 16 * N * N  # the whole job
-        achieved = b_alg / (kern_ms * 1e-3) / 1e9
         step_s = elapsed / args.steps
+        dom_ms = pair_ms if pair_ms else kern_ms
+        dom_name = ("accumulate_counts" if pair_ms else
+                    "accumulate_tiles (+ reduce_slabs: the kernels of one accumulate)")
+        peak, peak_src, peak_rec = lds_atomic_peak()
+        # one LDS atomic per update in both pair kernels (ds_add_u32 into the count tile / ds_add_u64 into the int64 tile)
+        achieved = local_updates / (dom_ms * 1e-3) / 1e9
+        roofline = {
+            # The binding limit (PMC: profiles/r03_pmc_*.txt): the updates are LDS atomics at random addresses of
+            # the workgroup's tile; HBM carries 0.1 of the brief's per-update byte count and runs at < 0.25 of peak.
+            "bound": "lds_atomic", "achieved": achieved, "peak": peak, "unit": "Gatomic/s",
+            "frac": (achieved / peak) if peak else None,
+            "peak_source": peak_src,
+            "peak_bank_conflict_free": peak_rec.get("peak_bank_conflict_free_gatomic_per_s") if peak_rec else None,
+            "kernel": dom_name, "kernel_ms": dom_ms, "updates_per_launch": local_updates,
+            "accumulate_phase_ms": kern_ms, "kernel_ms_last_timed_step": best["last_ms"],
+            # HBM bytes of the dominant kernel per launch, and the fraction of the HBM peak they amount to
+            "traffic": traffic_rec["hbm_bytes_per_launch"] if traffic_rec else None,
+            "traffic_source": ("profiles/%s_traffic.json (%s)" % (PROFILE_ROUND, traffic_rec.get("source", "rocprofv3 --pmc")))
+            if traffic_rec else None,
+            "hbm_frac_measured": (traffic_rec["hbm_bytes_per_launch"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS)
+            if traffic_rec else None,
+            # SURVEY 8d's contract figure, NOT a fraction of anything physical: 16 B per update are charged to HBM
+            # although the updates land in LDS (SURVEY 8d foresees values above 1 for such a design)
+            "b_alg": {"algorithmic_bytes": b_alg, "gbps_over_accumulate_phase": b_alg / (kern_ms * 1e-3) / 1e9,
+                      "b_alg_frac": b_alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                      "whole_step_b_alg_frac": b_alg_step / step_s / 1e9 / HBM_PEAK_GBPS / world},
+        }
+        if counters:
+            # VALU issue: a wave64 VALU instruction occupies its SIMD's issue port for 2 cycles on gfx950 (guide)
+            cyc = counters.get("GRBM_GUI_ACTIVE") or counters.get("kernel_cycles")
+            if cyc and counters.get("SQ_INSTS_VALU"):
+                roofline["valu_issue_frac"] = counters["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cyc)
+            if counters.get("SQ_WAIT_ANY") and counters.get("SQ_WAVE_CYCLES"):
+                roofline["wait_frac_of_wave_cycles"] = counters["SQ_WAIT_ANY"] / counters["SQ_WAVE_CYCLES"]
+            if counters.get("SQ_LDS_BANK_CONFLICT") and counters.get("SQ_LDS_IDX_ACTIVE"):
+                roofline["lds_bank_conflict_frac"] = counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"]
+            roofline["counters_source"] = "profiles/%s_counters.json" % PROFILE_ROUND
         line = {
             "metric": "cell-pair x locus updates/sec (similarity matrix)",
             "value": updates * args.steps / elapsed,
@@ -335,10 +547,15 @@ def main():
                                 "chromosomes/%d (packing + accumulation) + all-reduce of the int64 accumulator" % world
                                 if by_chromosome else "tiles/%d (replicated packing) + all-gather of the int64 "
                                                       "accumulator" % world),
-                "backend": "none" if world == 1 else ("RCCL (nccl)" if args.backend == "nccl" else args.backend),
-                "world_size": world,
+                "backend": backend_name, "world_size": world, "rccl_world_size": pg_world,
                 # tiles mode: every rank packs the whole pileup, only the pair accumulation is divided
                 "replicated_ms_per_step": phase.get("pack_ms") if world > 1 and not by_chromosome else None},
+            # the K-step block, timed `repeats` times: value / ms_per_step are the median block's
+            "repeats": len(best["blocks"]),
+            "block_ms_per_step": [b / args.steps * 1e3 for b in best["blocks"]],
+            "spread": (best["blocks"][-1] - best["blocks"][0]) / elapsed if elapsed else None,
+            "parity_checked": bool(parity and parity["ok"]),
+            "parity": parity,
             "partitionings": {("chromosomes+all-reduce" if m["by_chromosome"] else "tiles+all-gather"):
                               {"ms_per_step": m["elapsed"] / args.steps * 1e3,
                                "updates_per_s": m["updates"] * args.steps / m["elapsed"]} for m in modes},
@@ -349,26 +566,7 @@ def main():
             "phase_ms": {"pack": phase["pack_ms"], "accumulate": kern_ms, "finalize": phase["finalize_ms"]},
             "first_prepare_s": best["prepare_s"],
             "scale_log2": plan.scale_log2,
-            # SURVEY 8d accounting: achieved = ALGORITHMIC bytes of one accumulate launch / its duration.
-            # The updates land in LDS, so this is not HBM use: `traffic` is; the kernel's real limiter is
-            # vector-instruction issue (profiles/r02_pmc_C3.txt).
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "accumulate_counts (pair kernel) + correct_tiles (flagged reads, slab reduction): "
-                                   "the kernels of one accumulate", "kernel_ms": kern_ms,
-                         "kernel_ms_last_timed_step": best["last_ms"],
-                         # the dominant kernel by itself, to be held against its average in the committed
-                         # rocprofv3 kernel stats (profiles/r02_C3_kernel_stats.csv)
-                         "dominant_kernel": "accumulate_counts" if pair_ms else None,
-                         "dominant_kernel_ms": pair_ms,
-                         "achieved_dominant_kernel": (b_alg / (pair_ms * 1e-3) / 1e9) if pair_ms else None,
-                         "algorithmic_bytes": b_alg,
-                         "hbm_frac_measured": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                         "limiter": "vector-instruction issue (about 60 % of the SIMD cycles) and the LDS pipeline (about 40 %) "
-                                    "with 4 waves per SIMD (profiles/r02_pmc_C3.txt)",
-                         "whole_step": {"algorithmic_bytes": b_alg_step,
-                                        "achieved": b_alg_step / step_s / 1e9,
-                                        "frac": b_alg_step / step_s / 1e9 / HBM_PEAK_GBPS / world}},
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
             # the drop-in call itself: host buffers in, host matrix out (H2D, pack, accumulate, normalise,

@@ -138,13 +138,20 @@ uint64_t secedo_simmat_num_reads(const secedo_simmat_t *handle);
 uint64_t secedo_simmat_num_loci(const secedo_simmat_t *handle);
 
 /* Fixed-point scale of the accumulator. The int64 accumulators hold D * 2^scale_log2; the scale is 44 unless
- * the pileup's pair bound (an upper bound on the (read pair, shared locus) incidences one cell pair can
- * collect) says an int64 could overflow. Accumulators that are ADDED UP across handles -- chromosome shards
- * on several GPUs -- must share one scale: every rank reads its shard's bound after prepare(), the ranks
- * sum the bounds (the bound of the union is at most the sum), and every rank sets the sum before
- * accumulate(), ranks with an empty shard included. 0 restores the handle's own bound. scale_log2() is the
- * scale of the last accumulate(). */
+ * an int64 could overflow: |sum of one cell pair| <= pair bound (an upper bound on the (read pair, shared
+ * locus) incidences one cell pair can collect: the largest per-row sum over loci of squared entry counts) x
+ * the largest |D(x_s, x_d)| / (x_s + x_d) among the table entries the pileup can reach (x_s + x_d <= kept
+ * entries of its longest read). With the reference's default rates that leaves 44 up to ~1e7 incidences per
+ * cell pair. Accumulators that are ADDED UP across handles -- chromosome shards on several GPUs -- must
+ * share one scale: every rank reads its shard's per-row squares (cell_squares: num_cells uint64 in device
+ * memory) and longest read after prepare(), the ranks sum the vectors and take the maximum (the exact bound
+ * of the union) and the maximum of the read lengths, and every rank sets both before accumulate(), ranks with
+ * an empty shard included. (0, 0) restores the handle's own; so does setting a pileup of other sizes or
+ * arrays. set_pair_bound sets the first alone. scale_log2() is the scale of the last accumulate(). */
 uint64_t secedo_simmat_pair_bound(const secedo_simmat_t *handle);
+uint32_t secedo_simmat_max_read_entries(const secedo_simmat_t *handle);
+int secedo_simmat_cell_squares(secedo_simmat_t *handle, uint64_t *d_out /* num_cells, device */, void *stream);
+int secedo_simmat_set_scale_bounds(secedo_simmat_t *handle, uint64_t pair_bound, uint32_t max_read_entries);
 int secedo_simmat_set_pair_bound(secedo_simmat_t *handle, uint64_t pair_bound);
 int secedo_simmat_scale_log2(const secedo_simmat_t *handle);
 

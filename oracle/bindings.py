@@ -133,6 +133,9 @@ def oracle_compute(p, num_cells, max_fragment_length, group_id_to_pos=None, muta
         p.id_base, g2p, len(g2p), num_cells, max_fragment_length, mutation_rate,
         homozygous_rate, seq_error_rate, num_threads, NORMALIZATIONS.index(normalization), out,
         raw.ctypes.data if want_raw else None)
+    if rc == -3:
+        raise ValueError("a read pair shares >= max_fragment_length loci: the reference indexes past its tables "
+                         "there (similarity_matrix.cpp:314-317, :330), so there is no reference answer to restate")
     if rc != 0:
         raise RuntimeError("oracle_simmat_compute failed: %d" % rc)
     return (out, raw) if want_raw else out

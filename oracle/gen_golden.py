@@ -292,6 +292,46 @@ def c2_reference_run():
     print("c2_reference_digest: max %.6f sum %.6f" % (np.max(np.abs(out)), np.sum(out)))
 
 
+def c3_reference_run():
+    """The headline configuration (BASELINE configs[2], SYNTH-v1 seed 42: 8000 cells x 100000 loci, 22
+    chromosomes, T = 8, ADD_MIN) through the compiled reference ONCE (about five minutes and 1.5 GB here;
+    only run when named: `python oracle/gen_golden.py c3_reference_run`), kept as a digest: sha256 of the 512 MB
+    output, its maximum, its sum, per-row-block sums, and 6000 sampled entries (i, j, value): 3000 uniform, 1000
+    inside diagonal 128-cell tiles, 1000 with a cell of the last (partial: 8000 = 62.5 x 128) cell block, 1000
+    from the rows/columns of the first cell block. The input is regenerated by the product's deterministic
+    generator (secedo_amd.synth), whose entry/locus counts are stored too."""
+    import hashlib
+    import time
+    from secedo_amd.synth import CONFIGS, synth_config
+    n = CONFIGS["C3"][0]
+    p = synth_config("C3")
+    t0 = time.time()
+    out = ob.ref_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 8, "ADD_MIN")
+    dt = time.time() - t0
+    rng = np.random.default_rng(2025)
+    ii = [rng.integers(0, n, size=3000)]
+    jj = [rng.integers(0, n, size=3000)]
+    blk = rng.integers(0, (n + 127) // 128, size=1000)          # same 128-cell block on both sides
+    ii.append(np.minimum(blk * 128 + rng.integers(0, 128, size=1000), n - 1))
+    jj.append(np.minimum(blk * 128 + rng.integers(0, 128, size=1000), n - 1))
+    last0 = (n - 1) // 128 * 128                                  # a cell of the last block
+    ii.append(rng.integers(last0, n, size=1000)); jj.append(rng.integers(0, n, size=1000))
+    ii.append(rng.integers(0, n, size=1000)); jj.append(rng.integers(0, 128, size=1000))
+    ii = np.concatenate(ii); jj = np.concatenate(jj)
+    swap = rng.random(len(ii)) < 0.5
+    ii, jj = np.where(swap, jj, ii), np.where(swap, ii, jj)
+    row_block_sums = np.add.reduceat(out.sum(axis=1), np.arange(0, n, 128))
+    np.savez_compressed(os.path.join(GOLDEN, "c3_reference_digest.npz"),
+                        sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest(), dtype=np.uint8),
+                        max_abs=np.float64(np.max(np.abs(out))), total=np.float64(np.sum(out)),
+                        row_block_sums=row_block_sums,
+                        sample_i=ii.astype(np.uint32), sample_j=jj.astype(np.uint32), sample_v=out[ii, jj],
+                        n_entries=np.uint64(p.n_entries), n_loci=np.uint64(p.n_loci),
+                        reference_seconds=np.float64(dt),
+                        params=np.asarray([n, 1000, 0.01, 0.5, 0.01, 8, 0], dtype=np.float64))
+    print("c3_reference_digest: max %.6f sum %.6f  (reference took %.0f s)" % (np.max(np.abs(out)), np.sum(out), dt))
+
+
 def filter_cases():
     """Locus filter (Filter::filter / is_significant) vectors from the compiled reference."""
     rng = np.random.default_rng(7)
@@ -507,6 +547,8 @@ def main():
                random_cases, wrap_cases, c2_reference_run, files_pipeline, spectral_cases, filter_cases, reader_cases, laplacian_kat, em_cases):
         if not only or fn.__name__ in only:
             fn()
+    if "c3_reference_run" in only:   # five minutes of the reference: only when asked for by name
+        c3_reference_run()
 
 
 if __name__ == "__main__":

@@ -303,6 +303,7 @@ typedef struct {
     const uint32_t *g2p;
     uint32_t n_cells;
     uint64_t updates, pairs;
+    int out_of_tables; /* a read pair shared >= max_fragment_length loci (see compare_with_later_reads) */
 } Acc;
 
 static _Thread_local uint64_t g_last_updates, g_last_pairs;
@@ -355,6 +356,13 @@ static void compare_with_later_reads(Acc *a, const Live *lv, uint32_t first) {
             }
         }
         if (x_s == 0 && x_d == 0) continue; /* :231 */
+        /* The reference's tables have max_fragment_length rows (:314-317, :330): a read pair that shares
+         * that many loci makes it read past them (undefined behaviour there). No answer exists to restate:
+         * the call fails with ORACLE_E_OUT_OF_TABLES instead of indexing out of bounds. */
+        if (x_s + x_d >= a->tables->size) {
+            a->out_of_tables = 1;
+            continue;
+        }
         a->updates += x_s + x_d;
         a->pairs += 1;
         const uint64_t ij = (uint64_t)index1 * a->n_cells + index2;
@@ -471,5 +479,5 @@ int oracle_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr,
     g_last_pairs = a.pairs;
     free(a.mat_same); free(a.mat_diff); free(a.lp_same); free(a.lp_diff);
     tables_free(&tables);
-    return rc;
+    return a.out_of_tables ? -3 : rc;
 }

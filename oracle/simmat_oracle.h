@@ -35,7 +35,8 @@ enum { ORACLE_ADD_MIN = 0, ORACLE_EXPONENTIATE = 1, ORACLE_SCALE_MAX_1 = 2 };
  * out      : num_cells^2 doubles, row-major, the normalised matrix the reference returns.
  * out_raw  : optional (may be NULL) num_cells^2 doubles, mat_diff - mat_same before
  *            normalisation (similarity_matrix.cpp:428).
- * Returns 0, or a negative code for an invalid argument.
+ * Returns 0, or a negative code for an invalid argument; -3 (ORACLE_E_OUT_OF_TABLES) when a read pair
+ * shares >= max_fragment_length loci, where the reference reads past its tables (:314-317, :330).
  */
 int oracle_simmat_compute(const uint32_t *chr_locus_off,
                           uint32_t n_chr,

@@ -1,6 +1,9 @@
 #include "llr_table.hpp"
 
 #include <algorithm>
+#include <array>
+#include <map>
+#include <mutex>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -159,7 +162,18 @@ bool llr_exact_mode() {
     return env && std::atoi(env) != 0;
 }
 
-bool extend_reference(LlrTable *t, uint32_t max_shared) {
+namespace {
+// The reference-identical entries are a function of the three rates only and cost O(x_s^2 x_d^2) each
+// (0.6 s for the whole triangle): computed once per process and rate triple, whatever the number of handles.
+struct RefCacheEntry {
+    uint32_t upto = 0;
+    std::vector<double> value;  // kLlrTableDim^2; entries with 1 <= x_s + x_d <= upto are valid
+};
+std::mutex g_ref_mutex;
+std::map<std::array<double, 3>, RefCacheEntry> &g_ref_cache = *new std::map<std::array<double, 3>, RefCacheEntry>();
+}  // namespace
+
+bool extend_reference(LlrTable *t, uint32_t max_shared, unsigned max_threads) {
     const uint32_t want = std::min(max_shared, kLlrRefMax);
     bool finite = true;
     auto check = [&](uint32_t upto) {
@@ -171,10 +185,17 @@ bool extend_reference(LlrTable *t, uint32_t max_shared) {
         check(want);
         return finite;
     }
-    // the entries (ref_upto, want], heaviest first, shared among a few threads (O(x_s^2 x_d^2) each:
+    std::lock_guard<std::mutex> lock(g_ref_mutex);
+    RefCacheEntry &cached = g_ref_cache[{t->eps, t->h, t->theta}];
+    if (cached.value.empty()) cached.value.assign(kLlrTableDim * kLlrTableDim, 0.0);
+    auto take = [&](uint32_t from, uint32_t upto) {
+        for (uint32_t n = from + 1; n <= upto; ++n)
+            for (uint32_t s = 0; s <= n; ++s) t->value[s * kLlrTableDim + (n - s)] = cached.value[s * kLlrTableDim + (n - s)];
+    };
+    // the entries (cached.upto, want], heaviest first, shared among a few threads (O(x_s^2 x_d^2) each:
     // about 1e8 terms for the whole triangle up to 64)
     std::vector<std::pair<uint32_t, uint32_t>> todo;
-    for (uint32_t n = want; n > t->ref_upto; --n)
+    for (uint32_t n = want; n > cached.upto; --n)
         for (uint32_t s = 0; s <= n; ++s) todo.push_back({s, n - s});
     auto cost = [](const std::pair<uint32_t, uint32_t> &e) {
         return (uint64_t)(e.first + 1) * (e.first + 1) * (e.second + 1) * (e.second + 1);
@@ -185,15 +206,20 @@ bool extend_reference(LlrTable *t, uint32_t max_shared) {
     auto work = [&]() {
         for (size_t i; (i = next.fetch_add(1)) < todo.size();) {
             const uint32_t s = todo[i].first, d = todo[i].second;
-            t->value[s * kLlrTableDim + d] = rt.log_diff(s, d) - rt.log_same(s, d);
+            cached.value[s * kLlrTableDim + d] = rt.log_diff(s, d) - rt.log_same(s, d);
         }
     };
-    const unsigned hw = std::thread::hardware_concurrency();
-    const unsigned n_threads = want >= 32 ? std::max(1u, std::min(hw ? hw : 1u, 16u)) : 1u;
-    std::vector<std::thread> pool;
-    for (unsigned i = 1; i < n_threads; ++i) pool.emplace_back(work);
-    work();
-    for (auto &th : pool) th.join();
+    if (!todo.empty()) {
+        // helper threads only for the heavy part of the triangle, and no more than the caller's num_threads
+        const unsigned hw = std::thread::hardware_concurrency();
+        const unsigned n_threads = want >= 32 ? std::max(1u, std::min({hw ? hw : 1u, 16u, std::max(1u, max_threads)})) : 1u;
+        std::vector<std::thread> pool;
+        for (unsigned i = 1; i < n_threads; ++i) pool.emplace_back(work);
+        work();
+        for (auto &th : pool) th.join();
+        cached.upto = want;
+    }
+    take(t->ref_upto, want);
     t->ref_upto = want;
     double per_locus = 0;
     for (uint32_t s = 0; s < kLlrTableDim; ++s)
@@ -224,14 +250,33 @@ LlrTable make_llr_table(double eps, double h, double theta, uint64_t pair_bound)
         }
     }
     t.max_abs_per_locus = per_locus;
-    requantize(&t, llr_scale_for(t, pair_bound));
+    requantize(&t, llr_scale_for(t, pair_bound, kLlrRefMax + 1));
     return t;
 }
 
-int llr_scale_for(const LlrTable &t, uint64_t pair_bound) {
-    // |sum over one cell pair| <= per_locus * incidences; keep it below 2^62 (1.5x margin for the
-    // terms beyond the table, which grow linearly in x_s + x_d as well)
-    const double bound = std::max(1.0, 1.5 * t.max_abs_per_locus) * static_cast<double>(std::max<uint64_t>(pair_bound, 1));
+double llr_per_locus_bound(const LlrTable &t, uint32_t max_shared) {
+    // No read pair shares more loci than its shorter read has kept entries, so only the entries with
+    // x_s + x_d <= max_shared can be added; a pair that shares n loci is n incidences and adds |D| <= n * (the
+    // largest |D| / n among them). The reach is rounded up to a power of two so that the packing paths, whose
+    // longest-read figures may differ (an upper bound on the device, the exact one on the host), agree on it.
+    uint32_t reach = 1;
+    while (reach < max_shared && reach < kLlrRefMax) reach *= 2;
+    const bool whole = max_shared > kLlrRefMax;  // beyond the table D grows linearly: the table's maximum, with margin
+    double per_locus = 0;
+    for (uint32_t s = 0; s < kLlrTableDim; ++s)
+        for (uint32_t d = 0; d < kLlrTableDim; ++d) {
+            if (s + d == 0 || (!whole && s + d > reach)) continue;
+            const double v = t.value[s * kLlrTableDim + d];
+            if (std::isfinite(v)) per_locus = std::max(per_locus, std::fabs(v) / (s + d));
+        }
+    return whole ? std::max(1.0, 1.5 * per_locus) : per_locus;
+}
+
+int llr_scale_for(const LlrTable &t, uint64_t pair_bound, uint32_t max_shared) {
+    // |sum over one cell pair| <= per_locus * incidences (1.5x margin: rounding of the terms, the additions of
+    // the count tile's conversion); keep it below 2^62. Partial sums may wrap on the way -- two's complement
+    // addition is exact modulo 2^64 -- only the final sum has to fit.
+    const double bound = 1.5 * llr_per_locus_bound(t, max_shared) * static_cast<double>(std::max<uint64_t>(pair_bound, 1));
     int k = 44;
     while (k > 0 && std::ldexp(bound, k) >= std::ldexp(1.0, 62)) --k;
     return k;

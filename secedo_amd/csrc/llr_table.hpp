@@ -60,15 +60,20 @@ struct LlrTable {
 LlrTable make_llr_table(double mutation_rate, double homozygous_rate, double seq_error_rate,
                         uint64_t pair_bound);
 
-// largest fixed-point scale (<= 44) for which an int64 accumulator cannot overflow given the bound
-int llr_scale_for(const LlrTable &t, uint64_t pair_bound);
+// largest |D(x_s, x_d)| / (x_s + x_d) over the entries a pileup whose longest read has max_shared kept
+// entries can reach
+double llr_per_locus_bound(const LlrTable &t, uint32_t max_shared);
+// largest fixed-point scale (<= 44) for which an int64 accumulator cannot overflow: pair_bound bounds the
+// (read pair, shared locus) incidences of one cell pair, max_shared the loci one read pair can share
+int llr_scale_for(const LlrTable &t, uint64_t pair_bound, uint32_t max_shared);
 // re-derive t->fixed from t->value for another scale
 void requantize(LlrTable *t, int scale_log2);
 // Make the entries with x_s + x_d <= max_shared (capped at kLlrRefMax) reference-identical (no-op for
 // those that already are, and under SECEDO_LLR_EXACT=1). t->fixed is stale afterwards: requantize.
 // Returns false when one of those entries is not finite (rates for which the reference itself
 // produces inf / NaN, e.g. a sequencing error rate of 0).
-bool extend_reference(LlrTable *t, uint32_t max_shared);
+// Computed once per process and rate triple; at most max_threads helper threads (the caller's num_threads).
+bool extend_reference(LlrTable *t, uint32_t max_shared, unsigned max_threads = 1);
 bool llr_exact_mode();  // SECEDO_LLR_EXACT=1: the closed form everywhere
 
 }  // namespace secedo

@@ -1815,6 +1815,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         return std::string();
     }
     pk.pair_bound = hsc.pair_bound;
+    pk.cell_sq = per_cell_sq;
+    pk.cell_sq_n = n_kept ? nb * B : 0u;
+    pk.cell_sq_host.clear();
     pk.count_tile = caps.allow_counts && pk.pair_bound < kCountTileLimit;
     pk.cap_entries = pk.count_tile ? caps.entries_counts : caps.entries_plain;
     pk.cap_loci = pk.count_tile ? caps.loci_counts : caps.loci_plain;

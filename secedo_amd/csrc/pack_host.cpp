@@ -213,6 +213,7 @@ std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t m
         }
         pk.pair_bound = 0;
         for (uint64_t v : sq) pk.pair_bound = std::max(pk.pair_bound, v);
+        pk.cell_sq = std::move(sq);
     }
 
     // ---- pass 3b: locus ranges for LDS staging (greedy; one partition shared by all blocks) ----

@@ -86,6 +86,7 @@ struct PackedPileup {
     uint64_t num_reads = 0;     // live reads (segments)
     uint64_t raw_entries = 0;   // entries of the input pileup
     uint64_t pair_bound = 0;    // max over cells of sum_l n_cell(l)^2 (Cauchy-Schwarz bound)
+    std::vector<uint64_t> cell_sq;  // the per-cell sums themselves
     uint64_t multi_entries = 0; // entries of reads with more than one kept entry
     uint32_t max_read_entries = 0; // kept entries of the longest read: no read pair shares more loci
     bool any_window_overflow = false;

@@ -83,6 +83,7 @@ struct secedo_simmat {
     bool have_host = false, have_device = false;
     bool prepared = false;
     int packing_mode = 0;                // 0 auto (device, host when required), 1 host, 2 device only
+    uint32_t num_threads = 1;            // of the last prepare (the reference's parameter; bounds helper threads)
     int used_device_packing = 0;
 
     // raw pileup uploaded by prepare() when it came as host pointers
@@ -104,7 +105,11 @@ struct secedo_simmat {
     bool have_model = false, have_lut = false, have_slow = false;
     double lut_eps = 0, lut_h = 0, lut_theta = 0;
     int scale_log2 = 44;
-    uint64_t pair_bound_override = 0;  // secedo_simmat_set_pair_bound
+    // secedo_simmat_set_pair_bound / set_scale_bounds: the bounds of everything that is summed into one
+    // accumulator (shards on several ranks); they belong to the pileup that was set when they were given
+    uint64_t pair_bound_override = 0;
+    uint32_t max_shared_override = 0;
+    uint64_t pileup_identity = 0, override_identity = 0;
     secedo::LlrModel model;
     secedo::LlrTable table;
     secedo::SlowPathArgs slow_host;
@@ -180,6 +185,21 @@ namespace secedo {
 int api_fail(int code, const std::string &msg) { return fail(code, msg); }
 void em_release_cache();  // em_device.hip
 }  // namespace secedo
+
+// Which pileup the handle holds, as far as the scale overrides care: sizes and the entry array. Bounds set for
+// the shards of one pileup must not leak into the accumulation of another (they lower the fixed-point scale);
+// packing the same arrays again (another tile edge, the next step of a loop) keeps them.
+static void note_pileup(secedo_simmat *h, uint32_t n_chr, uint64_t n_loci, uint64_t n_entries, const void *read_ids) {
+    uint64_t id = 0xcbf29ce484222325ull;
+    for (uint64_t v : {(uint64_t)n_chr, n_loci, n_entries, (uint64_t)reinterpret_cast<uintptr_t>(read_ids)})
+        id = (id ^ v) * 0x100000001b3ull;
+    h->pileup_identity = id | 1ull;
+    if (h->override_identity != h->pileup_identity) {
+        h->pair_bound_override = 0;
+        h->max_shared_override = 0;
+        h->override_identity = 0;
+    }
+}
 
 extern "C" {
 
@@ -268,6 +288,7 @@ int secedo_simmat_set_pileup(secedo_simmat_t *h, const uint32_t *chr_locus_off, 
     h->have_host = true;
     h->have_device = false;
     h->prepared = false;
+    note_pileup(h, n_chr, h->view.n_loci(), h->view.n_entries(), read_ids);
     return SECEDO_OK;
 }
 
@@ -295,6 +316,7 @@ int secedo_simmat_set_pileup_device(secedo_simmat_t *h, const uint32_t *d_chr_lo
     h->have_device = true;
     h->have_host = false;
     h->prepared = false;
+    note_pileup(h, n_chr, n_loci, n_entries, d_read_ids);
     return SECEDO_OK;
 }
 
@@ -328,6 +350,7 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
     hipStream_t s = static_cast<hipStream_t>(stream);
     h->prepared = false;
     h->used_device_packing = 0;
+    h->num_threads = num_threads;
     secedo::DevicePacked &pk = h->pk;
 
     bool need_host = (mode == 1);
@@ -434,6 +457,9 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
         pk.num_entries = hp_pk.num_entries;
         pk.num_reads = hp_pk.num_reads;
         pk.pair_bound = hp_pk.pair_bound;
+        pk.cell_sq = nullptr;
+        pk.cell_sq_n = 0;
+        pk.cell_sq_host = std::move(hp_pk.cell_sq);
         pk.multi_entries = hp_pk.multi_entries;
         pk.max_read_entries = hp_pk.max_read_entries;
         pk.stage_masks = hp_pk.stage_masks;
@@ -481,9 +507,31 @@ uint64_t secedo_simmat_num_loci(const secedo_simmat_t *h) { return h ? h->pk.num
 
 uint64_t secedo_simmat_pair_bound(const secedo_simmat_t *h) { return h ? h->pk.pair_bound : 0; }
 int secedo_simmat_scale_log2(const secedo_simmat_t *h) { return h ? h->scale_log2 : 0; }
-int secedo_simmat_set_pair_bound(secedo_simmat_t *h, uint64_t pair_bound) {
+uint32_t secedo_simmat_max_read_entries(const secedo_simmat_t *h) { return h ? h->pk.max_read_entries : 0; }
+int secedo_simmat_set_scale_bounds(secedo_simmat_t *h, uint64_t pair_bound, uint32_t max_read_entries) {
     if (!h) return fail(SECEDO_E_INVALID_ARG, "handle is null");
     h->pair_bound_override = pair_bound;
+    h->max_shared_override = max_read_entries;
+    h->override_identity = (pair_bound || max_read_entries) ? h->pileup_identity : 0;
+    return SECEDO_OK;
+}
+int secedo_simmat_set_pair_bound(secedo_simmat_t *h, uint64_t pair_bound) {
+    return secedo_simmat_set_scale_bounds(h, pair_bound, h ? h->max_shared_override : 0);
+}
+int secedo_simmat_cell_squares(secedo_simmat_t *h, uint64_t *d_out, void *stream) {
+    if (!h || !d_out) return fail(SECEDO_E_INVALID_ARG, "null argument");
+    if (!h->prepared) return fail(SECEDO_E_STATE, "prepare was not called");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = h->pk.num_cells;
+    HIP_TRY(hipMemsetAsync(d_out, 0, n * 8, s));
+    if (h->pk.cell_sq && h->pk.cell_sq_n) {
+        HIP_TRY(hipMemcpyAsync(d_out, h->pk.cell_sq, std::min<size_t>(n, h->pk.cell_sq_n) * 8, hipMemcpyDeviceToDevice, s));
+    } else if (!h->pk.cell_sq_host.empty()) {
+        HIP_TRY(hipMemcpyAsync(d_out, h->pk.cell_sq_host.data(), std::min(n, h->pk.cell_sq_host.size()) * 8,
+                               hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));  // the source is pageable host memory of the handle
+    }
     return SECEDO_OK;
 }
 
@@ -533,16 +581,18 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
     }
     // the entries this pileup can reach (no read pair shares more loci than its shorter read has) as the
     // reference evaluates them, wrapping binomial products included (llr_table.hpp)
-    if (h->table.ref_upto < std::min(h->pk.max_read_entries, secedo::kLlrRefMax) && !secedo::llr_exact_mode())
+    // (with shards on several ranks: what ANY of them can reach, so that all quantise the same table)
+    const uint32_t reach = std::max(h->max_shared_override, h->pk.max_read_entries);
+    if (h->table.ref_upto < std::min(reach, secedo::kLlrRefMax) && !secedo::llr_exact_mode())
         h->have_lut = false;
-    if (!secedo::extend_reference(&h->table, h->pk.max_read_entries))
+    if (!secedo::extend_reference(&h->table, reach, std::max(1u, h->num_threads)))
         return fail(SECEDO_E_INVALID_ARG, "these rates give a non-finite log-likelihood ratio (log of 0: the reference "
                                           "would write inf / NaN into the matrix)");
     {
         // the fixed-point scale follows the pair bound of everything that is summed into one accumulator:
         // this pileup's own bound, or the one the caller set for all the shards that will be added up
-        const uint64_t bound = h->pair_bound_override ? std::max(h->pair_bound_override, h->pk.pair_bound) : h->pk.pair_bound;
-        const int want_scale = secedo::llr_scale_for(h->table, bound);
+        const uint64_t bound = std::max(h->pair_bound_override, h->pk.pair_bound);
+        const int want_scale = secedo::llr_scale_for(h->table, bound, reach);
         if (!h->have_lut || want_scale != h->scale_log2) {
             secedo::requantize(&h->table, want_scale);
             HIP_TRY(h->lut.ensure(h->table.fixed.size() * sizeof(int64_t)));
@@ -582,10 +632,11 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
                 HIP_TRY(hipMemsetAsync(d_acc + (size_t)tile_begin * b2, 0, (size_t)(tile_end - tile_begin) * b2 * sizeof(int64_t), s));
             }
         }
-        HIP_TRY(hipMemsetAsync(h->counters.p, 0, 16 * sizeof(unsigned long long), s));
+        HIP_TRY(hipMemsetAsync(h->counters.p, 0, 96 * sizeof(unsigned long long), s));
         HIP_TRY(hipEventRecord(h->ev_begin, s));
         HIP_TRY(hipEventRecord(h->ev_end, s));
         h->timed = true;
+        h->timed_mid = false;  // no pair kernel ran: last_pair_kernel_ms has nothing to report
         return SECEDO_OK;
     }
     const uint32_t n_tiles = tile_end - tile_begin;

@@ -93,26 +93,29 @@ def chromosome_shard(p, rank, world):
 
 
 def agree_on_shard_geometry(plan, prepare, world, device="cpu", group=None):
-    """Chromosome shards are summed into ONE accumulator, so the ranks must use the same tile edge and the
-    same fixed-point scale, and both are chosen from a shard's own statistics: the tile edge becomes the
-    smallest any rank chose (`prepare(block_cells)` packs again when it differs), the pair bound that
-    decides the scale becomes the SUM of the shards' bounds (the bound of the whole pileup is at most
-    that; a rank whose shard is empty takes part with 0 and gets the common scale all the same).
-    `device`: where the two-word exchange lives ("cuda" under RCCL, "cpu" under gloo).
+    """Chromosome shards are summed into ONE accumulator, so the ranks must use the same tile edge, the same
+    table and the same fixed-point scale, and all three are chosen from a shard's own statistics: the tile
+    edge becomes the smallest any rank chose (`prepare(block_cells)` packs again when it differs); the pair
+    bound that decides the scale becomes the EXACT bound of the whole pileup -- the per-row sums of squared
+    entry counts (plan.cell_squares()) add up over the shards, and the bound is the maximum of the summed
+    vector, so N ranks quantise exactly as one GPU does --; the longest read (which table entries are
+    reachable) becomes the maximum over the shards. A rank whose shard is empty takes part with zeros.
+    `device`: where the exchange lives ("cuda" under RCCL, "cpu" under gloo).
     Returns (block_cells, pair_bound)."""
     import torch
     import torch.distributed as dist
     if world <= 1:
         return plan.block_cells, plan.pair_bound
-    b = torch.tensor([plan.block_cells], dtype=torch.int64, device=device)
+    b = torch.tensor([plan.block_cells, -plan.max_read_entries], dtype=torch.int64, device=device)
     dist.all_reduce(b, op=dist.ReduceOp.MIN, group=group)
-    block_cells = int(b.item())
+    block_cells, longest = int(b[0].item()), -int(b[1].item())
     if block_cells != plan.block_cells:
         prepare(block_cells)
-    s = torch.tensor([plan.pair_bound], dtype=torch.int64, device=device)
-    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
-    plan.set_pair_bound(max(int(s.item()), 1))
-    return block_cells, int(s.item())
+    sq = plan.cell_squares().to(device)
+    dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=group)
+    bound = int(sq.max().item()) if sq.numel() else 0
+    plan.set_scale_bounds(max(bound, 1), max(longest, 1))
+    return block_cells, bound
 
 
 def chromosome_sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate, world, group=None):

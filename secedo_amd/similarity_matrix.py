@@ -227,6 +227,25 @@ class SimilarityMatrixPlan:
         return self
 
     @property
+    def max_read_entries(self) -> int:
+        """Kept entries of the longest read: no read pair shares more loci."""
+        return int(_lib.lib().secedo_simmat_max_read_entries(self._h))
+
+    def cell_squares(self):
+        """Per matrix row the sum over loci of (kept entries of the row at the locus)^2, an int64 CUDA tensor
+        of num_cells elements; pair_bound is its maximum. Shards that are added up sum these vectors."""
+        t = self._torch
+        out = t.empty(max(self.num_cells, 1), dtype=t.int64, device="cuda:%d" % self.device)
+        _lib.check(_lib.lib().secedo_simmat_cell_squares(self._h, C.c_void_p(out.data_ptr()), self._stream()))
+        return out[:self.num_cells]
+
+    def set_scale_bounds(self, pair_bound: int, max_read_entries: int):
+        """Pair bound and longest read of everything that will be summed into one accumulator (chromosome
+        shards on several ranks), so that all of them quantise the same table with the same scale."""
+        _lib.check(_lib.lib().secedo_simmat_set_scale_bounds(self._h, int(pair_bound), int(max_read_entries)))
+        return self
+
+    @property
     def scale_log2(self) -> int:
         """log2 of the fixed-point scale of the last accumulate()."""
         return int(_lib.lib().secedo_simmat_scale_log2(self._h))

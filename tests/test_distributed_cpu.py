@@ -153,13 +153,22 @@ def _shard_worker(rank, world, port, out):
 
 
 class FakeGeometryPlan:
-    """What agree_on_shard_geometry needs of a plan: a tile edge and a pair bound chosen from the shard."""
+    """What agree_on_shard_geometry needs of a plan: a tile edge, the per-row squares and the longest read of
+    the shard."""
 
-    def __init__(self, block_cells, pair_bound):
-        self.block_cells, self.pair_bound, self.bound_set, self.repacked = block_cells, pair_bound, None, []
+    def __init__(self, block_cells, squares, max_read_entries):
+        self.block_cells, self.squares, self.max_read_entries = block_cells, squares, max_read_entries
+        self.bounds_set, self.repacked = None, []
 
-    def set_pair_bound(self, b):
-        self.bound_set = b
+    @property
+    def pair_bound(self):
+        return max(self.squares)
+
+    def cell_squares(self):
+        return torch.tensor(self.squares, dtype=torch.int64)
+
+    def set_scale_bounds(self, bound, longest):
+        self.bounds_set = (bound, longest)
 
 
 def _geometry_worker(rank, world, port, out):
@@ -167,15 +176,16 @@ def _geometry_worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        # rank 0: a deep shard (bound beyond 2^18, where the scale drops below 44); rank 1: an EMPTY shard
-        plan = FakeGeometryPlan([128, 64][rank], [300000, 0][rank])
+        # rank 0: a deep row 0, reads of up to 3 entries; rank 1: a deep row 1, reads of 9 (an empty shard has
+        # all zeros and is covered on the GPU: tests/test_gpu_distributed.py)
+        plan = FakeGeometryPlan([128, 64][rank], [[300000, 10, 0], [0, 200000, 7]][rank], [3, 9][rank])
 
         def prepare(b):
             plan.repacked.append(b)
             plan.block_cells = b
 
         got = sd.agree_on_shard_geometry(plan, prepare, world)
-        res = torch.tensor([got[0], got[1], plan.bound_set, len(plan.repacked)], dtype=torch.int64)
+        res = torch.tensor([got[0], got[1], plan.bounds_set[0], plan.bounds_set[1], len(plan.repacked)], dtype=torch.int64)
         parts = [torch.zeros_like(res) for _ in range(world)]
         dist.all_gather(parts, res)
         if rank == 0:
@@ -185,9 +195,10 @@ def _geometry_worker(rank, world, port, out):
 
 
 def test_shards_agree_on_tile_edge_and_fixed_point_scale_gloo_world2():
-    """Chromosome shards are added into one accumulator: every rank must quantise with the same scale (the
-    SUM of the shards' pair bounds decides it -- ADVICE r01, high) and use the same tile edge (the smallest),
-    a rank with an empty shard included."""
+    """Chromosome shards are added into one accumulator: every rank must quantise with the same scale -- the
+    EXACT pair bound of the union decides it: the per-row squares add up over the shards and the bound is the
+    maximum of the sum (300010, not the 500000 the sum of the shards' maxima would give: ADVICE r02) --, reach the
+    same table entries (the longest read of any shard) and use the same tile edge (the smallest)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -199,8 +210,8 @@ def test_shards_agree_on_tile_edge_and_fixed_point_scale_gloo_world2():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    # (tile edge, summed bound, bound handed to the plan, re-packs): rank 0 re-packed with 64, rank 1 did not
-    assert q.get(timeout=10) == [[64, 300000, 300000, 1], [64, 300000, 300000, 0]]
+    # (tile edge, union bound, bound and longest read handed to the plan, re-packs): rank 0 re-packed with 64
+    assert q.get(timeout=10) == [[64, 300000, 300000, 9, 1], [64, 300000, 300000, 9, 0]]
 
 
 def test_chromosome_sharded_accumulate_gloo_world2():

@@ -178,57 +178,75 @@ def test_chromosome_shards_reproduce_single_process_bitwise(tmp_path):
     assert np.any(single != 0)
 
 
-def test_shards_with_pair_bounds_across_2_18_share_one_scale():
-    """the fixed-point scale drops below 44 once a shard's pair bound reaches 2^18, and
-    shards that are summed must use ONE scale. Chromosome 0 gives cell 0 sixteen reads at each of 1200 loci
-    (bound 16^2 x 1200 > 2^18 -> scale 43), the other chromosomes are shallow (scale 44 on their own).
-    With the bounds summed and set on every shard (what agree_on_shard_geometry does over RCCL), the
-    shards' accumulators add up to the single-process accumulator bit for bit; left to their own scales
-    they do not."""
+def _deep_and_shallow(n, deep_cells, reads_per_locus=100, loci=1200, seed=99):
+    """One deep chromosome per entry of deep_cells (that cell has `reads_per_locus` single-locus reads at each of
+    `loci` loci: per-row square sum reads^2 x loci), then one shallow chromosome."""
+    from tests.pileup_gen import from_rows
+    rng = np.random.default_rng(seed)
+    rid = iter(range(1, 10 ** 7))
+    chroms = []
+    for cell in deep_cells:
+        rows = []
+        others = np.array([c for c in range(n) if c != cell])
+        for l in range(loci):
+            ents = [(next(rid), cell, int(rng.integers(0, 4))) for _ in range(reads_per_locus)]
+            ents += [(next(rid), int(c), int(rng.integers(0, 4))) for c in rng.choice(others, 6, replace=False)]
+            rows.append((1000 + 2000 * l, ents))
+        chroms.append(rows)
+    chroms.append([(1000 + 2000 * l, [(next(rid), int(c), int(rng.integers(0, 4)))
+                                      for c in rng.choice(n, 8, replace=False)]) for l in range(300)])
+    return from_rows(chroms)
+
+
+def test_shards_across_a_scale_threshold_share_one_scale():
+    """the fixed-point scale drops below 44 once 1.5 x pair bound x the largest
+    per-locus |D| reaches 2^18 (single-locus reads at the default rates: a bound of 1.9e7), and shards that are
+    summed must use ONE scale -- that of the whole pileup. Two deep chromosomes of 1.2e7 each:
+    (a) both on cell 0: the union (2.4e7) is at scale 43, every shard on its own at 44 -- with the summed
+        per-row squares set on every shard (what agree_on_shard_geometry does over RCCL) the shards' accumulators
+        add up to the single-process accumulator bit for bit; left to their own scales they do not;
+    (b) on cells 0 and 5: the union is at 1.2e7, scale 44 like every shard -- the SUM OF THE SHARDS' MAXIMA
+        (2.4e7, what round 2 exchanged) would have lowered the scale to 43 and lost the bitwise match."""
     import secedo_amd
     from secedo_amd import distributed as sd
-    from tests.pileup_gen import from_rows
 
     n, world = 20, 3
-    rng = np.random.default_rng(99)
-    rid = iter(range(1, 10 ** 7))
-    deep = []
-    for l in range(1200):
-        ents = [(next(rid), 0, int(rng.integers(0, 4))) for _ in range(16)]
-        ents += [(next(rid), int(c), int(rng.integers(0, 4))) for c in rng.choice(np.arange(1, n), 6, replace=False)]
-        deep.append((1000 + 2000 * l, ents))
-    shallow = [[(1000 + 2000 * l, [(next(rid), int(c), int(rng.integers(0, 4)))
-                                   for c in rng.choice(n, 8, replace=False)]) for l in range(300)]
-               for _ in range(2)]
-    p = from_rows([deep] + shallow)
-    with secedo_amd.SimilarityMatrixPlan(0) as plan:
-        plan.prepare(p, n, 1000, None, 1, block_cells=64)
-        full = plan.new_acc()
-        plan.accumulate(full, 0.01, 0.5, 0.01)
-        assert plan.pair_bound >= 1 << 18 and plan.scale_log2 == 43
-        want = plan.finalize(full, "ADD_MIN").clone()
-        shards = [sd.chromosome_shard(p, r, world) for r in range(world)]
-        # cuts follow the entries: the deep chromosome is a shard of its own, one shard is EMPTY, one shallow
-        assert sorted(s.n_chr for s in shards) == [0, 1, 2] and sum(s.n_entries for s in shards) == p.n_entries
-        bounds, own_scales = [], []
-        for s in shards:
-            plan.prepare(s, n, 1000, None, 1, block_cells=64)
-            bounds.append(plan.pair_bound)
-            part = plan.new_acc()
-            plan.accumulate(part, 0.01, 0.5, 0.01)
-            own_scales.append(plan.scale_log2)
-        assert sorted(own_scales) == [43, 44, 44]  # the hole: each shard on its own picks another scale
-        total = torch.zeros_like(full)
-        for s in shards:
-            plan.prepare(s, n, 1000, None, 1, block_cells=64)
-            plan.set_pair_bound(sum(bounds))
-            part = plan.new_acc()
-            plan.accumulate(part, 0.01, 0.5, 0.01)
-            assert plan.scale_log2 == 43
-            total += part
-        assert torch.equal(total, full)
-        assert torch.equal(plan.finalize(total, "ADD_MIN"), want)  # finalize of the last shard: same scale
-        plan.set_pair_bound(0)
+    for deep_cells, union_scale in (((0, 0), 43), ((0, 5), 44)):
+        p = _deep_and_shallow(n, deep_cells)
+        with secedo_amd.SimilarityMatrixPlan(0) as plan:
+            plan.prepare(p, n, 1000, None, 1, block_cells=64)
+            full = plan.new_acc()
+            plan.accumulate(full, 0.01, 0.5, 0.01)
+            assert plan.scale_log2 == union_scale
+            assert int(plan.cell_squares().max()) == plan.pair_bound
+            want = plan.finalize(full, "ADD_MIN").clone()
+            shards = [sd.chromosome_shard(p, r, world) for r in range(world)]
+            assert [s.n_chr for s in shards] == [1, 1, 1]
+            squares, longest, own_scales, maxima = torch.zeros(n, dtype=torch.int64, device="cuda"), 0, [], []
+            for s in shards:
+                plan.prepare(s, n, 1000, None, 1, block_cells=64)
+                squares += plan.cell_squares()
+                maxima.append(plan.pair_bound)
+                longest = max(longest, plan.max_read_entries)
+                part = plan.new_acc()
+                plan.accumulate(part, 0.01, 0.5, 0.01)
+                own_scales.append(plan.scale_log2)
+            assert own_scales == [44, 44, 44]
+            assert int(squares.max()) == (sum(maxima[:2]) if union_scale == 43 else max(maxima))
+            total = torch.zeros_like(full)
+            for s in shards:
+                plan.prepare(s, n, 1000, None, 1, block_cells=64)
+                plan.set_scale_bounds(int(squares.max()), longest)
+                part = plan.new_acc()
+                plan.accumulate(part, 0.01, 0.5, 0.01)
+                assert plan.scale_log2 == union_scale
+                total += part
+            assert torch.equal(total, full)
+            assert torch.equal(plan.finalize(total, "ADD_MIN"), want)  # finalize of the last shard: same scale
+            # the bounds belong to the pileup they were set on: another pileup gets its own scale back
+            plan.prepare(shards[2], n, 1000, None, 1, block_cells=64)
+            plan.accumulate(plan.new_acc(), 0.01, 0.5, 0.01)
+            assert plan.scale_log2 == 44
 
 
 def test_more_ranks_than_chromosomes_leave_empty_shards():

@@ -67,6 +67,51 @@ def test_c3_full_size_properties():
     assert float(m.min()) == 0.0 and float(off_diag_min) == 0.0  # ADD_MIN: all >= 0, the best pair at 0
 
 
+def digest_errors(z, sample_values, ref_max):
+    """(norm-wise error, element-wise relative max, 99.9-percentile) of sampled entries against a digest."""
+    err = np.abs(sample_values - z["sample_v"])
+    big = np.abs(z["sample_v"]) > 1e-6 * ref_max
+    rel = err[big] / np.abs(z["sample_v"][big])
+    return float(np.max(err) / ref_max), float(np.max(rel)), float(np.percentile(rel, 99.9))
+
+
+def test_c3_against_the_compiled_reference():
+    """The headline configuration held against the REFERENCE itself: tests/golden/c3_reference_digest.npz is
+    one run of the compiled, unmodified reference on C3 (8000 cells x 100 K loci, T = 8, ADD_MIN; 238 s in the
+    build container, oracle/gen_golden.py c3_reference_run): 6000 sampled entries (uniform, inside diagonal
+    tiles, in the last partial cell block, in the first cell block), the maximum, the sum and the sums of
+    every 128-row block. Checked here: the sequence bench.py times (pileup resident in HBM -> prepare_resident
+    -> assign_finalize) and the one-shot drop-in call, norm-wise 1e-9 (north_star), with the element-wise
+    percentiles of SURVEY.md 8d printed."""
+    z = np.load(gu.GOLDEN + "/c3_reference_digest.npz")
+    n, mfl, eps, h, theta, T, _ = z["params"]
+    n, mfl, T = int(n), int(mfl), int(T)
+    p = synth_config("C3")
+    assert p.n_entries == int(z["n_entries"]) and p.n_loci == int(z["n_loci"])
+    ref_max, ii, jj = float(z["max_abs"]), z["sample_i"].astype(np.int64), z["sample_j"].astype(np.int64)
+    ti, tj = torch.from_numpy(ii).cuda(), torch.from_numpy(jj).cuda()
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        resident = plan.upload(p, None, n)
+        plan.prepare_resident(resident, n, mfl, T)
+        acc = plan.new_acc()
+        out = plan.assign_finalize(acc, eps, h, theta, "ADD_MIN")
+        torch.cuda.synchronize()
+        assert plan.scale_log2 == 44
+        normwise, rel_max, rel_999 = digest_errors(z, out[ti, tj].cpu().numpy(), ref_max)
+        print("\nC3 assign_finalize vs compiled reference, %d sampled entries: norm-wise %.2e, element-wise "
+              "relative max %.2e, 99.9-percentile %.2e" % (len(ii), normwise, rel_max, rel_999))
+        assert normwise <= 1e-9
+        assert abs(float(out.abs().max()) - ref_max) <= 1e-9 * ref_max
+        assert abs(float(out.sum()) - float(z["total"])) <= 1e-9 * abs(float(z["total"]))
+        blocks = torch.stack([out[lo:lo + 128].sum() for lo in range(0, n, 128)]).cpu().numpy()
+        assert np.max(np.abs(blocks - z["row_block_sums"])) <= 1e-9 * np.max(np.abs(z["row_block_sums"]))
+        assert rel_max <= 1e-7  # elements near 0 carry the reference's own cancellation error (SURVEY 7.2)
+        kept = out.clone()
+    got = secedo_amd.compute_similarity_matrix(p, n, mfl, None, eps, h, theta, T, "", "ADD_MIN")
+    assert np.array_equal(got, kept.cpu().numpy())  # the drop-in call returns the same bits
+    assert digest_errors(z, got[ii, jj], ref_max)[0] <= 1e-9
+
+
 def test_c5_full_size_properties():
     """C5 (32000 cells x 200 K loci, 1.05e10 updates; cell ids beyond the reference's 14 bits, so the
     32-bit id_base variant): GPU packing against the host emulation in counters and in every bit of the

@@ -50,3 +50,19 @@ def test_invalid_normalization():
     p, cases = gu.load("probe_single_locus")
     with pytest.raises(ValueError):
         ob.oracle_compute(p, 4, 1000, None, 0.01, 0.5, 0.01, 1, "BOGUS")
+
+
+def test_oracle_refuses_read_pairs_beyond_the_reference_tables():
+    """A read pair that shares >= max_fragment_length loci makes the reference index past its
+    max_fragment_length-sized tables (similarity_matrix.cpp:314-317, :330): the oracle returns an error for
+    such a pileup instead of following it out of bounds (it used to crash the test process)."""
+    import pytest
+    from oracle import bindings as ob
+    from tests.pileup_gen import from_rows
+    # two reads of different cells over 12 adjacent loci, then far loci of a third cell so that they flush
+    rows = [(100 + l, [(1, 0, l & 3), (2, 1, (l + l // 5) & 3)]) for l in range(12)]
+    rows += [(50000 + 5000 * k, [(10 + k, 2, 0)]) for k in range(6)]
+    p = from_rows([rows])
+    ob.oracle_compute(p, 3, 13, None, 0.01, 0.5, 0.01, 1, "ADD_MIN")  # 12 shared loci < 13 table rows: fine
+    with pytest.raises(ValueError, match="max_fragment_length"):
+        ob.oracle_compute(p, 3, 12, None, 0.01, 0.5, 0.01, 1, "ADD_MIN")

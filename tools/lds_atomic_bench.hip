@@ -48,7 +48,73 @@ void run(const char *name, uint32_t cells, size_t lds, int blocks) {
     hipFree(sink);
 }
 
-int main() {
+// --json: the peak that bench.py's roofline uses -- random ds_add_u32 (what accumulate_counts issues per update)
+// over the geometries the pair kernel could run in; the best of them is the chip's rate for this instruction mix.
+template <int CONFLICT_FREE>
+__global__ __launch_bounds__(1024) void k32(uint32_t iters, uint32_t mask, uint32_t *sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    uint32_t *t32 = reinterpret_cast<uint32_t *>(raw);
+    for (uint32_t i = threadIdx.x; i <= mask; i += blockDim.x) t32[i] = 0;
+    __syncthreads();
+    uint32_t x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#pragma unroll 4
+    for (uint32_t it = 0; it < iters; ++it) {
+        x = x * 1664525u + 1013904223u;
+        uint32_t idx = (x >> 8) & mask;
+        if (CONFLICT_FREE) idx = (idx & ~31u) | (threadIdx.x & 31u);  // every lane its own bank
+        atomicAdd(&t32[idx], (x & 1u) ? 0x10000u : 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sink[blockIdx.x] = t32[1];
+}
+
+template <int CONFLICT_FREE>
+double run32(int threads, uint32_t cells, int blocks) {
+    uint32_t *sink;
+    hipMalloc(&sink, blocks * 4);
+    const uint32_t iters = 8192;
+    const size_t lds = (size_t)cells * 4;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k32<CONFLICT_FREE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL(k32<CONFLICT_FREE>, dim3(blocks), dim3(threads), lds, 0, iters, cells - 1, sink);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (rep) best = ms < best ? ms : best;
+    }
+    hipFree(sink);
+    return (double)blocks * threads * iters / (best * 1e-3);
+}
+
+int json_main() {
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    struct Cfg { int threads; uint32_t cells; int per_cu; };
+    const Cfg cfgs[] = {{256, 8192, 4}, {256, 8192, 8}, {512, 16384, 2}, {512, 16384, 4}, {1024, 16384, 1},
+                        {1024, 16384, 2}, {1024, 32768, 1}};
+    double peak = 0, peak_cf = 0;
+    printf("{\"device\": \"%s\", \"compute_units\": %d, \"clock_mhz\": %d, \"instruction\": \"ds_add_u32, 64 random addresses per "
+           "wave instruction\", \"configs\": [", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000);
+    bool first = true;
+    for (const Cfg &c : cfgs) {
+        const int blocks = prop.multiProcessorCount * c.per_cu * 4;  // four rounds of resident workgroups
+        const double r = run32<0>(c.threads, c.cells, blocks), f = run32<1>(c.threads, c.cells, blocks);
+        peak = r > peak ? r : peak;
+        peak_cf = f > peak_cf ? f : peak_cf;
+        printf("%s{\"threads\": %d, \"tile_bytes\": %u, \"workgroups_per_cu\": %d, \"random_gatomic_per_s\": %.1f, "
+               "\"bank_conflict_free_gatomic_per_s\": %.1f}", first ? "" : ", ", c.threads, c.cells * 4, c.per_cu, r * 1e-9, f * 1e-9);
+        first = false;
+    }
+    printf("], \"peak_random_gatomic_per_s\": %.1f, \"peak_bank_conflict_free_gatomic_per_s\": %.1f}\n", peak * 1e-9, peak_cf * 1e-9);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1 && argv[1][0] == '-' && argv[1][1] == '-' && argv[1][2] == 'j') return json_main();
     for (int blocks : {256 * 2, 256 * 4, 256 * 8}) {
         run<0>("ds_add_u32 random", 4096, 32768, blocks);
         run<1>("ds_add_u64 random", 4096, 32768, blocks);
