@@ -140,6 +140,9 @@ def parse_args(argv=None):
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--only", default="both", choices=["both", "tiles", "chromosomes"],
                     help="N > 1: time only one of the two partitionings")
+    ap.add_argument("--chunks", type=int, default=4,
+                    help="N > 1, tiles: also time the all-gather issued in this many chunks on a second stream while "
+                         "the next chunk accumulates (1 = only the single all-gather at the end)")
     ap.add_argument("--gathered", action="store_true",
                     help="N > 1 with --workload C5: gather the matrix like C3 instead of BASELINE configs[4] "
                          "(sharded rows + distributed spectral step)")
@@ -238,8 +241,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_mode(by_chromosome):
-        """W warm-up steps, then K timed steps of one partitioning. Returns its record and live objects."""
+    def run_mode(by_chromosome, overlapped=False):
+        """W warm-up steps, then K timed steps of one partitioning. Returns its record and live objects.
+        overlapped (tiles only): the all-gather goes chunk by chunk on a second stream behind the accumulation."""
         mine = sd.chromosome_shard(p, rank, world) if by_chromosome else p
         plan = secedo_amd.SimilarityMatrixPlan(local_rank)
         resident = plan.upload(mine, None, n_cells)  # the raw flat pileup, in HBM before the clock starts
@@ -253,6 +257,7 @@ def main():
             block_cells, _ = sd.agree_on_shard_geometry(
                 plan, lambda b: plan.prepare_resident(resident, n_cells, mfl, threads, b), world, red_dev)
         acc = plan.new_acc(pad_tiles_to=1 if by_chromosome else world)
+        comm = torch.cuda.Stream() if overlapped else None
         my_tiles = (0, plan.num_tiles) if by_chromosome else sd.tile_range(plan.num_tiles, rank, world)
 
         def step():
@@ -263,6 +268,8 @@ def main():
                 return
             if by_chromosome:
                 sd.chromosome_sharded_accumulate(plan, acc, *rates, world)
+            elif overlapped:
+                sd.sharded_accumulate_overlapped(plan, acc, *rates, rank, world, chunks=args.chunks, comm_stream=comm)
             else:
                 sd.sharded_accumulate(plan, acc, *rates, rank, world)
             plan.finalize(acc, norm, out)
@@ -296,7 +303,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         updates, pairs, kept_entries, reads = (int(v.item()) for v in cnt)
-        return dict(by_chromosome=by_chromosome, plan=plan, resident=resident, acc=acc, my_tiles=my_tiles,
+        return dict(by_chromosome=by_chromosome, overlapped=overlapped, plan=plan, resident=resident, acc=acc, my_tiles=my_tiles,
                     block_cells=block_cells, elapsed=float(t.item()), blocks=blocks, updates=updates, pairs=pairs,
                     kept_entries=kept_entries, reads=reads, local_updates=local_updates, last_ms=last_ms,
                     prepare_s=prepare_s)
@@ -402,6 +409,8 @@ def main():
     else:
         if args.only in ("both", "tiles"):
             modes.append(run_mode(False))
+            if args.chunks > 1:
+                modes.append(run_mode(False, overlapped=True))
         if args.only in ("both", "chromosomes") and p.n_chr >= 2:
             modes.append(run_mode(True))
     best = min(modes, key=lambda m: m["elapsed"])
@@ -546,7 +555,9 @@ def main():
                 "parallelism": ("single GPU" if world == 1 else
                                 "chromosomes/%d (packing + accumulation) + all-reduce of the int64 accumulator" % world
                                 if by_chromosome else "tiles/%d (replicated packing) + all-gather of the int64 "
-                                                      "accumulator" % world),
+                                                      "accumulator%s" % (world, " in %d chunks on a second stream behind "
+                                                                                "the accumulation" % args.chunks
+                                                                         if best["overlapped"] else "")),
                 "backend": backend_name, "world_size": world, "rccl_world_size": pg_world,
                 # tiles mode: every rank packs the whole pileup, only the pair accumulation is divided
                 "replicated_ms_per_step": phase.get("pack_ms") if world > 1 and not by_chromosome else None},
@@ -556,7 +567,9 @@ def main():
             "spread": (best["blocks"][-1] - best["blocks"][0]) / elapsed if elapsed else None,
             "parity_checked": bool(parity and parity["ok"]),
             "parity": parity,
-            "partitionings": {("chromosomes+all-reduce" if m["by_chromosome"] else "tiles+all-gather"):
+            "partitionings": {("chromosomes+all-reduce" if m["by_chromosome"] else
+                               "tiles+all-gather in %d chunks behind the accumulation" % args.chunks if m["overlapped"]
+                               else "tiles+all-gather"):
                               {"ms_per_step": m["elapsed"] / args.steps * 1e3,
                                "updates_per_s": m["updates"] * args.steps / m["elapsed"]} for m in modes},
             "wall_s_full_matrix": step_s,

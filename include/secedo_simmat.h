@@ -71,6 +71,16 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
                           uint32_t max_fragment_length, double mutation_rate,
                           double homozygous_rate, double seq_error_rate, uint32_t num_threads,
                           int normalization, double *out);
+/* Pinned host staging for callers that assemble the flat pileup themselves (the C++ shim flattens the
+ * reference's vector<vector<PosData>> straight into it, several threads at a time): five buffers of at least
+ * bytes[0..4] bytes -- for chr_locus_off, locus_pos, locus_entry_off, read_ids, id_base in this order --
+ * kept by the library between calls (page-locked, so secedo_simmat_compute uploads them by DMA without an
+ * intermediate copy, and no fresh pages are touched per call). One caller at a time: returns SECEDO_E_STATE
+ * while another thread holds them (fall back to buffers of your own). release() hands them back (they stay
+ * allocated until secedo_simmat_release_cache()). */
+int secedo_simmat_staging_acquire(const uint64_t bytes[5], void *ptrs[5]);
+void secedo_simmat_staging_release(void);
+
 /* secedo_simmat_compute keeps its device buffers between calls (one set per device; the reference calls
  * computeSimilarityMatrix once per sub-cluster of its recursion), and so does secedo_em_refine* with its
  * scratch (secedo_em.h). This frees both. Never required. */

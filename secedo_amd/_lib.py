@@ -63,6 +63,8 @@ SIGNATURES = {
                                         C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double,
                                         C.c_uint32, C.c_int, _vp]),
     "secedo_simmat_release_cache": (None, []),
+    "secedo_simmat_staging_acquire": (C.c_int, [_vp, _vp]),
+    "secedo_simmat_staging_release": (None, []),
     "secedo_simmat_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "secedo_simmat_destroy": (None, [_vp]),
     "secedo_simmat_set_pileup": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp,

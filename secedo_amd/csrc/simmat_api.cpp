@@ -13,6 +13,9 @@
 #include "simmat_kernels.hpp"
 
 #include <hip/hip_runtime_api.h>
+#if defined(__linux__)
+#include <sys/mman.h>
+#endif
 
 #include <algorithm>
 #include <cstdio>
@@ -24,6 +27,7 @@
 #include <new>
 #include <queue>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -185,6 +189,92 @@ namespace secedo {
 int api_fail(int code, const std::string &msg) { return fail(code, msg); }
 void em_release_cache();  // em_device.hip
 }  // namespace secedo
+
+// ---- pinned host memory kept between one-shot calls: the caller's staging (five buffers) and the bounce ring of
+// the matrix download
+namespace {
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= bytes && p) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        const size_t want = n + n / 8 + 4096;  // some slack: the next sub-cluster is rarely the same size
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+std::mutex g_staging_mutex;
+bool g_staging_busy = false;
+PinnedBuf g_staging[5];
+PinnedBuf g_bounce;  // guarded by g_bounce_mutex for the duration of a download
+std::mutex g_bounce_mutex;
+
+// d_src (device) -> dst (pageable host memory, typically the fresh pages of the caller's matrix): chunks go
+// through a page-locked ring by DMA while `threads` host threads copy the chunk before out of the ring, each
+// its own slice -- touching the destination's fresh pages in parallel is what a single-threaded copy into
+// pageable memory cannot do (12-20 GB/s for hipMemcpy on the 512 MB of C3).
+hipError_t download_pipelined(const void *d_src, void *dst, size_t bytes, unsigned threads) {
+    constexpr size_t kChunk = 32u << 20;
+    constexpr int kSlots = 3;
+    std::lock_guard<std::mutex> lock(g_bounce_mutex);
+    hipError_t e = g_bounce.ensure(kChunk * kSlots);
+    if (e != hipSuccess) {  // no pinned memory to be had: the plain copy
+        (void)hipGetLastError();
+        return hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost);
+    }
+#if defined(__linux__)
+    {   // huge pages for the destination where the kernel grants them on request: 2 MiB faults instead of 4 KiB
+        const uintptr_t a = (reinterpret_cast<uintptr_t>(dst) + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1);
+        const uintptr_t b = (reinterpret_cast<uintptr_t>(dst) + bytes) & ~(uintptr_t)((2u << 20) - 1);
+        if (b > a) (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
+    }
+#endif
+    hipStream_t s = nullptr;
+    hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr};
+    if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) return e;
+    for (int i = 0; i < kSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+    threads = std::max(1u, std::min(threads, 16u));
+    auto issue = [&](size_t c) {
+        const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+        hipError_t r = hipMemcpyAsync(static_cast<char *>(g_bounce.p) + (c % kSlots) * kChunk,
+                                      static_cast<const char *>(d_src) + off, len, hipMemcpyDeviceToHost, s);
+        if (r == hipSuccess) r = hipEventRecord(ev[c % kSlots], s);
+        return r;
+    };
+    for (size_t c = 0; c < std::min<size_t>(kSlots - 1, n_chunks) && e == hipSuccess; ++c) e = issue(c);
+    for (size_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
+        if (c + kSlots - 1 < n_chunks) e = issue(c + kSlots - 1);  // its slot was emptied by the copy of chunk c - 1
+        if (e == hipSuccess) e = hipEventSynchronize(ev[c % kSlots]);
+        if (e != hipSuccess) break;
+        const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+        const char *src = static_cast<const char *>(g_bounce.p) + (c % kSlots) * kChunk;
+        char *out = static_cast<char *>(dst) + off;
+        const size_t slice = ((len + threads - 1) / threads + 4095) & ~(size_t)4095;
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads; ++t) {
+            const size_t lo = std::min(len, t * slice), hi = std::min(len, (t + 1) * slice);
+            if (hi > lo) pool.emplace_back([=] { std::memcpy(out + lo, src + lo, hi - lo); });
+        }
+        std::memcpy(out, src, std::min(len, slice));
+        for (auto &th : pool) th.join();
+    }
+    (void)hipStreamSynchronize(s);
+    for (int i = 0; i < kSlots; ++i)
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+    (void)hipStreamDestroy(s);
+    return e;
+}
+}  // namespace
 
 // Which pileup the handle holds, as far as the scale overrides care: sizes and the entry array. Bounds set for
 // the shards of one pileup must not leak into the accumulation of another (they lower the fixed-point scale);
@@ -1055,10 +1145,15 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
     if (rc != SECEDO_OK) return rc;
     if (trace) HIP_TRY(hipDeviceSynchronize());
     const auto t2 = clock::now();
-    // (pageable destination: 12-20 GB/s for the 512 MB of C3, the longest phase of a one-shot call; four
-    // threads with a pinned buffer and a stream each were no faster -- the second hop into fresh pages is the
-    // limit, not the staging)
-    HIP_TRY(hipMemcpy(out, h->own_out.p, out_bytes, hipMemcpyDeviceToHost));
+    // (a plain hipMemcpy into the caller's pageable, usually untouched matrix runs at 12-20 GB/s: 25-45 ms for
+    // the 512 MB of C3, the longest phase of a one-shot call)
+    static const bool plain_copy = [] { const char *e = std::getenv("SECEDO_ONE_SHOT_COPY"); return e && !std::strcmp(e, "plain"); }();
+    if (out_bytes >= (8u << 20) && !plain_copy) {
+        HIP_TRY(hipStreamSynchronize(nullptr));  // the matrix is complete (the download runs on a stream of its own)
+        HIP_TRY(download_pipelined(h->own_out.p, out, out_bytes, std::max(1u, num_threads)));
+    } else {
+        HIP_TRY(hipMemcpy(out, h->own_out.p, out_bytes, hipMemcpyDeviceToHost));
+    }
     if (trace)
         std::fprintf(stderr, "[one-shot] upload + packing %.2f ms, matrix %.2f ms, copy to the host %.2f ms\n", ms(t0, t1),
                      ms(t1, t2), ms(t2, clock::now()));
@@ -1066,8 +1161,36 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
     return SECEDO_OK;
 }
 
+int secedo_simmat_staging_acquire(const uint64_t bytes[5], void *ptrs[5]) {
+    if (!bytes || !ptrs) return fail(SECEDO_E_INVALID_ARG, "null argument");
+    if (secedo_simmat_device_count() <= 0) return fail(SECEDO_E_NO_DEVICE, "no HIP device is visible");
+    std::lock_guard<std::mutex> lock(g_staging_mutex);
+    if (g_staging_busy) return fail(SECEDO_E_STATE, "the staging buffers are held by another caller");
+    for (int i = 0; i < 5; ++i) {
+        const hipError_t e = g_staging[i].ensure(static_cast<size_t>(bytes[i]));
+        if (e != hipSuccess) return hip_fail(e, "hipHostMalloc (staging)");
+        ptrs[i] = g_staging[i].p;
+    }
+    g_staging_busy = true;
+    return SECEDO_OK;
+}
+
+void secedo_simmat_staging_release(void) {
+    std::lock_guard<std::mutex> lock(g_staging_mutex);
+    g_staging_busy = false;
+}
+
 void secedo_simmat_release_cache(void) {
     secedo::em_release_cache();
+    {
+        std::lock_guard<std::mutex> lock(g_staging_mutex);
+        if (!g_staging_busy)
+            for (PinnedBuf &b : g_staging) b.release();
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_bounce_mutex);
+        g_bounce.release();
+    }
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (auto &slot : g_pool) {
         if (slot.second) secedo_simmat_destroy(slot.second);

@@ -1577,6 +1577,9 @@ hipError_t launch_acc(const AccumulateArgs &args, uint32_t grid, hipStream_t str
     return hipGetLastError();
 }
 
+template <int B>
+hipError_t launch_correct(const AccumulateArgs &args, hipStream_t stream, const SideStream *side);
+
 template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
 hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t stream, const SideStream *side,
                          hipEvent_t mid) {
@@ -1597,6 +1600,15 @@ hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t 
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
     if (mid && (e = hipEventRecord(mid, stream)) != hipSuccess) return e;
+    return launch_correct<B>(args, stream, side);
+}
+
+// The second kernel of the sparse-loci path, after the pair kernel.
+template <int B>
+hipError_t launch_correct(const AccumulateArgs &args, hipStream_t stream, const SideStream *side) {
+    hipError_t e = hipSuccess;
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
     // What the flags of the reads mean, and the count tiles' way into the accumulator: one workgroup per tile.
     // The flagged entries' lists may still be in the making on the side stream (build_flagged_lists).
     if (side && side->stream) {

@@ -61,6 +61,57 @@ def sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate
     return acc
 
 
+def sharded_accumulate_overlapped(plan, acc, mutation_rate, homozygous_rate, seq_error_rate, rank, world,
+                                  chunks=4, group=None, comm_stream=None):
+    """sharded_accumulate with the exchange hidden behind the accumulation: the rank's tile range is worked off
+    in `chunks` launches, and as soon as a chunk's tiles are final (correct_tiles has stored them) its
+    all-gather is issued on a second stream while the next chunk accumulates; the calling stream waits for the
+    last exchange at the end. Tiles keep their place in `acc` (position = tile index), so chunk k of rank r is
+    the k-th part of r's slice and the gather of chunk k writes `world` separate slices of `acc` (all_gather
+    with a list of views). Bitwise the same accumulator as sharded_accumulate. `acc` from
+    plan.new_acc(pad_tiles_to=world). On rehearsal backends (gloo) the chunks are exchanged one after the other
+    through the host."""
+    import torch
+    import torch.distributed as dist
+
+    b2 = plan.block_cells ** 2
+    per = tiles_per_rank(plan.num_tiles, world)
+    assert acc.numel() == per * world * b2, "acc must be padded with new_acc(pad_tiles_to=world)"
+    lo, hi = tile_range(plan.num_tiles, rank, world)
+    n_mine = hi - lo
+    chunks = max(1, min(chunks, per))
+    step = -(-per // chunks)
+    direct = world > 1 and acc.is_cuda and dist.get_backend(group) == "nccl"
+    main = torch.cuda.current_stream(acc.device) if acc.is_cuda else None
+    if direct and comm_stream is None:
+        comm_stream = torch.cuda.Stream(acc.device)
+    for c_lo in range(0, per, step):
+        c_hi = min(c_lo + step, per)  # the chunk, in tiles of a rank's slice
+        t_lo, t_hi = lo + min(c_lo, n_mine), lo + min(c_hi, n_mine)
+        if t_hi > t_lo:
+            plan.accumulate(acc, mutation_rate, homozygous_rate, seq_error_rate, t_lo, t_hi, overwrite=True)
+        if c_hi > n_mine:  # padding tiles of the last ranks' slices
+            acc[(rank * per + max(c_lo, n_mine)) * b2:(rank * per + c_hi) * b2].zero_()
+        if world == 1:
+            continue
+        outs = [acc[(r * per + c_lo) * b2:(r * per + c_hi) * b2] for r in range(world)]
+        if direct:
+            done = torch.cuda.Event()
+            done.record(main)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(done)
+                dist.all_gather(outs, outs[rank].clone(), group=group)
+        else:
+            parts = [torch.empty(outs[rank].shape, dtype=acc.dtype) for _ in range(world)]
+            dist.all_gather(parts, outs[rank].cpu(), group=group)
+            for o, part in zip(outs, parts):
+                o.copy_(part)
+    if direct:
+        main.wait_stream(comm_stream)
+        acc.record_stream(comm_stream)
+    return acc
+
+
 def chromosome_cuts(chr_locus_off, locus_entry_off, world):
     """world + 1 chromosome indices: rank r takes chromosomes [cuts[r], cuts[r + 1]). Contiguous, each
     cut at the chromosome boundary nearest to an equal share of the entries (a rank may get none)."""

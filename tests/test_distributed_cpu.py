@@ -41,7 +41,7 @@ class FakePlan:
                 acc[t * b2:(t + 1) * b2] += t + 1
 
 
-def _worker(rank, world, port, num_tiles, out):
+def _worker(rank, world, port, num_tiles, chunks, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -49,7 +49,10 @@ def _worker(rank, world, port, num_tiles, out):
         plan = FakePlan(num_tiles, 4)
         per = sd.tiles_per_rank(num_tiles, world)
         acc = torch.full((per * world * 16,), -7, dtype=torch.int64)  # garbage that must disappear
-        sd.sharded_accumulate(plan, acc, 0.01, 0.5, 0.01, rank, world)
+        if chunks:
+            sd.sharded_accumulate_overlapped(plan, acc, 0.01, 0.5, 0.01, rank, world, chunks=chunks)
+        else:
+            sd.sharded_accumulate(plan, acc, 0.01, 0.5, 0.01, rank, world)
         expect = torch.zeros_like(acc)
         for t in range(num_tiles):
             expect[t * 16:(t + 1) * 16] = t + 1
@@ -62,14 +65,16 @@ def _worker(rank, world, port, num_tiles, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("num_tiles", [5, 36])
-def test_sharded_accumulate_gloo_world2(num_tiles):
+@pytest.mark.parametrize("num_tiles,chunks", [(5, 0), (36, 0), (5, 2), (36, 4), (37, 3), (2, 4)])
+def test_sharded_accumulate_gloo_world2(num_tiles, chunks):
+    """chunks = 0: one all-gather after the rank's tiles; otherwise the chunked exchange (on RCCL it overlaps the
+    accumulation of the next chunk): both must leave every tile at its place, bit for bit, padding zeroed."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, num_tiles, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, num_tiles, chunks, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
