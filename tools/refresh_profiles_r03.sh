@@ -1,0 +1,51 @@
+#!/bin/bash
+# refresh_profiles_r03.sh -- the artefacts of round 3 under profiles/ (run on the GPU box; output in
+# gpurun_out/r03, copied to profiles/r03_* by hand). One gpurun call, about six minutes.
+#   1. the driver's own command, `python bench.py` (C3 = 8000 cells x 100K loci), and the LDS-atomic peak
+#   2. rocprofv3 --kernel-trace --stats over the same command (program directly after --)
+#   3. FETCH_SIZE / WRITE_SIZE passes over it (separate --pmc runs) + the calibration of both counters
+#   4. SQ / LDS counters of the accumulate kernels -> pmc_C3.txt and counters.json (what bench.py's roofline reads)
+#   5. the clustered-loci variants (gap_max = 300): bench lines + kernel stats of C3 and C2, SQ counters of C3
+#   6. C2 and C5 bench lines
+set -e
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT/gpurun_out/r03
+rm -rf $R; mkdir -p $R
+tools/lds_atomic_bench.bin --json > $R/lds_atomic_peak.json
+python bench.py > $R/C3_bench.json 2> $R/C3_bench.err
+echo "C3 bench done"; head -c 400 $R/C3_bench.json; echo
+stats() {  # name, bench args...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/prof_$name -- python bench.py --no-cpu-baseline --repeats 2 "$@" > $R/prof_$name.log 2>&1
+  cp $(find $R/prof_$name -name "*kernel_stats.csv" | head -1) $R/${name}_kernel_stats.csv
+  python tools/kstats.py $R/prof_$name > $R/${name}_kernel_stats_readable.txt
+  rm -rf $R/prof_$name
+  echo "$name kernel stats done"
+}
+stats C3
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $R/calib_$c -- tools/fetch_calib.bin > $R/calib_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $R/pmc_$c -- python bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline > $R/pmc_$c.log 2>&1
+done
+python tools/traffic_json.py $R > $R/traffic.json
+echo "traffic done"
+P="--steps 3 --warmup 1 --repeats 1"
+tools/pmc.sh r03_a "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" $P > $R/pmc_C3_a.txt
+tools/pmc.sh r03_b "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU" $P > $R/pmc_C3_b.txt
+tools/pmc.sh r03_c "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU" $P > $R/pmc_C3_c.txt
+cat $R/pmc_C3_a.txt $R/pmc_C3_b.txt $R/pmc_C3_c.txt > $R/pmc_C3.txt
+echo "pmc done"
+# clustered loci
+python bench.py --clustered --no-cpu-baseline > $R/C3_clustered_bench.json 2> $R/C3_clustered_bench.err
+python bench.py --workload C2 --clustered --no-cpu-baseline > $R/C2_clustered_bench.json 2> $R/C2_clustered_bench.err
+stats C3_clustered --clustered --steps 5
+stats C2_clustered --workload C2 --clustered
+tools/pmc.sh r03_ca "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" --clustered $P > $R/pmc_C3_clustered_a.txt
+tools/pmc.sh r03_cb "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM" --clustered $P > $R/pmc_C3_clustered_b.txt
+cat $R/pmc_C3_clustered_a.txt $R/pmc_C3_clustered_b.txt > $R/pmc_C3_clustered.txt
+python tools/counters_json.py $R > $R/counters.json
+cat $R/counters.json
+python bench.py --workload C2 --no-cpu-baseline > $R/C2_bench.json 2> $R/C2_bench.err
+python bench.py --workload C5 --no-cpu-baseline --steps 5 > $R/C5_bench.json 2> $R/C5_bench.err
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_r03_* $R/pmc_FETCH_SIZE $R/pmc_WRITE_SIZE $R/calib_FETCH_SIZE $R/calib_WRITE_SIZE 2>/dev/null || true
+echo "all done"
