@@ -100,6 +100,9 @@ struct secedo_simmat {
     uint32_t plan_tile_begin = 0xFFFFFFFFu, plan_tile_end = 0, plan_ranges = 0, plan_blocks = 0, plan_workgroups = 0;
     DevBuf flag_tmp, flag_pre, flag_grp, flag_rec, flag_idx;  // sparse-loci path: the flagged entries, compact
     bool flags_ready = false;                                 // ... of the current packed pileup
+    bool wide_known = false;                                  // clustered loci: the reads that reach beyond their windows ...
+    uint32_t n_wide = 0;                                      // ... their entries, listed per cell block
+    DevBuf wide_tab, wide_list;
     DevBuf own_acc, own_out;  // used by the one-shot entry point only
     DevBuf tile_ids;          // tile list of accumulate_list / max_of_tiles
     std::vector<uint16_t> host_tile_row, host_tile_col;
@@ -583,6 +586,7 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
     h->prepared = true;
     h->timed = false;
     h->flags_ready = false;
+    h->wide_known = false;
     return SECEDO_OK;
 }
 
@@ -827,6 +831,31 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         *max_done = true;
     }
     a.counters = h->counters.as<unsigned long long>();
+    if (h->pk.stage_masks && h->pk.block_cells == 64) {
+        // accumulate_masks pairs from the 8-locus windows alone; the entries of reads that reach beyond them are
+        // listed per cell block once per prepare for its second kernel (SECEDO_MASKS_KERNEL=0: accumulate_tiles)
+        static const bool allowed = [] { const char *e = std::getenv("SECEDO_MASKS_KERNEL"); return !(e && std::atoi(e) == 0); }();
+        if (allowed && !h->wide_known) {
+            const uint32_t nb = h->pk.num_blocks;
+            HIP_TRY(h->wide_tab.ensure(((size_t)3 * nb + 2) * 4));
+            uint32_t *cnt = h->wide_tab.as<uint32_t>(), *off = cnt + nb, *cur = off + nb + 1;
+            HIP_TRY(secedo::wide_count(a.entry32, a.blk_off, a.stride, nb, cnt, off, cur, s));
+            uint32_t total = 0;
+            HIP_TRY(hipMemcpyAsync(&total, off + nb, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            h->n_wide = total;
+            if (total) {
+                HIP_TRY(h->wide_list.ensure((size_t)total * 4));
+                HIP_TRY(secedo::wide_fill(a.entry32, a.blk_off, a.stride, nb, cur, h->wide_list.as<uint32_t>(), s));
+            }
+            h->wide_known = true;
+        }
+        a.masks_kernel = allowed;
+        if (allowed && h->n_wide) {
+            a.wide_off = h->wide_tab.as<uint32_t>() + h->pk.num_blocks;
+            a.wide_list = h->wide_list.as<uint32_t>();
+        }
+    }
 
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, 96 * sizeof(unsigned long long), s));
     const secedo::SideStream *side = nullptr;

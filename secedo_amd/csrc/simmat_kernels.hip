@@ -726,7 +726,11 @@ constexpr uint32_t IT_REC_MASK = 0x1FFu;  // cell (7 bits) | base (2 bits)
 //   C5 (1.3):                                 31.4 / 30.6 / 31.6 / -
 // (with seven vector instructions per slot, before col32, the empty slots of GROUP 4 cost more than the trips
 // through the ring: 4.87 / 4.49 / 4.38 / 5.62 on C3.) 4 by default, 2 below 2.5 entries per block and locus.
-template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
+// SLOT_ASM: the pair slot as five hand-placed instructions between one s_and_saveexec and one s_mov exec. From the
+// C++ form the compiler builds, per slot, saveexec + a branch around the (out-of-line) body + s_or exec + the test
+// of the wave-uniform `diag` flag with its branch: five scalar / branch instructions for three vector ones and
+// the ds_add -- 0.63e9 scalar instructions per C3 launch through the ONE scalar unit of a CU, 2.3e8 branches.
+template <int B, int THREADS, int CAPJ, int CAPL, int GROUP, bool SLOT_ASM>
 __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArgs a) {
     static_assert(CAPJ <= 8192, "13 bits of column index in an item");
     static_assert(GROUP >= 1 && GROUP <= 4, "group size");
@@ -787,8 +791,9 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
     }
     for (uint32_t i = tid; i < B * ROW_WORDS; i += THREADS) tile32[i] = 0u;
 
-    unsigned long long n_updates = 0;  // lane 0 of each wave carries the wave's count
+    unsigned long long n_updates = 0;  // per lane; lane 0 also carries the wave-uniform counts
     uint32_t upd_w = 0;                // this wave's pairs in the current range (wave-uniform)
+    uint32_t upd_lane = 0;             // ... and those counted per lane (the hand-placed slots)
     uint32_t ring_head = 0, ring_tail = 0;  // wave-uniform, free-running
 
     // the next range, in flight in registers while the current one is paired
@@ -864,6 +869,9 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
         // one (row entry, column entry) incidence per lane of `in`. w = col32_of(column entry): the address is
         // row + its low half, the base test its third byte against the row entry's base -- with sub-dword
         // operand selects three vector instructions and the ds_add
+        // the tile's place in LDS as ds_add takes it (the dynamic segment starts behind whatever static LDS the
+        // kernel's helpers use): folded into the row offset of the hand-placed slot
+        const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds_raw);
         auto pair_slot = [&](uint32_t rec9, uint32_t row_byte, uint32_t w, unsigned long long in) {
             if (DIAG) in &= __ballot((w & 0xFFFFu) != ((rec9 & C_CELL) << 2));  // same cell (:215)
             upd_w += (uint32_t)__popcll(in);
@@ -871,6 +879,26 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
             if (__builtin_amdgcn_inverse_ballot_w64(in))
                 atomicAdd(reinterpret_cast<uint32_t *>(lds_raw + addr),
                           (w >> 16) != (rec9 >> C_BASE_SHIFT) ? 0x10000u : 1u);
+        };
+        // SLOT_ASM, tiles off the diagonal (all but one in num_blocks): exec = in; same base? (third byte of w
+        // against the row entry's base); address = row + low half of w; 1 or 0x10000; ds_add; exec back. (The
+        // s_nop covers the SDWA compare's write of vcc before v_cndmask reads it, as in the compiler's own
+        // sequence. lgkmcnt: the compiler does not see this ds_add; LDS returns in order, so its counted waits
+        // for earlier reads can only become stricter.)
+        auto pair_slot_asm = [&](uint32_t rbase, uint32_t row_addr, uint32_t w, unsigned long long in) {
+            uint32_t addr, val;
+            unsigned long long saved;
+            asm volatile("s_and_saveexec_b64 %[saved], %[in]\n\t"
+                         "v_cmp_eq_u32_sdwa vcc, %[w], %[rb] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                         "v_add_u32_sdwa %[addr], %[row], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD "
+                         "src1_sel:WORD_0\n\t"
+                         "s_nop 0\n\t"
+                         "v_cndmask_b32_e64 %[val], %[k], 1, vcc\n\t"
+                         "ds_add_u32 %[addr], %[val]\n\t"
+                         "s_mov_b64 exec, %[saved]"
+                         : [saved] "=&s"(saved), [addr] "=&v"(addr), [val] "=&v"(val)
+                         : [in] "s"(in), [w] "v"(w), [rb] "v"(rbase), [row] "v"(row_addr), [k] "v"(0x10000u)
+                         : "vcc", "memory");
         };
 
         // 64 items, each against its first GROUP column entries; items with more go to the ring.
@@ -891,8 +919,16 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
 #pragma unroll
             for (int u = 0; u < GROUP; ++u) in[u] = __ballot(c > (uint32_t)u);
             const unsigned long long more = __ballot(c > (uint32_t)GROUP);
+            // (the wave-uniform `diag` flag is tested once per group, not once per slot)
+            if (SLOT_ASM && !DIAG) {
+                const uint32_t rbase = rec9 >> C_BASE_SHIFT, row_addr = lds_base + row_byte;
+                upd_lane += min(c, (uint32_t)GROUP);  // off the diagonal every slot is a pair: counted per lane, not per slot
 #pragma unroll
-            for (int u = 0; u < GROUP; ++u) pair_slot(rec9, row_byte, w[u], in[u]);
+                for (int u = 0; u < GROUP; ++u) pair_slot_asm(rbase, row_addr, w[u], in[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < GROUP; ++u) pair_slot(rec9, row_byte, w[u], in[u]);
+            }
             if (more) {
                 if (__builtin_amdgcn_inverse_ballot_w64(more)) {
                     const uint32_t slot = ring_tail + __builtin_amdgcn_mbcnt_hi(
@@ -939,6 +975,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
 
             const uint32_t nI = ie - ib;
             upd_w = 0;
+            upd_lane = 0;
             if (staged) {
                 // items of this thread's row entries: the column entries of the entry's locus are
                 // sJ[j0 .. j0 + c); in a diagonal tile the entries after this one (each pair once)
@@ -1045,6 +1082,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
                 }
                 n_updates += upd;
             }
+            n_updates += upd_lane;
             if (lane == 0u) n_updates += upd_w;
         }
     }
@@ -1086,6 +1124,486 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
             atomicAdd(&a.counters[0], u);
             atomicAdd(&a.counters[1], u);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// accumulate_masks: clustered loci (the 8-locus window masks staged), in the shape of accumulate_counts.
+//
+// accumulate_tiles<MASKS> flattens a batch's pairs over the lanes and then walks, per pair, a chain of
+// dependent LDS reads (owner strip -> row record -> row mask -> column entry -> column mask -> table): one
+// pair per lane and trip, nothing in flight beside it. Here the row side lives in registers as in
+// accumulate_counts -- a thread keeps its JPT row entries of the range as items {entry bits, first column
+// entry, count} plus the entry's window mask --, a wave pairs 64 items with GROUP column entries each, the
+// column entry and its mask arrive in ONE 8-byte LDS read, issued for the next item before the current one
+// is paired, and the value comes out of ONE unconditional table read: with x_s / x_d counted over the
+// windows' shared loci plus this locus, D(1,0) and D(0,1) are table entries like the joint terms. Longer
+// items go through the wave's ring (item and mask), 32 or more column entries are paired by the whole wave.
+// A pair of two multi-locus reads is owned by its first shared locus (prev masks disjoint), as before;
+// reads whose window overflowed (C_WIDE) need the 16-byte records and the entry indices: pileups that have
+// any keep to accumulate_tiles (launch_accumulate).
+// ------------------------------------------------------------------------------------------------
+constexpr int MASKS_RING = 128;
+constexpr uint32_t MK_J_SHIFT = 12, MK_J_MASK = 0xFFFu, MK_C_SHIFT = 24, MK_REC_MASK = 0xFFFu;
+
+template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
+__global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs a) {
+    static_assert(CAPJ <= 4096, "12 bits of column index in an item");
+    static_assert(GROUP >= 1 && GROUP <= 4, "group size");
+    constexpr size_t TILE_BYTES = (size_t)B * B * 8;
+    constexpr int WAVES = THREADS / 64;
+    constexpr int JPT = (CAPJ + THREADS - 1) / THREADS;      // staged / held entries per thread
+    constexpr int OPT = (CAPL + 1 + THREADS - 1) / THREADS;  // staged offsets per thread
+    constexpr int RING = MASKS_RING;
+
+    // LDS: [ tile | sJ CAPJ x {entry bits, window mask} | sOff CAPL+2 u16 | sLut | per wave: ring of {item, mask} ]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long *tile64 = reinterpret_cast<unsigned long long *>(lds_raw);
+    uint2 *sJ = reinterpret_cast<uint2 *>(lds_raw + TILE_BYTES);
+    uint16_t *sOff = reinterpret_cast<uint16_t *>(sJ + CAPJ);
+    long long *sLut = reinterpret_cast<long long *>(sOff + CAPL + 2);
+    uint2 *ring = reinterpret_cast<uint2 *>(sLut + SLUT_DIM * SLUT_DIM) + (threadIdx.x >> 6) * RING;
+
+    const uint32_t t_local = a.wg_tile[blockIdx.x];
+    const uint32_t t = a.tile_ids ? a.tile_ids[t_local] : a.tile_begin + t_local;
+    const uint32_t chunk = blockIdx.x - a.tile_wg_begin[t_local];
+    const uint32_t n_chunks_t = a.tile_wg_begin[t_local + 1] - a.tile_wg_begin[t_local];
+    const uint32_t I = a.tile_row[t], J = a.tile_col[t];
+    const bool DIAG = (I == J);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t *offI = a.blk_off + (size_t)I * a.stride;
+    const uint32_t *offJ = a.blk_off + (size_t)J * a.stride;
+    // chunks: equal shares of the tile's row-side entries (see accumulate_tiles)
+    uint32_t r_begin = 0, r_end = a.num_ranges;
+    uint32_t row_begin = 0u, row_end = 0xFFFFFFFFu;
+    if (n_chunks_t > 1u) {
+        const uint32_t L = a.stride - 1u;
+        const uint32_t e0 = offI[0];
+        const unsigned long long n_row = offI[L] - e0;
+        row_begin = e0 + (uint32_t)(n_row * chunk / n_chunks_t);
+        row_end = e0 + (uint32_t)(n_row * (chunk + 1u) / n_chunks_t);
+        uint32_t before = 0, upto = 0;
+        for (uint32_t base = 0; base < a.num_ranges; base += THREADS) {
+            const uint32_t k = base + tid;
+            bool ends_before = false, begins_inside = false;
+            if (k < a.num_ranges) {
+                ends_before = offI[a.range_off[k + 1u]] <= row_begin;
+                begins_inside = offI[a.range_off[k]] < row_end;
+            }
+            before += (uint32_t)__syncthreads_count(ends_before);
+            upto += (uint32_t)__syncthreads_count(begins_inside);
+        }
+        r_begin = __builtin_amdgcn_readfirstlane(before);
+        r_end = __builtin_amdgcn_readfirstlane(upto);
+        row_begin = __builtin_amdgcn_readfirstlane(row_begin);
+        row_end = __builtin_amdgcn_readfirstlane(row_end);
+    }
+    for (uint32_t i = tid; i < B * B; i += THREADS) tile64[i] = 0ull;
+    for (uint32_t i = tid; i < SLUT_DIM * SLUT_DIM; i += THREADS) sLut[i] = a.lut[(i / SLUT_DIM) * LUT_DIM + (i % SLUT_DIM)];
+
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B;
+    unsigned long long n_updates = 0, n_pairs = 0;  // lane 0 of each wave carries the wave's counts
+    uint32_t upd_w = 0, skip_w = 0;                 // this wave's incidences / not-owned incidences in the range
+    uint32_t ring_head = 0, ring_tail = 0;          // wave-uniform, free-running
+
+    // the next range, in flight in registers while the current one is paired
+    uint32_t pJ[JPT], pMj[JPT], pI[JPT], pMi[JPT], pO[OPT];
+    uint32_t n_la = 0, n_lb = 0, n_ib = 0, n_ie = 0, n_jb = 0, n_je = 0, n_dsh = 0;
+    bool n_staged = false;
+    uint32_t q_la = 0, q_lb = 0;  // locus span of the range `ahead` holds the offsets of
+    uint32_t ahead = 0;           // lanes 0-3: offsets of the next range; lanes 4-5: span of the one after
+    auto fetch_ahead = [&](uint32_t r) {
+        const uint32_t *src = lane == 0u ? offI + q_la : lane == 1u ? offI + q_lb : lane == 2u ? offJ + q_la
+                            : lane == 3u ? offJ + q_lb : a.range_off + (r + lane - 3u);
+        ahead = 0u;
+        if (lane < 4u || (lane < 6u && r + 1u < r_end)) ahead = *src;
+    };
+    auto prefetch = [&](uint32_t r) {
+        n_la = q_la;
+        n_lb = q_lb;
+        const uint32_t range_ib = __builtin_amdgcn_readlane(ahead, 0);
+        n_ib = max(range_ib, row_begin);  // this chunk's part of the range's row side
+        n_ie = max(n_ib, min((uint32_t)__builtin_amdgcn_readlane(ahead, 1), row_end));
+        n_dsh = n_ib - range_ib;
+        n_jb = __builtin_amdgcn_readlane(ahead, 2);
+        n_je = __builtin_amdgcn_readlane(ahead, 3);
+        q_la = __builtin_amdgcn_readlane(ahead, 4);
+        q_lb = __builtin_amdgcn_readlane(ahead, 5);
+        if (r + 1u < r_end) fetch_ahead(r + 1u);
+        n_staged = (n_je - n_jb) <= (uint32_t)CAPJ && (n_ie - n_ib) <= (uint32_t)CAPJ
+                && (n_lb - n_la) <= (uint32_t)CAPL;
+        // buffer loads: the descriptor bounds the slice, a lane past the end gets 0 (see accumulate_counts)
+        if (n_staged) {
+            const int nj = (int)((n_je - n_jb) * 4u);
+            const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.entry32 + n_jb), 0, nj, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.mask32 + n_jb), 0, nj, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<uint32_t *>(offJ + n_la), 0, (int)((n_lb - n_la + 1u) * 4u), 0x00020000);
+#pragma unroll
+            for (int k = 0; k < JPT; ++k) {
+                pJ[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rj, (int)(tid * 4u), k * THREADS * 4, 0);
+                pMj[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rm, (int)(tid * 4u), k * THREADS * 4, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < OPT; ++k)
+                pO[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ro, (int)(tid * 4u), k * THREADS * 4, 0);
+        }
+    };
+    auto prefetch_rows = [&]() {
+        if (n_staged) {
+            const int ni = (int)((n_ie - n_ib) * 4u);
+            const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.entry32 + n_ib), 0, ni, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.mask32 + n_ib), 0, ni, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < JPT; ++k) {
+                pI[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, (int)(tid * 4u), k * THREADS * 4, 0);
+                pMi[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rm, (int)(tid * 4u), k * THREADS * 4, 0);
+            }
+        }
+    };
+    if (r_begin < r_end) {
+        q_la = __builtin_amdgcn_readfirstlane(a.range_off[r_begin]);
+        q_lb = __builtin_amdgcn_readfirstlane(a.range_off[r_begin + 1u]);
+        fetch_ahead(r_begin);
+        prefetch(r_begin);
+        prefetch_rows();
+    }
+
+    // GROUP (row entry, column entry) incidences per lane: `rec` / `m1` the row entry's bits and window mask,
+    // w2[u] = {column entry bits, its window mask}, in[u] = the lanes that have a u-th column entry.
+    // Phase 1 decides who pairs, who owns, and the table index; phase 2 reads the table (all GROUP reads in
+    // flight together); phase 3 adds.
+    auto pair_group = [&](uint32_t rec, uint32_t m1, const uint2 (&w2)[GROUP], unsigned long long (&in)[GROUP]) {
+        const uint32_t row = (rec & C_CELL) * (uint32_t)B;
+        uint32_t idx[GROUP], cell[GROUP];
+        unsigned long long add[GROUP];
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) {
+            const uint32_t w = w2[u].x, m2 = w2[u].y;
+            const uint32_t x = rec ^ w, both = rec & w;
+            // reads both never flushed do not pair (:407-408); in a diagonal tile equal cells do not pair (:215);
+            // a pair with a read that reaches beyond its windows is left to wide_pairs
+            const bool ok = (both & C_TAIL) == 0u && (!DIAG || (x & C_CELL) != 0u) && ((rec | w) & C_WIDE) == 0u;
+            const unsigned long long act = in[u] & __ballot(ok);
+            upd_w += (uint32_t)__popcll(act);
+            const bool differ = (x & (3u << C_BASE_SHIFT)) != 0u;
+            // two multi-locus reads: the pair belongs to their first shared locus; x_s / x_d over the shared loci
+            // of the two windows behind this one, plus this locus. Anything else shares this locus only.
+            const bool joint = (both & C_MULTI) != 0u;
+            const uint32_t mm = joint ? (m1 & m2) : 0u;
+            const bool owner = (mm & 0xFFu) == 0u;
+            const uint32_t shared = (mm >> 8) & 0xFFu;
+            const uint32_t y = m1 ^ m2;
+            const uint32_t nd = __popc(((y >> 16) | (y >> 24)) & shared);
+            const uint32_t xd = nd + (differ ? 1u : 0u);
+            const uint32_t xs = __popc(shared) - nd + (differ ? 0u : 1u);
+            idx[u] = xs * SLUT_DIM + xd;  // x_s + x_d <= 9: inside the table, whatever a masked lane holds
+            cell[u] = row + (w & C_CELL);
+            add[u] = act & __ballot(owner);
+            skip_w += (uint32_t)__popcll(act) - (uint32_t)__popcll(add[u]);
+        }
+        long long v[GROUP];
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) v[u] = sLut[idx[u]];
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u)
+            if (__builtin_amdgcn_inverse_ballot_w64(add[u])) atomicAdd(&tile64[cell[u]], (unsigned long long)v[u]);
+    };
+    auto group_load = [&](uint32_t item, uint2 (&w2)[GROUP]) {
+        const uint2 *p = sJ + ((item >> MK_J_SHIFT) & MK_J_MASK);
+        // (lanes with fewer than GROUP read on inside the staging area or the offsets behind it: masked by `in`)
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) w2[u] = p[u];
+    };
+    auto group_pair = [&](uint32_t item, uint32_t m1, const uint2 (&w2)[GROUP]) {
+        const uint32_t c = item >> MK_C_SHIFT;
+        unsigned long long in[GROUP];
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) in[u] = __ballot(c > (uint32_t)u);
+        const unsigned long long more = __ballot(c > (uint32_t)GROUP);
+        pair_group(item & MK_REC_MASK, m1, w2, in);
+        if (more) {
+            if (__builtin_amdgcn_inverse_ballot_w64(more)) {
+                const uint32_t slot = ring_tail + __builtin_amdgcn_mbcnt_hi(
+                        (uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                ring[slot & (RING - 1)] = make_uint2(item + ((uint32_t)GROUP << MK_J_SHIFT) - ((uint32_t)GROUP << MK_C_SHIFT), m1);
+            }
+            ring_tail += (uint32_t)__popcll(more);
+        }
+    };
+    auto drain_one = [&]() {  // one batch from the ring (up to 64 items)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n = min(64u, ring_tail - ring_head);
+        uint2 it = make_uint2(0u, 0u);
+        if (lane < n) it = ring[(ring_head + lane) & (RING - 1)];
+        __builtin_amdgcn_wave_barrier();
+        ring_head += n;
+        uint2 w2[GROUP];
+        group_load(it.x, w2);
+        group_pair(it.x, it.y, w2);
+    };
+
+    for (uint32_t r = r_begin; r < r_end; ++r) {
+        const uint32_t la = n_la, ib = n_ib, ie = n_ie, jb = n_jb, dsh = n_dsh;
+        const bool staged = n_staged;
+        __syncthreads();  // every wave is done with the previous range (first time: with zeroing)
+        if (staged) {
+            static_assert(JPT * THREADS <= CAPJ && OPT * THREADS <= CAPL + 2, "unconditional staging stores");
+#pragma unroll
+            for (int k = 0; k < JPT; ++k) sJ[tid + k * THREADS] = make_uint2(pJ[k] & 0xFFFFu, pMj[k]);
+#pragma unroll
+            for (int k = 0; k < OPT; ++k) sOff[tid + k * THREADS] = (uint16_t)(pO[k] - jb);
+        }
+        __syncthreads();
+        const uint32_t nI = ie - ib;
+        upd_w = 0;
+        skip_w = 0;
+        if (staged) {
+            uint32_t item[JPT], im[JPT];
+            uint32_t any_wide = 0;
+#pragma unroll
+            for (int k = 0; k < JPT; ++k) {
+                const uint32_t i = tid + k * THREADS;
+                const uint32_t rec = pI[k];
+                const uint32_t lrel = rec >> 16;
+                uint32_t j0 = sOff[lrel];
+                const uint32_t j1 = sOff[lrel + 1];
+                if (DIAG) j0 = i + dsh + 1u;  // a diagonal tile: the entries after this one, each pair once
+                const uint32_t c = (i < nI && j1 > j0) ? j1 - j0 : 0u;
+                any_wide |= c;
+                item[k] = (rec & MK_REC_MASK) | ((j0 & MK_J_MASK) << MK_J_SHIFT) | (c << MK_C_SHIFT);
+                im[k] = pMi[k];
+            }
+            // wide entries (32 column entries or more): the whole wave pairs one row entry with 64 at a time
+            if (__ballot(any_wide >= IT_WIDE)) {
+#pragma unroll
+                for (int k = 0; k < JPT; ++k) {
+                    const uint32_t i = tid + k * THREADS;
+                    const uint32_t rec = pI[k];
+                    const uint32_t lrel = rec >> 16;
+                    uint32_t j0 = sOff[lrel];
+                    const uint32_t j1 = sOff[lrel + 1];
+                    if (DIAG) j0 = i + dsh + 1u;
+                    const uint32_t c = (i < nI && j1 > j0) ? j1 - j0 : 0u;
+                    unsigned long long todo = __ballot(c >= IT_WIDE);
+                    while (todo) {
+                        const int src = __builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        const uint32_t recw = __builtin_amdgcn_readlane(rec, src) & MK_REC_MASK;
+                        const uint32_t m1w = __builtin_amdgcn_readlane(pMi[k], src);
+                        const uint32_t cw = __builtin_amdgcn_readlane(c, src);
+                        const uint32_t j0w = __builtin_amdgcn_readlane(j0, src);
+                        for (uint32_t base = 0; base < cw; base += 64u) {
+                            uint2 w2[GROUP];
+                            unsigned long long in[GROUP];
+                            w2[0] = sJ[min(j0w + base + lane, (uint32_t)CAPJ - 1u)];
+                            in[0] = __ballot(base + lane < cw);
+#pragma unroll
+                            for (int u = 1; u < GROUP; ++u) {
+                                w2[u] = w2[0];
+                                in[u] = 0ull;
+                            }
+                            pair_group(recw, m1w, w2, in);
+                        }
+                    }
+                    if (c >= IT_WIDE) item[k] = 0u;  // done
+                }
+            }
+            if (r + 1 < r_end) prefetch(r + 1);  // the column-side registers are free again
+            {
+                uint2 wc[GROUP], wn[GROUP];
+                group_load(item[0], wc);
+#pragma unroll
+                for (int k = 0; k < JPT; ++k) {
+                    if (k + 1 < JPT) group_load(item[k + 1], wn);
+                    while (ring_tail - ring_head > (uint32_t)(RING - 64)) drain_one();  // room for 64 continuations
+                    group_pair(item[k], im[k], wc);
+#pragma unroll
+                    for (int u = 0; u < GROUP; ++u) wc[u] = wn[u];
+                }
+            }
+            if (r + 1 < r_end) prefetch_rows();
+            while (ring_tail != ring_head) drain_one();
+        } else {
+            if (r + 1 < r_end) {
+                prefetch(r + 1);
+                prefetch_rows();
+            }
+            // a locus range that does not fit the staging buffers (a single very deep locus): paired straight
+            // from HBM/L2 with the compact entries, straight into HBM (as accumulate_tiles does)
+            const long long d10 = a.lut[1 * LUT_DIM + 0], d01 = a.lut[0 * LUT_DIM + 1];
+            uint32_t upd = 0, skipped = 0;
+            for (uint32_t e1 = ib + tid; e1 < ie; e1 += THREADS) {
+                const uint32_t r1 = a.entry32[e1];
+                const uint32_t l = la + (r1 >> 16);
+                const uint32_t j0 = DIAG ? e1 + 1 : offJ[l];
+                const uint32_t j1 = offJ[l + 1];
+                const uint32_t row = (r1 & C_CELL) * B;
+                for (uint32_t e2 = j0; e2 < j1; ++e2) {
+                    const uint32_t r2 = a.entry32[e2];
+                    const uint32_t x = r1 ^ r2, both = r1 & r2;
+                    if (DIAG && (x & C_CELL) == 0u) continue;  // same cell (:215)
+                    if (both & C_TAIL) continue;               // both never flushed (:407-408)
+                    if ((r1 | r2) & C_WIDE) continue;          // wide_pairs
+                    ++upd;
+                    long long v = (x & (3u << C_BASE_SHIFT)) ? d01 : d10;
+                    if (both & C_MULTI) {
+                        v = pair_value_full(a.slow, e1, e2);
+                        if (v == NO_PAIR) {
+                            ++skipped;
+                            continue;
+                        }
+                    }
+                    atomicAdd(&dst[row + (r2 & C_CELL)], (unsigned long long)v);
+                }
+            }
+            n_updates += upd;
+            n_pairs += (unsigned long long)upd - skipped;
+        }
+        if (lane == 0u) {
+            n_updates += upd_w;
+            n_pairs += (unsigned long long)upd_w - skip_w;
+        }
+    }
+    __syncthreads();
+
+    // flush: the tile goes to the workgroup's own slab with plain coalesced stores; reduce_slabs adds up
+    {
+        uint4 *out = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned long long *>(a.slab) + (size_t)blockIdx.x * B * B);
+        const uint4 *src = reinterpret_cast<const uint4 *>(tile64);
+        for (uint32_t i = tid; i < B * B / 2; i += THREADS) out[i] = src[i];
+    }
+    // work counters: wave reduction, then one atomic pair per workgroup (see accumulate_tiles)
+    for (int off = 32; off > 0; off >>= 1) {
+        n_updates += __shfl_down(n_updates, off);
+        n_pairs += __shfl_down(n_pairs, off);
+    }
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(sJ);
+    if (lane == 0u) {
+        red[(tid >> 6) * 2] = n_updates;
+        red[(tid >> 6) * 2 + 1] = n_pairs;
+    }
+    __syncthreads();
+    if (tid == 0u) {
+        unsigned long long u = 0, q = 0;
+        for (int w = 0; w < WAVES; ++w) {
+            u += red[w * 2];
+            q += red[w * 2 + 1];
+        }
+        if (u | q) {
+            atomicAdd(&a.counters[0], u);
+            atomicAdd(&a.counters[1], q);
+        }
+    }
+}
+
+// ---- reads that reach beyond their 8-locus windows (C_WIDE): rare where loci are a read length apart (C2 clustered:
+// 0.01 % of the reads), and what they need -- the 16-byte records, the entry indices, sometimes the merge walk --
+// is what the hot loop of accumulate_masks does without. Their entries are listed per cell block once per prepare
+// (count, scan, fill: entries of a block are contiguous in the packed arrays), and wide_pairs adds every pair
+// with at least one of them to the accumulator after the main kernel: a workgroup per tile, a thread per
+// (wide entry, partner entry) run.
+__global__ __launch_bounds__(256) void k_wide_count(const uint32_t *entry32, const uint32_t *blk_off, uint32_t stride,
+                                                   uint32_t *cnt) {
+    const uint32_t b = blockIdx.y, e0 = blk_off[(size_t)b * stride], e1 = blk_off[(size_t)b * stride + stride - 1u];
+    uint32_t n = 0;
+    for (uint32_t d = e0 + blockIdx.x * 256 + threadIdx.x; d < e1; d += gridDim.x * 256) n += (entry32[d] & C_WIDE) ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
+    if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&cnt[b], n);
+}
+// off[0 .. nb] = exclusive scan of cnt[0 .. nb), cur[b] = off[b] (the fill's cursors); one workgroup
+__global__ __launch_bounds__(1024) void k_wide_scan(const uint32_t *cnt, uint32_t nb, uint32_t *off, uint32_t *cur) {
+    __shared__ uint32_t s[1024];
+    const uint32_t tid = threadIdx.x;
+    s[tid] = tid < nb ? cnt[tid] : 0u;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = tid >= d ? s[tid - d] : 0u;
+        __syncthreads();
+        s[tid] += v;
+        __syncthreads();
+    }
+    if (tid < nb) {
+        const uint32_t ex = s[tid] - cnt[tid];
+        off[tid] = ex;
+        cur[tid] = ex;
+    }
+    if (tid == nb - 1u) off[nb] = s[tid];
+}
+__global__ __launch_bounds__(256) void k_wide_fill(const uint32_t *entry32, const uint32_t *blk_off, uint32_t stride,
+                                                  uint32_t *cur, uint32_t *list) {
+    const uint32_t b = blockIdx.y, e0 = blk_off[(size_t)b * stride], e1 = blk_off[(size_t)b * stride + stride - 1u];
+    for (uint32_t d = e0 + blockIdx.x * 256 + threadIdx.x; d < e1; d += gridDim.x * 256)
+        if (entry32[d] & C_WIDE) list[atomicAdd(&cur[b], 1u)] = d;
+}
+
+struct WideArgs {
+    const uint32_t *blk_off;
+    uint32_t stride;
+    const uint32_t *entry32;
+    const uint4 *entry;
+    const SlowPathArgs *slow;
+    const long long *lut;
+    const uint16_t *tile_row, *tile_col;
+    uint32_t tile_begin;
+    const uint32_t *tile_ids;
+    const uint32_t *wide_off, *wide_list;
+    long long *acc;
+    unsigned long long *counters;
+};
+template <int B>
+__global__ __launch_bounds__(256) void wide_pairs(const WideArgs a) {
+    const uint32_t t = a.tile_ids ? a.tile_ids[blockIdx.x] : a.tile_begin + blockIdx.x;
+    const uint32_t I = a.tile_row[t], J = a.tile_col[t];
+    const bool diag = I == J;
+    const long long d10 = a.lut[1 * LUT_DIM + 0], d01 = a.lut[0 * LUT_DIM + 1];
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B;
+    uint32_t upd = 0, skipped = 0;
+    // side 0: the wide entries of block I as row entries against every entry of block J at their locus (in a
+    // diagonal tile: against the non-wide entries, and the wide ones behind them -- each pair once);
+    // side 1 (I != J): the wide entries of block J as column entries against the NON-wide entries of block I
+    for (int side = 0; side < (diag ? 1 : 2); ++side) {
+        const uint32_t bw = side ? J : I, bo = side ? I : J;
+        const uint32_t *off_o = a.blk_off + (size_t)bo * a.stride;
+        for (uint32_t k = a.wide_off[bw] + threadIdx.x; k < a.wide_off[bw + 1]; k += 256) {
+            const uint32_t ew = a.wide_list[k];
+            const uint32_t rw = a.entry32[ew];
+            const uint32_t l = a.entry[ew].w;  // (every wide entry is multi-locus: it has its 16-byte record)
+            for (uint32_t eo = off_o[l]; eo < off_o[l + 1]; ++eo) {
+                const uint32_t ro = a.entry32[eo];
+                if (ro & C_WIDE) {
+                    if (side == 1) continue;          // wide x wide: side 0 has it
+                    if (diag && eo <= ew) continue;   // ... and in a diagonal tile the earlier of the two
+                } else if (diag && eo == ew) {
+                    continue;
+                }
+                const uint32_t x = rw ^ ro, both = rw & ro;
+                if (diag && (x & C_CELL) == 0u) continue;  // same cell (:215)
+                if (both & C_TAIL) continue;               // both never flushed (:407-408)
+                ++upd;
+                long long v = (x & (3u << C_BASE_SHIFT)) ? d01 : d10;
+                const uint32_t e_row = side ? eo : ew, e_col = side ? ew : eo;
+                if (both & C_MULTI) {
+                    v = pair_value_full(a.slow, e_row, e_col);
+                    if (v == NO_PAIR) {
+                        ++skipped;
+                        continue;
+                    }
+                }
+                const uint32_t r_row = side ? ro : rw, r_col = side ? rw : ro;
+                atomicAdd(&dst[(r_row & C_CELL) * B + (r_col & C_CELL)], (unsigned long long)v);
+            }
+        }
+    }
+    unsigned long long u = upd, q = (unsigned long long)upd - skipped;
+    for (int off = 32; off > 0; off >>= 1) {
+        u += __shfl_down(u, off);
+        q += __shfl_down(q, off);
+    }
+    if ((threadIdx.x & 63u) == 0u && (u | q)) {
+        atomicAdd(&a.counters[0], u);
+        atomicAdd(&a.counters[1], q);
     }
 }
 
@@ -1581,13 +2099,55 @@ template <int B>
 hipError_t launch_correct(const AccumulateArgs &args, hipStream_t stream, const SideStream *side);
 
 template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
-hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t stream, const SideStream *side,
-                         hipEvent_t mid) {
+hipError_t launch_masks(const AccumulateArgs &args, uint32_t grid, hipStream_t stream) {
+    constexpr size_t lds = (size_t)B * B * 8 + (size_t)CAPJ * 8 + ((size_t)CAPL + 2) * 2 + SLUT_DIM * SLUT_DIM * 8
+            + (size_t)(THREADS / 64) * MASKS_RING * 8;
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    static_assert((CAPL + 2) % 4 == 0 && CAPJ % 8 == 0, "alignment of the LDS carve-up");
+    auto kern = &accumulate_masks<B, THREADS, CAPJ, CAPL, GROUP>;
+    static thread_local int configured_device = -1;  // the attribute is per device and sticky
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (configured_device != dev) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        if (e != hipSuccess) return e;
+        configured_device = dev;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
+    hipLaunchKernelGGL((reduce_slabs<B, false>), dim3(args.n_tiles * (B * B / 256)), dim3(256), 0, stream, args.slab,
+                       args.tile_wg_begin, args.tile_begin, args.tile_ids, args.lut,
+                       reinterpret_cast<long long *>(args.acc));
+    if (args.wide_list) {  // the pairs of reads that reach beyond their windows
+        WideArgs w;
+        w.blk_off = args.blk_off;
+        w.stride = args.stride;
+        w.entry32 = args.entry32;
+        w.entry = args.entry;
+        w.slow = args.slow;
+        w.lut = args.lut;
+        w.tile_row = args.tile_row;
+        w.tile_col = args.tile_col;
+        w.tile_begin = args.tile_begin;
+        w.tile_ids = args.tile_ids;
+        w.wide_off = args.wide_off;
+        w.wide_list = args.wide_list;
+        w.acc = reinterpret_cast<long long *>(args.acc);
+        w.counters = args.counters;
+        hipLaunchKernelGGL((wide_pairs<B>), dim3(args.n_tiles), dim3(256), 0, stream, w);
+    }
+    return hipGetLastError();
+}
+
+template <int B, int THREADS, int CAPJ, int CAPL, int GROUP, bool SLOT_ASM>
+hipError_t launch_counts_v(const AccumulateArgs &args, uint32_t grid, hipStream_t stream, const SideStream *side,
+                           hipEvent_t mid) {
     constexpr size_t lds = ((size_t)B * (B + 1) * 4 + 15) / 16 * 16 + (size_t)CAPJ * 4 + ((size_t)CAPL + 2) * 2
             + (size_t)(THREADS / 64) * (size_t)COUNTS_RING * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((CAPL + 2) % 4 == 0 && CAPJ % 8 == 0, "alignment of the LDS carve-up");
-    auto kern = &accumulate_counts<B, THREADS, CAPJ, CAPL, GROUP>;
+    auto kern = &accumulate_counts<B, THREADS, CAPJ, CAPL, GROUP, SLOT_ASM>;
     static thread_local int configured_device = -1;  // the attribute is per device and sticky
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1601,6 +2161,15 @@ hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
     if (mid && (e = hipEventRecord(mid, stream)) != hipSuccess) return e;
     return launch_correct<B>(args, stream, side);
+}
+
+// (SECEDO_SLOT_ASM=0: the compiler's pair slot, for A/B measurements)
+template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
+hipError_t launch_counts(const AccumulateArgs &args, uint32_t grid, hipStream_t stream, const SideStream *side,
+                         hipEvent_t mid) {
+    static const bool slot_asm = [] { const char *e = std::getenv("SECEDO_SLOT_ASM"); return !(e && std::atoi(e) == 0); }();
+    return slot_asm ? launch_counts_v<B, THREADS, CAPJ, CAPL, GROUP, true>(args, grid, stream, side, mid)
+                    : launch_counts_v<B, THREADS, CAPJ, CAPL, GROUP, false>(args, grid, stream, side, mid);
 }
 
 // The second kernel of the sparse-loci path, after the pair kernel.
@@ -1708,6 +2277,22 @@ hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint
     return hipGetLastError();
 }
 
+hipError_t wide_count(const uint32_t *entry32, const uint32_t *blk_off, uint32_t stride, uint32_t num_blocks,
+                      uint32_t *cnt, uint32_t *off, uint32_t *cur, hipStream_t stream) {
+    if (num_blocks == 0 || num_blocks > 1024) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)num_blocks * 4, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_wide_count, dim3(16, num_blocks), dim3(256), 0, stream, entry32, blk_off, stride, cnt);
+    hipLaunchKernelGGL(k_wide_scan, dim3(1), dim3(1024), 0, stream, cnt, num_blocks, off, cur);
+    return hipGetLastError();
+}
+
+hipError_t wide_fill(const uint32_t *entry32, const uint32_t *blk_off, uint32_t stride, uint32_t num_blocks,
+                     uint32_t *cur, uint32_t *list, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wide_fill, dim3(16, num_blocks), dim3(256), 0, stream, entry32, blk_off, stride, cur, list);
+    return hipGetLastError();
+}
+
 size_t accumulate_slab_bytes(uint32_t block_cells, bool count_tile, uint32_t n_workgroups) {
     return (size_t)n_workgroups * block_cells * block_cells * (count_tile ? 4 : 8);
 }
@@ -1751,6 +2336,7 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
         if (count_tile) return launch_acc<128, 1024, kCapJ128C, kCapL128C, 1024, false, true>(args, grid, stream);
         return launch_acc<128, 1024, kCapJ128, kCapL128, 512, false, false>(args, grid, stream);
     }
+    if (stage_masks && args.masks_kernel) return launch_masks<64, 512, kCapJ64M, kCapL64M, 4>(args, grid, stream);
     if (stage_masks) return launch_acc<64, 512, kCapJ64M, kCapL64M, 1024, true, false>(args, grid, stream);
     if (count_tile && pair_mode() != 0) return launch_counts<64, 512, kCapJ64C, kCapL64C, 4>(args, grid, stream, side, mid);
     if (count_tile) return launch_acc<64, 256, kCapJ64C, kCapL64C, 1024, false, true>(args, grid, stream);

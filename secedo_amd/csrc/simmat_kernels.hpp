@@ -19,7 +19,7 @@ struct LlrModelDev {  // LlrModel of llr_table.hpp, by value into the kernel
 // LDS staging geometry of accumulate_tiles per tile size: column-side entries and loci per locus
 // range, without / with the 8-locus window masks staged too. pack_host.cpp cuts the locus ranges
 // to these limits. LDS per workgroup: B=64: 32 KiB tile + 12/28 KiB; B=128: 128 KiB tile + 24/28 KiB.
-constexpr uint32_t kCapJ64 = 4096, kCapL64 = 2046, kCapJ64M = 4096, kCapL64M = 2046, kCapJ64C = 4096, kCapL64C = 2046;
+constexpr uint32_t kCapJ64 = 4096, kCapL64 = 2046, kCapJ64M = 2048, kCapL64M = 2046, kCapJ64C = 4096, kCapL64C = 2046;
 constexpr uint32_t kCapJ128 = 4096, kCapL128 = 2046, kCapJ128M = 4096, kCapL128M = 2046;
 constexpr uint32_t kCapJ128C = 8192, kCapL128C = 8190;  // the 64 KiB count tile leaves room for longer ranges
 constexpr double kMasksThreshold = 0.05;  // stage the masks when > 5 % of the entries are multi-locus
@@ -71,6 +71,9 @@ struct AccumulateArgs {
     const uint32_t *flag_idx = nullptr;     // ... and entry indices
     int group_hint = 4;                     // GROUP of accumulate_counts by the entries per (cell block, locus)
     bool overwrite = false;                 // acc[tiles of the launch] = result (no need to zero them first)
+    bool masks_kernel = false;              // staged masks: accumulate_masks (+ wide_pairs) instead of accumulate_tiles
+    const uint32_t *wide_off = nullptr;     // num_blocks + 1: the C_WIDE entries per cell block ...
+    const uint32_t *wide_list = nullptr;    // ... their entry indices (null: none)
     // counts path, one workgroup per tile (counts_split(n_tiles) == 1), all tiles in one launch: max(0, max D) of
     // the stored tiles by atomicMax, as launch_tile_max leaves it (zeroed by the caller)
     unsigned long long *max_bits = nullptr;
@@ -93,6 +96,13 @@ hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint
                                uint32_t *pre, uint32_t *grp, uint4 *rec, uint32_t *idx, hipStream_t stream);
 
 StageGeometry stage_geometry(uint32_t block_cells);
+// The entries flagged C_WIDE (their read reaches beyond the 8-locus windows), listed per cell block for
+// accumulate_masks' second kernel: wide_count leaves cnt[num_blocks], off[num_blocks + 1] (exclusive scan; the total
+// in off[num_blocks]) and the fill cursors cur[num_blocks]; wide_fill writes the entry indices (room for the total).
+hipError_t wide_count(const uint32_t *entry32, const uint32_t *blk_off, uint32_t stride, uint32_t num_blocks,
+                      uint32_t *cnt, uint32_t *off, uint32_t *cur, hipStream_t stream);
+hipError_t wide_fill(const uint32_t *entry32, const uint32_t *blk_off, uint32_t stride, uint32_t num_blocks,
+                     uint32_t *cur, uint32_t *list, hipStream_t stream);
 
 // workspace of one accumulate launch: a tile per workgroup (plain-store flush, then reduce_slabs)
 size_t accumulate_slab_bytes(uint32_t block_cells, bool count_tile, uint32_t n_workgroups);

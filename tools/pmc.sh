@@ -5,11 +5,11 @@ export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$name
 rm -rf $out
 rocprofv3 --pmc $ctrs --output-format csv -d $out -- python bench.py "$@" --no-cpu-baseline > /dev/null 2> $out.err
-f=$(find $out -name "*counter_collection.csv" | head -1)
-python - "$f" <<'PY'
+python - $(find $out -name "*counter_collection.csv") <<'PY'
 import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
-for row in csv.DictReader(open(sys.argv[1])):
+for f in sys.argv[1:]:  # one file per process of the run (bench.py starts the LDS-atomic microbenchmark as a child)
+  for row in csv.DictReader(open(f)):
     k = row["Kernel_Name"][:60]
     acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
     n[(k, row["Counter_Name"])] += 1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""traffic_json.py <dir> -- profiles/r02_traffic.json from the FETCH_SIZE / WRITE_SIZE passes that
-tools/refresh_profiles_r02.sh left under <dir>: per accumulate_tiles launch, with the counters calibrated
+"""traffic_json.py <dir> -- profiles/r03_traffic.json from the FETCH_SIZE / WRITE_SIZE passes that
+tools/refresh_profiles_r03.sh left under <dir>: per accumulate_tiles launch, with the counters calibrated
 on a known 1 GiB stream in the same run (tools/fetch_calib.hip) as MI355X_MICROARCH.md (HBM) prescribes."""
 import collections
 import csv
@@ -13,11 +13,12 @@ R = sys.argv[1]
 
 
 def per_kernel(sub, counter):
-    f = glob.glob(os.path.join(R, sub, "**", "*counter_collection.csv"), recursive=True)[0]
+    # (every process of the run leaves a file: bench.py also starts the LDS-atomic microbenchmark as a child)
     acc = collections.defaultdict(list)
-    for row in csv.DictReader(open(f)):
-        if row["Counter_Name"] == counter:
-            acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    for f in glob.glob(os.path.join(R, sub, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == counter:
+                acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
     return acc
 
 
