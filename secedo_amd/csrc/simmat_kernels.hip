@@ -791,9 +791,8 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
     }
     for (uint32_t i = tid; i < B * ROW_WORDS; i += THREADS) tile32[i] = 0u;
 
-    unsigned long long n_updates = 0;  // per lane; lane 0 also carries the wave-uniform counts
+    unsigned long long n_updates = 0;  // lane 0 of each wave carries the wave's count
     uint32_t upd_w = 0;                // this wave's pairs in the current range (wave-uniform)
-    uint32_t upd_lane = 0;             // ... and those counted per lane (the hand-placed slots)
     uint32_t ring_head = 0, ring_tail = 0;  // wave-uniform, free-running
 
     // the next range, in flight in registers while the current one is paired
@@ -886,6 +885,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
         // sequence. lgkmcnt: the compiler does not see this ds_add; LDS returns in order, so its counted waits
         // for earlier reads can only become stricter.)
         auto pair_slot_asm = [&](uint32_t rbase, uint32_t row_addr, uint32_t w, unsigned long long in) {
+            upd_w += (uint32_t)__popcll(in);  // (counted per lane instead -- v_min + v_add per group -- C5 took 7 % longer)
             uint32_t addr, val;
             unsigned long long saved;
             asm volatile("s_and_saveexec_b64 %[saved], %[in]\n\t"
@@ -922,7 +922,6 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
             // (the wave-uniform `diag` flag is tested once per group, not once per slot)
             if (SLOT_ASM && !DIAG) {
                 const uint32_t rbase = rec9 >> C_BASE_SHIFT, row_addr = lds_base + row_byte;
-                upd_lane += min(c, (uint32_t)GROUP);  // off the diagonal every slot is a pair: counted per lane, not per slot
 #pragma unroll
                 for (int u = 0; u < GROUP; ++u) pair_slot_asm(rbase, row_addr, w[u], in[u]);
             } else {
@@ -975,7 +974,6 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
 
             const uint32_t nI = ie - ib;
             upd_w = 0;
-            upd_lane = 0;
             if (staged) {
                 // items of this thread's row entries: the column entries of the entry's locus are
                 // sJ[j0 .. j0 + c); in a diagonal tile the entries after this one (each pair once)
@@ -1082,7 +1080,6 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
                 }
                 n_updates += upd;
             }
-            n_updates += upd_lane;
             if (lane == 0u) n_updates += upd_w;
         }
     }
@@ -1202,8 +1199,8 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
     for (uint32_t i = tid; i < SLUT_DIM * SLUT_DIM; i += THREADS) sLut[i] = a.lut[(i / SLUT_DIM) * LUT_DIM + (i % SLUT_DIM)];
 
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B;
-    unsigned long long n_updates = 0, n_pairs = 0;  // lane 0 of each wave carries the wave's counts
-    uint32_t upd_w = 0, skip_w = 0;                 // this wave's incidences / not-owned incidences in the range
+    unsigned long long n_updates = 0, n_pairs = 0;  // per lane
+    uint32_t upd_lane = 0, skip_lane = 0;           // this lane's incidences / not-owned incidences in the range
     uint32_t ring_head = 0, ring_tail = 0;          // wave-uniform, free-running
 
     // the next range, in flight in registers while the current one is paired
@@ -1270,58 +1267,59 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
     }
 
     // GROUP (row entry, column entry) incidences per lane: `rec` / `m1` the row entry's bits and window mask,
-    // w2[u] = {column entry bits, its window mask}, in[u] = the lanes that have a u-th column entry.
-    // Phase 1 decides who pairs, who owns, and the table index; phase 2 reads the table (all GROUP reads in
-    // flight together); phase 3 adds.
-    auto pair_group = [&](uint32_t rec, uint32_t m1, const uint2 (&w2)[GROUP], unsigned long long (&in)[GROUP]) {
+    // w2[u] = {column entry bits, its window mask}, a lane takes part in slot u iff c > u. Every condition is a
+    // bit test on plain words, combined without short circuits (as `a && b` the compiler had wrapped them in
+    // exec-masked regions, four exec switches per slot), and the counters are per lane (an add with the
+    // condition as carry instead of a scalar population count per slot). Phase 1 decides who pairs, who owns, and
+    // the table index; phase 2 reads the table (all GROUP reads in flight together); phase 3 adds.
+    const uint32_t off_diagonal = DIAG ? 0u : 1u;
+    auto pair_group = [&](uint32_t rec, uint32_t m1, const uint2 (&w2)[GROUP], uint32_t c) {
         const uint32_t row = (rec & C_CELL) * (uint32_t)B;
         uint32_t idx[GROUP], cell[GROUP];
-        unsigned long long add[GROUP];
+        bool add[GROUP];
 #pragma unroll
         for (int u = 0; u < GROUP; ++u) {
             const uint32_t w = w2[u].x, m2 = w2[u].y;
             const uint32_t x = rec ^ w, both = rec & w;
-            // reads both never flushed do not pair (:407-408); in a diagonal tile equal cells do not pair (:215);
-            // a pair with a read that reaches beyond its windows is left to wide_pairs
-            const bool ok = (both & C_TAIL) == 0u && (!DIAG || (x & C_CELL) != 0u) && ((rec | w) & C_WIDE) == 0u;
-            const unsigned long long act = in[u] & __ballot(ok);
-            upd_w += (uint32_t)__popcll(act);
-            const bool differ = (x & (3u << C_BASE_SHIFT)) != 0u;
+            // reads both never flushed do not pair (:407-408); a pair with a read that reaches beyond its windows
+            // is left to wide_pairs; in a diagonal tile equal cells do not pair (:215)
+            const uint32_t bad = (both & C_TAIL) | ((rec | w) & C_WIDE);
+            const uint32_t cells_differ = (x & C_CELL) | off_diagonal;
+            const bool act = (c > (uint32_t)u) & (bad == 0u) & (cells_differ != 0u);
+            upd_lane += act ? 1u : 0u;
+            const uint32_t differ = (x >> C_BASE_SHIFT) & 3u ? 1u : 0u;
             // two multi-locus reads: the pair belongs to their first shared locus; x_s / x_d over the shared loci
             // of the two windows behind this one, plus this locus. Anything else shares this locus only.
-            const bool joint = (both & C_MULTI) != 0u;
-            const uint32_t mm = joint ? (m1 & m2) : 0u;
+            const uint32_t joint = 0u - ((both >> 10) & 1u);  // C_MULTI on both: all ones
+            const uint32_t mm = m1 & m2 & joint;
             const bool owner = (mm & 0xFFu) == 0u;
             const uint32_t shared = (mm >> 8) & 0xFFu;
             const uint32_t y = m1 ^ m2;
             const uint32_t nd = __popc(((y >> 16) | (y >> 24)) & shared);
-            const uint32_t xd = nd + (differ ? 1u : 0u);
-            const uint32_t xs = __popc(shared) - nd + (differ ? 0u : 1u);
-            idx[u] = xs * SLUT_DIM + xd;  // x_s + x_d <= 9: inside the table, whatever a masked lane holds
+            const uint32_t xd = nd + differ;
+            const uint32_t xs = __popc(shared) - nd + 1u - differ;
+            idx[u] = xs * SLUT_DIM + xd;  // x_s + x_d <= 9: inside the table, whatever an idle lane holds
             cell[u] = row + (w & C_CELL);
-            add[u] = act & __ballot(owner);
-            skip_w += (uint32_t)__popcll(act) - (uint32_t)__popcll(add[u]);
+            add[u] = act & owner;
+            skip_lane += (act & !owner) ? 1u : 0u;
         }
         long long v[GROUP];
 #pragma unroll
         for (int u = 0; u < GROUP; ++u) v[u] = sLut[idx[u]];
 #pragma unroll
         for (int u = 0; u < GROUP; ++u)
-            if (__builtin_amdgcn_inverse_ballot_w64(add[u])) atomicAdd(&tile64[cell[u]], (unsigned long long)v[u]);
+            if (add[u]) atomicAdd(&tile64[cell[u]], (unsigned long long)v[u]);
     };
     auto group_load = [&](uint32_t item, uint2 (&w2)[GROUP]) {
         const uint2 *p = sJ + ((item >> MK_J_SHIFT) & MK_J_MASK);
-        // (lanes with fewer than GROUP read on inside the staging area or the offsets behind it: masked by `in`)
+        // (lanes with fewer than GROUP read on inside the staging area or the offsets behind it: idle in those slots)
 #pragma unroll
         for (int u = 0; u < GROUP; ++u) w2[u] = p[u];
     };
     auto group_pair = [&](uint32_t item, uint32_t m1, const uint2 (&w2)[GROUP]) {
         const uint32_t c = item >> MK_C_SHIFT;
-        unsigned long long in[GROUP];
-#pragma unroll
-        for (int u = 0; u < GROUP; ++u) in[u] = __ballot(c > (uint32_t)u);
         const unsigned long long more = __ballot(c > (uint32_t)GROUP);
-        pair_group(item & MK_REC_MASK, m1, w2, in);
+        pair_group(item & MK_REC_MASK, m1, w2, c);
         if (more) {
             if (__builtin_amdgcn_inverse_ballot_w64(more)) {
                 const uint32_t slot = ring_tail + __builtin_amdgcn_mbcnt_hi(
@@ -1357,8 +1355,8 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
         }
         __syncthreads();
         const uint32_t nI = ie - ib;
-        upd_w = 0;
-        skip_w = 0;
+        upd_lane = 0;
+        skip_lane = 0;
         if (staged) {
             uint32_t item[JPT], im[JPT];
             uint32_t any_wide = 0;
@@ -1396,15 +1394,10 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
                         const uint32_t j0w = __builtin_amdgcn_readlane(j0, src);
                         for (uint32_t base = 0; base < cw; base += 64u) {
                             uint2 w2[GROUP];
-                            unsigned long long in[GROUP];
                             w2[0] = sJ[min(j0w + base + lane, (uint32_t)CAPJ - 1u)];
-                            in[0] = __ballot(base + lane < cw);
 #pragma unroll
-                            for (int u = 1; u < GROUP; ++u) {
-                                w2[u] = w2[0];
-                                in[u] = 0ull;
-                            }
-                            pair_group(recw, m1w, w2, in);
+                            for (int u = 1; u < GROUP; ++u) w2[u] = w2[0];
+                            pair_group(recw, m1w, w2, base + lane < cw ? 1u : 0u);  // slot 0 only
                         }
                     }
                     if (c >= IT_WIDE) item[k] = 0u;  // done
@@ -1461,10 +1454,8 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
             n_updates += upd;
             n_pairs += (unsigned long long)upd - skipped;
         }
-        if (lane == 0u) {
-            n_updates += upd_w;
-            n_pairs += (unsigned long long)upd_w - skip_w;
-        }
+        n_updates += upd_lane;
+        n_pairs += (unsigned long long)upd_lane - skip_lane;
     }
     __syncthreads();
 
@@ -2336,7 +2327,14 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
         if (count_tile) return launch_acc<128, 1024, kCapJ128C, kCapL128C, 1024, false, true>(args, grid, stream);
         return launch_acc<128, 1024, kCapJ128, kCapL128, 512, false, false>(args, grid, stream);
     }
-    if (stage_masks && args.masks_kernel) return launch_masks<64, 512, kCapJ64M, kCapL64M, 4>(args, grid, stream);
+    if (stage_masks && args.masks_kernel) {
+        // column entries per item and pass: C2 clustered (9 entries per cell block and locus) 1.160 / 1.143 / 1.111 ms
+        // of accumulate with 4 / 2 / 3
+        static const int g = [] { const char *e = std::getenv("SECEDO_MASKS_GROUP"); return e ? std::atoi(e) : 3; }();
+        if (g == 2) return launch_masks<64, 512, kCapJ64M, kCapL64M, 2>(args, grid, stream);
+        if (g == 4) return launch_masks<64, 512, kCapJ64M, kCapL64M, 4>(args, grid, stream);
+        return launch_masks<64, 512, kCapJ64M, kCapL64M, 3>(args, grid, stream);
+    }
     if (stage_masks) return launch_acc<64, 512, kCapJ64M, kCapL64M, 1024, true, false>(args, grid, stream);
     if (count_tile && pair_mode() != 0) return launch_counts<64, 512, kCapJ64C, kCapL64C, 4>(args, grid, stream, side, mid);
     if (count_tile) return launch_acc<64, 256, kCapJ64C, kCapL64C, 1024, false, true>(args, grid, stream);
