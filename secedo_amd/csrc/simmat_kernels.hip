@@ -885,7 +885,9 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
         // sequence. lgkmcnt: the compiler does not see this ds_add; LDS returns in order, so its counted waits
         // for earlier reads can only become stricter.)
         auto pair_slot_asm = [&](uint32_t rbase, uint32_t row_addr, uint32_t w, unsigned long long in) {
-            upd_w += (uint32_t)__popcll(in);  // (counted per lane instead -- v_min + v_add per group -- C5 took 7 % longer)
+            // (the updates counted elsewhere -- per lane in the group, v_min + v_add, or as the items' column entries
+            // when the items are built -- instead of this scalar population count per slot: C5 7-8 % slower both times)
+            upd_w += (uint32_t)__popcll(in);
             uint32_t addr, val;
             unsigned long long saved;
             asm volatile("s_and_saveexec_b64 %[saved], %[in]\n\t"
