@@ -112,6 +112,9 @@ struct secedo_simmat {
     bool have_model = false, have_lut = false, have_slow = false;
     double lut_eps = 0, lut_h = 0, lut_theta = 0;
     int scale_log2 = 44;
+    int scale_wanted = 44;               // llr_scale_for(table, scale_for_bound, scale_for_reach)
+    uint64_t scale_for_bound = ~0ull;
+    uint32_t scale_for_reach = ~0u;
     // secedo_simmat_set_pair_bound / set_scale_bounds: the bounds of everything that is summed into one
     // accumulator (shards on several ranks); they belong to the pileup that was set when they were given
     uint64_t pair_bound_override = 0;
@@ -639,6 +642,31 @@ int secedo_simmat_zero_acc(secedo_simmat_t *h, int64_t *d_acc, void *stream) {
 }
 
 
+// The compact lists of the flagged entries (build_flagged_lists), issued on `stream`: the launch stream itself, or
+// the handle's side stream -- then behind the fork event and followed by the join event.
+struct FlagBuild {
+    secedo_simmat *h = nullptr;
+    const uint32_t *entry32 = nullptr, *blk_off = nullptr;
+    const uint4 *entry = nullptr;
+    uint32_t ne = 0;
+    size_t n_off = 0;
+    hipStream_t stream = nullptr;
+    bool done = false;
+    static hipError_t run(void *ctx) {
+        FlagBuild *b = static_cast<FlagBuild *>(ctx);
+        secedo_simmat *h = b->h;
+        const bool on_side = h->side.stream && b->stream == h->side.stream;
+        hipError_t e = hipSuccess;
+        if (on_side && (e = hipStreamWaitEvent(b->stream, h->side.fork, 0)) != hipSuccess) return e;
+        e = secedo::build_flagged_lists(b->entry32, b->entry, b->ne, b->blk_off, b->n_off, h->flag_tmp.p, h->flag_tmp.bytes,
+                                        h->flag_pre.as<uint32_t>(), h->flag_grp.as<uint32_t>(), h->flag_rec.as<uint4>(),
+                                        h->flag_idx.as<uint32_t>(), b->stream);
+        if (e == hipSuccess && on_side) e = hipEventRecord(h->side.join, b->stream);
+        b->done = true;
+        return e;
+    }
+};
+
 // tiles [tile_begin, tile_end) when list == nullptr, else the n_list tiles of `list` (global indices)
 // overwrite: acc[tiles of the launch] = result instead of +=
 static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double theta, uint32_t tile_begin,
@@ -686,7 +714,13 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         // the fixed-point scale follows the pair bound of everything that is summed into one accumulator:
         // this pileup's own bound, or the one the caller set for all the shards that will be added up
         const uint64_t bound = std::max(h->pair_bound_override, h->pk.pair_bound);
-        const int want_scale = secedo::llr_scale_for(h->table, bound, reach);
+        // (the bound is a pass over the 65 x 65 table: kept per table, pair bound and reach)
+        if (!h->have_lut || bound != h->scale_for_bound || reach != h->scale_for_reach) {
+            h->scale_wanted = secedo::llr_scale_for(h->table, bound, reach);
+            h->scale_for_bound = bound;
+            h->scale_for_reach = reach;
+        }
+        const int want_scale = h->scale_wanted;
         if (!h->have_lut || want_scale != h->scale_log2) {
             secedo::requantize(&h->table, want_scale);
             HIP_TRY(h->lut.ensure(h->table.fixed.size() * sizeof(int64_t)));
@@ -859,6 +893,8 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
 
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, 96 * sizeof(unsigned long long), s));
     const secedo::SideStream *side = nullptr;
+    secedo::SideStream side_call;
+    FlagBuild build;
     if (h->pk.count_tile && !h->pk.stage_masks && secedo::counts_path_enabled()) {
         // accumulate_counts + correct_tiles. The compact list of flagged entries, once per prepare, is read by
         // the second kernel only: it is built on a stream of the handle's own while the pair kernel runs
@@ -881,21 +917,26 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
             HIP_TRY(h->flag_pre.ensure(((size_t)ne + 1) * 4));
             HIP_TRY(h->flag_rec.ensure(std::max<size_t>(ne, 1) * 16));
             HIP_TRY(h->flag_idx.ensure(std::max<size_t>(ne, 1) * 4));
-            hipStream_t list_stream = s;
-            if (side) {
-                HIP_TRY(hipEventRecord(side->fork, s));
-                HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
-                list_stream = side->stream;
-            }
             const size_t n_off = (size_t)h->pk.num_blocks * a.stride;
             HIP_TRY(h->flag_grp.ensure(std::max<size_t>(n_off, 1) * 4));
-            HIP_TRY(secedo::build_flagged_lists(a.entry32, a.entry, ne, a.blk_off, n_off, h->flag_tmp.p,
-                                                h->flag_tmp.bytes, h->flag_pre.as<uint32_t>(),
-                                                h->flag_grp.as<uint32_t>(), h->flag_rec.as<uint4>(),
-                                                h->flag_idx.as<uint32_t>(), list_stream));
+            build.h = h;
+            build.entry32 = a.entry32;
+            build.entry = a.entry;
+            build.blk_off = a.blk_off;
+            build.ne = ne;
+            build.n_off = n_off;
             if (side) {
-                HIP_TRY(hipEventRecord(side->join, side->stream));
-                if (n_tiles == 0) HIP_TRY(hipStreamWaitEvent(s, side->join, 0));  // nothing below waits for it
+                // the lists depend on the packed pileup (complete on `s` by now) and are read by correct_tiles
+                // only: the host enqueues their kernels behind the pair kernel's launch, on the side stream
+                HIP_TRY(hipEventRecord(side->fork, s));
+                build.stream = side->stream;
+                side_call = *side;
+                side_call.deferred = &FlagBuild::run;
+                side_call.deferred_ctx = &build;
+                side = &side_call;
+            } else {
+                build.stream = s;
+                if (FlagBuild::run(&build) != hipSuccess) return fail(SECEDO_E_HIP, "building the flagged entries' lists failed");
             }
             h->flags_ready = true;
         }
@@ -916,6 +957,10 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
     h->timed_mid = count_tile && !h->pk.stage_masks && secedo::counts_path_enabled();
     HIP_TRY(secedo::launch_accumulate(a, h->pk.block_cells, h->pk.stage_masks, count_tile, n_tiles, s, side,
                                       h->timed_mid ? h->ev_mid : nullptr));
+    if (build.h && build.stream != s && !build.done) {  // no tile in the launch: nobody issued the lists yet
+        if (FlagBuild::run(&build) != hipSuccess) return fail(SECEDO_E_HIP, "building the flagged entries' lists failed");
+        HIP_TRY(hipStreamWaitEvent(s, h->side.join, 0));
+    }
     h->timed_mid = h->timed_mid && n_tiles > 0;
     HIP_TRY(hipEventRecord(h->ev_end, s));
     h->timed = true;

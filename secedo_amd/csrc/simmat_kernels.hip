@@ -2153,6 +2153,7 @@ hipError_t launch_counts_v(const AccumulateArgs &args, uint32_t grid, hipStream_
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
     if (mid && (e = hipEventRecord(mid, stream)) != hipSuccess) return e;
+    if (side && side->deferred && (e = side->deferred(side->deferred_ctx)) != hipSuccess) return e;
     return launch_correct<B>(args, stream, side);
 }
 

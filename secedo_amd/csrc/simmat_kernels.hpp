@@ -114,6 +114,10 @@ size_t accumulate_slab_bytes(uint32_t block_cells, bool count_tile, uint32_t n_w
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    // work for the side stream that the launch issues right AFTER the pair kernel (so that the host's enqueueing of
+    // it does not delay that kernel) and whose `join` the second kernel waits for; null: nothing pending
+    hipError_t (*deferred)(void *ctx) = nullptr;
+    void *deferred_ctx = nullptr;
 };
 // mid: when non-null, recorded on `stream` between the pair kernel and what follows it (the duration of the
 // dominant kernel by itself: secedo_simmat_last_pair_kernel_ms)
