@@ -52,6 +52,8 @@ def lds_atomic_peak():
     runs, else the committed measurement. -> (peak, source, whole record)"""
     exe = os.path.join(ROOT, "tools", "lds_atomic_bench.bin")
     try:
+        if os.environ.get("SECEDO_BENCH_NO_CHILD"):  # under a profiler: no second process in the trace
+            raise OSError("child processes disabled")
         r = subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=120)
         rec = json.loads(r.stdout.strip().splitlines()[-1])
         return rec["peak_random_gatomic_per_s"], "tools/lds_atomic_bench.bin --json, this run", rec
@@ -497,8 +499,7 @@ def main():
         b_alg_step = 16 * updates + 6 * best["kept_entries"] + 4 * n_loci + 16 * N * N  # the whole job
         step_s = elapsed / args.steps
         dom_ms = pair_ms if pair_ms else kern_ms
-        dom_name = ("accumulate_counts" if pair_ms else
-                    "accumulate_tiles (+ reduce_slabs: the kernels of one accumulate)")
+        dom_name = plan.pair_kernel if pair_ms else plan.pair_kernel + " (+ its reduction kernels: the accumulate phase)"
         peak, peak_src, peak_rec = lds_atomic_peak()
         # one LDS atomic per update in both pair kernels (ds_add_u32 into the count tile / ds_add_u64 into the int64 tile)
         achieved = local_updates / (dom_ms * 1e-3) / 1e9

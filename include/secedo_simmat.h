@@ -226,6 +226,10 @@ int secedo_simmat_last_accumulate_ms(secedo_simmat_t *handle, float *ms);
 /* ... and of its dominant kernel by itself when the sparse-loci kernels ran (accumulate_counts, from the start
  * of the accumulate to the launch that follows it); SECEDO_E_STATE otherwise. */
 int secedo_simmat_last_pair_kernel_ms(secedo_simmat_t *handle, float *ms);
+/* Which pair kernel the prepared pileup runs: "accumulate_counts" (sparse loci: count tile, followed by
+ * correct_tiles), "accumulate_masks" (clustered loci: window masks staged, followed by wide_pairs when reads reach
+ * beyond their windows) or "accumulate_tiles" (deep pileups, and the A/B switches). Static string. */
+const char *secedo_simmat_pair_kernel(const secedo_simmat_t *handle);
 
 /* log-likelihood ratio D(x_s, x_d) = log P(x_s,x_d | different) - log P(x_s,x_d | same) as the
  * device tables hold it (host-only, no device): for x_s + x_d <= 64 what the reference's nested sums

@@ -96,6 +96,7 @@ SIGNATURES = {
     "secedo_simmat_last_counts": (C.c_int, [_vp, _u64p, _u64p]),
     "secedo_simmat_last_accumulate_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "secedo_simmat_last_pair_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "secedo_simmat_pair_kernel": (C.c_char_p, [_vp]),
     "secedo_simmat_llr": (C.c_double, [C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double]),
     "secedo_simmat_llr_closed_form": (C.c_double, [C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double]),
     "secedo_simmat_pair_bound": (C.c_uint64, [_vp]),

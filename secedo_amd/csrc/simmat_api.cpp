@@ -1169,6 +1169,16 @@ int secedo_simmat_last_accumulate_ms(secedo_simmat_t *h, float *ms) {
     return SECEDO_OK;
 }
 
+const char *secedo_simmat_pair_kernel(const secedo_simmat_t *h) {
+    if (!h || !h->prepared) return "";
+    if (h->pk.count_tile && !h->pk.stage_masks && secedo::counts_path_enabled()) return "accumulate_counts";
+    if (h->pk.stage_masks && h->pk.block_cells == 64) {
+        const char *e = std::getenv("SECEDO_MASKS_KERNEL");
+        if (!(e && std::atoi(e) == 0)) return "accumulate_masks";
+    }
+    return "accumulate_tiles";
+}
+
 int secedo_simmat_last_pair_kernel_ms(secedo_simmat_t *h, float *ms) {
     if (!h || !ms) return fail(SECEDO_E_INVALID_ARG, "null argument");
     if (!h->timed || !h->timed_mid) return fail(SECEDO_E_STATE, "the last accumulate did not run the sparse-loci kernels");

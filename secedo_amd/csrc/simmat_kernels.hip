@@ -733,7 +733,7 @@ constexpr uint32_t IT_REC_MASK = 0x1FFu;  // cell (7 bits) | base (2 bits)
 template <int B, int THREADS, int CAPJ, int CAPL, int GROUP, bool SLOT_ASM>
 __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArgs a) {
     static_assert(CAPJ <= 8192, "13 bits of column index in an item");
-    static_assert(GROUP >= 1 && GROUP <= 4, "group size");
+    static_assert(GROUP >= 1 && GROUP <= 8, "group size");
     // Rows of the LDS tile are B + 1 words apart: the lanes of a wave that share a locus add to the SAME column
     // (their common column entry) in DIFFERENT rows, and with a row stride of B words all of them would hit one
     // bank (bank = column mod 32): 3-4 lanes deep at every locus, on top of the random collisions.
@@ -2319,6 +2319,9 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
         if (count_tile && pair_mode() != 0) {
             static const int g = [] { const char *e = std::getenv("SECEDO_GROUP"); return e ? std::atoi(e) : 0; }();
             if (g == 1) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 1>(args, grid, stream, side, mid);
+            if (g == 5) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 5>(args, grid, stream, side, mid);
+            if (g == 6) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 6>(args, grid, stream, side, mid);
+            if (g == 8) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 8>(args, grid, stream, side, mid);
             if (g == 3) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 3>(args, grid, stream, side, mid);
             if (g == 4) return launch_counts<128, 1024, kCapJ128C, kCapL128C, 4>(args, grid, stream, side, mid);
             if (g == 2 || (g == 0 && args.group_hint == 2))

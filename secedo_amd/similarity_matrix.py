@@ -367,6 +367,11 @@ class SimilarityMatrixPlan:
             return None
         return float(ms.value)
 
+    @property
+    def pair_kernel(self) -> str:
+        """The pair kernel the prepared pileup runs (secedo_simmat_pair_kernel)."""
+        return _lib.lib().secedo_simmat_pair_kernel(self._h).decode()
+
     def last_accumulate_ms(self) -> float:
         ms = C.c_float()
         _lib.check(_lib.lib().secedo_simmat_last_accumulate_ms(self._h, C.byref(ms)))

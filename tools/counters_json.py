@@ -40,12 +40,12 @@ for key, pmc, stats in (("C3", "pmc_C3.txt", "C3_kernel_stats.csv"),
     if not os.path.exists(os.path.join(R, pmc)):
         continue
     t = table(os.path.join(R, pmc))
-    kern = next((k for k in t if "accumulate_counts" in k), None) or next((k for k in t if "accumulate_tiles" in k), None)
+    kern = next((k for k in t if "::accumulate_" in k), None)
     if not kern:
         continue
     c = dict(t[kern])
     c["kernel"] = kern
-    ns = avg_ns(os.path.join(R, stats), "accumulate_counts" if "accumulate_counts" in kern else "accumulate_tiles")
+    ns = avg_ns(os.path.join(R, stats), kern.split("::")[-1].split("<")[0] + "<")
     if ns:
         c["kernel_avg_ns"] = ns
         c["kernel_cycles"] = ns * CLOCK_GHZ

@@ -9,10 +9,11 @@
 #   6. C2 and C5 bench lines
 set -e
 export TMPDIR=/tmp
+export SECEDO_BENCH_NO_CHILD=1   # (set again to empty for the plain bench runs below: they measure the LDS peak live)
 R=$GRAFT_REPO_ROOT/gpurun_out/r03
 rm -rf $R; mkdir -p $R
 tools/lds_atomic_bench.bin --json > $R/lds_atomic_peak.json
-python bench.py > $R/C3_bench.json 2> $R/C3_bench.err
+SECEDO_BENCH_NO_CHILD= python bench.py > $R/C3_bench.json 2> $R/C3_bench.err
 echo "C3 bench done"; head -c 400 $R/C3_bench.json; echo
 stats() {  # name, bench args...
   local name=$1; shift
@@ -36,8 +37,8 @@ tools/pmc.sh r03_c "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_TH
 cat $R/pmc_C3_a.txt $R/pmc_C3_b.txt $R/pmc_C3_c.txt > $R/pmc_C3.txt
 echo "pmc done"
 # clustered loci
-python bench.py --clustered --no-cpu-baseline > $R/C3_clustered_bench.json 2> $R/C3_clustered_bench.err
-python bench.py --workload C2 --clustered --no-cpu-baseline > $R/C2_clustered_bench.json 2> $R/C2_clustered_bench.err
+SECEDO_BENCH_NO_CHILD= python bench.py --clustered --no-cpu-baseline > $R/C3_clustered_bench.json 2> $R/C3_clustered_bench.err
+SECEDO_BENCH_NO_CHILD= python bench.py --workload C2 --clustered --no-cpu-baseline > $R/C2_clustered_bench.json 2> $R/C2_clustered_bench.err
 stats C3_clustered --clustered --steps 5
 stats C2_clustered --workload C2 --clustered
 tools/pmc.sh r03_ca "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" --clustered $P > $R/pmc_C3_clustered_a.txt
@@ -45,7 +46,7 @@ tools/pmc.sh r03_cb "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTI
 cat $R/pmc_C3_clustered_a.txt $R/pmc_C3_clustered_b.txt > $R/pmc_C3_clustered.txt
 python tools/counters_json.py $R > $R/counters.json
 cat $R/counters.json
-python bench.py --workload C2 --no-cpu-baseline > $R/C2_bench.json 2> $R/C2_bench.err
-python bench.py --workload C5 --no-cpu-baseline --steps 5 > $R/C5_bench.json 2> $R/C5_bench.err
+SECEDO_BENCH_NO_CHILD= python bench.py --workload C2 --no-cpu-baseline > $R/C2_bench.json 2> $R/C2_bench.err
+SECEDO_BENCH_NO_CHILD= python bench.py --workload C5 --no-cpu-baseline --steps 5 > $R/C5_bench.json 2> $R/C5_bench.err
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_r03_* $R/pmc_FETCH_SIZE $R/pmc_WRITE_SIZE $R/calib_FETCH_SIZE $R/calib_WRITE_SIZE 2>/dev/null || true
 echo "all done"
