@@ -279,7 +279,11 @@ def main():
         for _ in range(args.warmup):
             step()
         sync()
-        local_updates, local_pairs = plan.last_counts()  # exact integer work counters of one pass
+        # exact integer work counters of one pass over this rank's tiles (one untimed launch of the whole range: the
+        # chunked exchange leaves the counters of its last chunk only)
+        plan.accumulate(acc, *rates, *my_tiles, overwrite=True)
+        local_updates, local_pairs = plan.last_counts()
+        sync()
         # EXACTLY K steps between barrier + synchronize on both sides, `--repeats` times over; the reported block
         # is the median one (max over ranks of each block first), the others give the spread
         blocks = []
