@@ -245,9 +245,10 @@ def wrap_cases():
     (similarity_matrix.cpp:125, :159; single binomials up to row 64 still fit), and what it returns is
     the wrapped sum -- D(60,4) = 0.464 where its own formula gives 0.578. The product reproduces exactly
     that (llr_table.cpp: reference_llr), so these vectors come straight from the compiled reference.
-    `wrap_beyond64` goes further (reads of 70-100 loci): from 65 shared loci on the product returns the
-    closed form instead; the fixture records what the reference does there so that the test can state
-    the difference."""
+    `wrap_beyond64` goes further (reads of 70-100 loci): the product follows the reference there too (up to 128
+    shared loci since round 3). `wrap_beyond128` (reads of 140-170 loci): from 129 shared loci on the product
+    returns the closed form instead; the fixture records what the reference does there so that the test can
+    state the difference."""
     # (a) known answers D(x_s, x_d) up to x_s + x_d = 64, as in kat_llr_table
     params = [(0.01, 0.5, 0.01), (0.01, 0.15, 0.001)]
     combos = [(48, 0), (50, 3), (60, 4), (32, 32), (64, 0), (0, 64), (40, 24), (24, 40), (63, 1), (47, 1),
@@ -268,6 +269,9 @@ def wrap_cases():
          + [case(10, 1000, 2, "ADD_MIN", h=0.15, theta=0.001)])
     p = random_pileup(105, 8, 1, 500, 4, 7, frag_min=300, frag_max=400, dup_frac=0.0)
     save("wrap_beyond64", p, [case(8, 1000, 1, "ADD_MIN")])
+    # reads of 140-170 loci: beyond the 128 shared loci up to which the product restates the reference's sums
+    p = random_pileup(106, 8, 1, 700, 4, 7, frag_min=560, frag_max=680, dup_frac=0.0)
+    save("wrap_beyond128", p, [case(8, 1000, 1, "ADD_MIN")])
 
 
 def c2_reference_run():

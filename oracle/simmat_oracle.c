@@ -38,9 +38,9 @@ typedef struct {
  * reproduces the reference bit for bit. */
 static _Thread_local int g_exact_mode = 0;
 void oracle_set_exact_binomials(int on) { g_exact_mode = on; }
-/* Mode 2: exact binomials only for x_s + x_d > 64 -- what the MI355X path documents for read pairs that
+/* Mode 2: exact binomials only for x_s + x_d > 128 -- what the MI355X path documents for read pairs that
  * share more loci than its table of reference-identical terms covers. */
-#define g_exact_binomials (g_exact_mode == 1 || (g_exact_mode == 2 && x_s + x_d > 64))
+#define g_exact_binomials (g_exact_mode == 1 || (g_exact_mode == 2 && x_s + x_d > 128))
 
 static double *pow_table(double base, uint32_t size) {
     /* similarity_matrix.cpp:53-65 start each table as {1, x}; :85-94 extend by

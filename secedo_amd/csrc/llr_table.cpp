@@ -69,7 +69,8 @@ namespace {
 constexpr uint32_t kRows = kLlrRefMax + 1;
 
 // Powers as the reference builds them (each entry = previous * base, similarity_matrix.cpp:85-94) and
-// Pascal's triangle in uint64_t (:95-101). Up to row 64 no single binomial wraps; the PRODUCTS do.
+// Pascal's triangle in uint64_t (:95-101). Up to row 67 no single binomial wraps, the PRODUCTS do from about
+// row 48 on; beyond row 67 the additions of the triangle wrap too (unsigned arithmetic modulo 2^64 here as there).
 struct RefTables {
     double pss[kRows], psd[kRows], pds[kRows], pdd[kRows];
     double a1[kRows], a2[kRows], b2[kRows], hh[kRows], ehalf[kRows];  // (1-e-h)^k (1-e/2-h)^k (h+e/2)^k h^k (e^k * .5^k)
@@ -193,7 +194,8 @@ bool extend_reference(LlrTable *t, uint32_t max_shared, unsigned max_threads) {
             for (uint32_t s = 0; s <= n; ++s) t->value[s * kLlrTableDim + (n - s)] = cached.value[s * kLlrTableDim + (n - s)];
     };
     // the entries (cached.upto, want], heaviest first, shared among a few threads (O(x_s^2 x_d^2) each:
-    // about 1e8 terms for the whole triangle up to 64)
+    // about 1e8 terms for the whole triangle up to 64, 6e9 up to 128: two seconds on eight threads, once per process
+    // and rate triple, and only for a pileup with a read of that many kept entries)
     std::vector<std::pair<uint32_t, uint32_t>> todo;
     for (uint32_t n = want; n > cached.upto; --n)
         for (uint32_t s = 0; s <= n; ++s) todo.push_back({s, n - s});

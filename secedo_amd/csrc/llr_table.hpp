@@ -15,9 +15,10 @@
 // multiplies its binomials as uint64_t before the product becomes a double (:125, :159), and those
 // products wrap from about x_s + x_d = 48 on: what it returns there is the wrapped sum, not the formula
 // (D(60,4) differs by 0.11). A drop-in must return what the reference returns, so the table entries a
-// pileup can reach (x_s + x_d <= longest read, up to 64) are evaluated by reference_llr(), which
-// restates the reference's nested sums with the same wrapping integer arithmetic; the closed form
-// serves beyond the table (read pairs sharing more than 64 loci) and under SECEDO_LLR_EXACT=1.
+// pileup can reach (x_s + x_d <= longest read, up to 128; 64 until round 3) are evaluated by reference_llr(),
+// which restates the reference's nested sums with the same wrapping integer arithmetic (from row 68 on the
+// single binomials of its uint64 Pascal triangle wrap as well: the same modular additions here); the closed
+// form serves beyond the table (read pairs sharing more than 128 loci) and under SECEDO_LLR_EXACT=1.
 #pragma once
 
 #include <cstdint>
@@ -37,8 +38,8 @@ LlrModel make_llr_model(double mutation_rate, double homozygous_rate, double seq
 // D(x_s, x_d), evaluated in log space (stable for any x_s, x_d).
 double llr(const LlrModel &m, uint32_t x_s, uint32_t x_d);
 
-constexpr uint32_t kLlrTableDim = 65;  // x_s, x_d in [0, 64]: one 32-locus window either side + 1
-constexpr uint32_t kLlrRefMax = 64;    // entries with x_s + x_d <= this can be made reference-identical
+constexpr uint32_t kLlrTableDim = 129;  // x_s, x_d in [0, 128]
+constexpr uint32_t kLlrRefMax = 128;    // entries with x_s + x_d <= this can be made reference-identical
 
 // D(x_s, x_d) as the reference computes it: log of the four-fold sum of :117-141 minus log of the
 // two-fold sum of :153-170, binomials multiplied in uint64_t (wrap-around kept). x_s + x_d <= kLlrRefMax.

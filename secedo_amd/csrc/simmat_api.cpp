@@ -714,7 +714,7 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         // the fixed-point scale follows the pair bound of everything that is summed into one accumulator:
         // this pileup's own bound, or the one the caller set for all the shards that will be added up
         const uint64_t bound = std::max(h->pair_bound_override, h->pk.pair_bound);
-        // (the bound is a pass over the 65 x 65 table: kept per table, pair bound and reach)
+        // (the bound is a pass over the whole table: kept per table, pair bound and reach)
         if (!h->have_lut || bound != h->scale_for_bound || reach != h->scale_for_reach) {
             h->scale_wanted = secedo::llr_scale_for(h->table, bound, reach);
             h->scale_for_bound = bound;

@@ -31,7 +31,7 @@ constexpr uint32_t C_BASE_SHIFT = 7;
 constexpr uint32_t C_TAIL = 1u << 9;
 constexpr uint32_t C_MULTI = 1u << 10;
 constexpr uint32_t C_WIDE = 1u << 11;
-constexpr int LUT_DIM = 65;
+constexpr int LUT_DIM = 129;  // llr_table.hpp: kLlrTableDim
 constexpr int SLUT_DIM = 10;  // LDS copy of the table for the 8-locus windows: x_s + x_d <= 9
 constexpr long long NO_PAIR = (long long)0x8000000000000000ull;  // "another locus owns this pair"
 

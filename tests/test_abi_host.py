@@ -99,23 +99,25 @@ def test_llr_closed_form_equals_reference_sums(eps, h, theta):
 def test_llr_closed_form_matches_exact_binomials_anywhere():
     ob.set_exact_binomials(True)
     try:
-        for xs, xd in [(50, 3), (60, 4), (64, 64), (70, 10), (3, 64)]:
+        for xs, xd in [(50, 3), (60, 4), (64, 64), (70, 10), (3, 64), (100, 40), (129, 0), (90, 90)]:
             ref = ob.oracle_log_prob_diff(xs, xd, 0.01, 0.5, 0.01) - ob.oracle_log_prob_same(xs, xd, 0.01, 0.5, 0.01)
             assert abs(secedo_amd.llr_closed_form(xs, xd, 0.01, 0.5, 0.01) - ref) < 1e-12 * max(1.0, abs(ref))
-            if xs + xd > 64:  # beyond the table of reference-identical terms the device uses the closed form
+            if xs + xd > 128:  # beyond the table of reference-identical terms the device uses the closed form
                 assert secedo_amd.llr(xs, xd, 0.01, 0.5, 0.01) == secedo_amd.llr_closed_form(xs, xd, 0.01, 0.5, 0.01)
     finally:
         ob.set_exact_binomials(False)
 
 
 @pytest.mark.parametrize("eps,h,theta", LLR_PARAMS[:3])
-def test_llr_table_is_reference_identical_up_to_64_shared_loci(eps, h, theta):
-    """The terms the device tables hold (x_s + x_d <= 64) are the reference's, wrap-around of its uint64
-    binomial products included (similarity_matrix.cpp:95-101, :125, :159): D(60,4) is 0.464 in the
-    reference and 0.578 by its formula. Checked against the restated sums of the oracle (default mode =
-    the reference bit for bit) on a grid that covers the wrapping region."""
+def test_llr_table_is_reference_identical_up_to_128_shared_loci(eps, h, theta):
+    """The terms the device tables hold (x_s + x_d <= 128; 64 until round 3) are the reference's, wrap-around
+    of its uint64 binomial products -- and, from row 68 on, of its uint64 Pascal triangle itself -- included
+    (similarity_matrix.cpp:95-101, :125, :159): D(60,4) is 0.464 in the reference and 0.578 by its formula,
+    D(100,0) is -1.3e-6 where the formula gives -0.50. Checked against the restated sums of the oracle (default
+    mode = the reference bit for bit) on a grid that covers the wrapping region."""
     grid = [(xs, xd) for xs in range(0, 65, 4) for xd in range(0, 65 - xs, 5) if xs + xd] \
-        + [(50, 3), (60, 4), (64, 0), (0, 64), (32, 32), (47, 1), (1, 63)]
+        + [(50, 3), (60, 4), (64, 0), (0, 64), (32, 32), (47, 1), (1, 63)] \
+        + [(65, 0), (70, 10), (100, 0), (0, 100), (64, 64), (90, 38), (128, 0), (1, 127), (37, 80)]
     wrapped = 0
     for xs, xd in grid:
         ref = ob.oracle_log_prob_diff(xs, xd, eps, h, theta) - ob.oracle_log_prob_same(xs, xd, eps, h, theta)

@@ -35,14 +35,15 @@ def test_hip_matches_reference_vectors(name):
         assert np.all(np.diag(got) == 0)
 
 
-def test_read_pairs_sharing_more_than_64_loci_documented_difference():
-    """Up to 64 shared loci the HIP path returns the reference's own terms (its wrapped uint64 binomial
-    products included: wrap_dense_10cells above is a vector of the compiled reference). Beyond 64 it
-    returns the reference's FORMULA in exact arithmetic, where the reference returns the wrapped sums
-    (DESIGN.md section 4). wrap_beyond64 holds the compiled reference's output for reads of 70-100 loci:
-    the HIP matrix equals the oracle in its "exact beyond 64" mode to 1e-9 and differs from the
-    reference's by what the wrap is worth there."""
-    p, cases = gu.load("wrap_beyond64")
+def test_read_pairs_sharing_more_than_128_loci_documented_difference():
+    """Up to 128 shared loci (64 until round 3) the HIP path returns the reference's own terms, its wrapped uint64
+    arithmetic included: wrap_dense_10cells (48-64 shared loci) and wrap_beyond64 (reads of 70-100 loci) are
+    vectors of the compiled reference and are held to 1e-9 by test_hip_matches_reference_vectors. Beyond 128 it
+    returns the reference's FORMULA in exact arithmetic, where the reference returns the wrapped sums (DESIGN.md
+    section 4). wrap_beyond128 holds the compiled reference's output for reads of 140-170 loci: the HIP matrix
+    equals the oracle in its "exact beyond 128" mode to 1e-9 and differs from the reference's by what the wrap
+    is worth there."""
+    p, cases = gu.load("wrap_beyond128")
     c = cases[0]
     got = hip(p, c)
     ob.set_exact_binomials(2)
@@ -87,7 +88,7 @@ RANDOM = [
     # where the reference's u64 binomial products wrap (x_s + x_d from ~48 on) the HIP path returns the
     # reference's wrapped terms up to 64 shared loci and the exact formula beyond (oracle mode 2)
     (25, 16, 1, 300, 6, 9, 1000, 1, 500, 2),           # > 32 loci per read: window overflow path
-    (26, 70, 2, 700, 4, 5, 1000, 2, 700, 2),           # > 64 shared loci: beyond the LLR table
+    (26, 70, 2, 700, 4, 5, 1000, 2, 700, 2),           # > 128 shared loci: beyond the LLR table
 ]
 
 
