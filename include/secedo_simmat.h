@@ -232,7 +232,7 @@ int secedo_simmat_last_pair_kernel_ms(secedo_simmat_t *handle, float *ms);
 const char *secedo_simmat_pair_kernel(const secedo_simmat_t *handle);
 
 /* log-likelihood ratio D(x_s, x_d) = log P(x_s,x_d | different) - log P(x_s,x_d | same) as the
- * device tables hold it (host-only, no device): for x_s + x_d <= 64 what the reference's nested sums
+ * device tables hold it (host-only, no device): for x_s + x_d <= 128 what the reference's nested sums
  * return (similarity_matrix.cpp:117-170), including the wrap-around of its uint64_t binomial products
  * from x_s + x_d ~ 48 on; beyond 128 -- and everywhere under SECEDO_LLR_EXACT=1 -- the closed form of
  * the same sums, i.e. the reference's formula in exact arithmetic (secedo_simmat_llr_closed_form). */
