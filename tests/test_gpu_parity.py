@@ -687,3 +687,69 @@ def test_plain_copy_readbacks_give_the_same_matrix(tmp_path):
     p = random_pileup(91, 150, 2, 400, 25, 300, dup_frac=0.03)
     ref = ob.oracle_compute(p, 150, 200, None, 0.01, 0.5, 0.01, 2, "ADD_MIN")
     assert gu.normwise_err(outs[0], ref) <= TOL
+
+
+def test_kernel_variants_give_the_same_accumulator(tmp_path):
+    """The A/B switches select other kernels for the same integer sums (each read once per process: child
+    processes): clustered loci with reads that reach beyond their 8- and 16-locus windows -- accumulate_masks +
+    wide_pairs (default) against accumulate_tiles (SECEDO_MASKS_KERNEL=0) --, sparse loci -- the hand-placed pair
+    slot of accumulate_counts (default) against the compiler's (SECEDO_SLOT_ASM=0) and against the flattening
+    kernel (SECEDO_PAIR_MODE=0). The un-normalised matrices and both work counters must be bit-identical (the
+    accumulators themselves may differ inside diagonal tiles, which hold a pair in either orientation)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = "\n".join([
+        "import numpy as np, sys, torch",
+        "sys.path.insert(0, %r)" % root,
+        "import secedo_amd",
+        "from tests.pileup_gen import random_pileup",
+        "clustered = random_pileup(311, 200, 2, 900, 30, 12, frag_min=20, frag_max=260, dup_frac=0.03)   # 4 blocks of 64, spans up to 40 loci",
+        "sparse = random_pileup(312, 300, 2, 1500, 40, 30000, frag_min=30, frag_max=500, dup_frac=0.03)",
+        "out = {}",
+        "for name, p, n in (('clustered', clustered, 200), ('sparse', sparse, 300)):",
+        "    with secedo_amd.SimilarityMatrixPlan(0) as plan:",
+        "        plan.prepare(p, n, 1000, None, 2)",
+        "        acc = plan.new_acc()",
+        "        plan.accumulate(acc, 0.01, 0.5, 0.01)",
+        "        torch.cuda.synchronize()",
+        "        out[name] = plan.finalize_raw(acc).cpu().numpy()",
+        "        out[name + '_counts'] = np.asarray(plan.last_counts(), dtype=np.uint64)",
+        "        out[name + '_kernel'] = np.frombuffer(plan.pair_kernel.encode(), dtype=np.uint8)",
+        "np.savez(sys.argv[1], **out)"])
+    runs = {}
+    for tag, env in (("default", {}), ("tiles", {"SECEDO_MASKS_KERNEL": "0"}), ("cslot", {"SECEDO_SLOT_ASM": "0"}),
+                     ("flat", {"SECEDO_PAIR_MODE": "0"})):
+        out = str(tmp_path / (tag + ".npz"))
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=dict(os.environ, **env), timeout=600)
+        runs[tag] = np.load(out)
+    kern = lambda z, name: bytes(z[name + "_kernel"]).decode()
+    assert kern(runs["default"], "clustered") == "accumulate_masks" and kern(runs["tiles"], "clustered") == "accumulate_tiles"
+    assert kern(runs["default"], "sparse") == "accumulate_counts" and kern(runs["flat"], "sparse") == "accumulate_tiles"
+    for tag in ("tiles", "cslot", "flat"):
+        for name in ("clustered", "sparse"):
+            assert np.array_equal(runs[tag][name], runs["default"][name]), (tag, name)
+            assert np.array_equal(runs[tag][name + "_counts"], runs["default"][name + "_counts"]), (tag, name)
+    assert np.any(runs["default"]["clustered"] != 0) and np.any(runs["default"]["sparse"] != 0)
+
+
+def test_staging_buffers_are_handed_to_one_caller_at_a_time():
+    """secedo_simmat_staging_acquire (the page-locked buffers the C++ shim flattens into): a second acquire while
+    the first is held is refused with SECEDO_E_STATE -- the shim then uses buffers of its own --, release makes
+    them available again, and they grow on request."""
+    import ctypes as C
+    from secedo_amd import _lib
+    L = _lib.lib()
+    sizes = (C.c_uint64 * 5)(64, 1 << 20, 1 << 20, 4 << 20, 2 << 20)
+    ptrs = (C.c_void_p * 5)()
+    assert L.secedo_simmat_staging_acquire(sizes, ptrs) == 0
+    first = list(ptrs)
+    assert all(first)
+    again = (C.c_void_p * 5)()
+    assert L.secedo_simmat_staging_acquire(sizes, again) == _lib.E_STATE
+    L.secedo_simmat_staging_release()
+    bigger = (C.c_uint64 * 5)(64, 1 << 20, 1 << 20, 64 << 20, 2 << 20)
+    assert L.secedo_simmat_staging_acquire(bigger, again) == 0
+    C.memset(again[3], 0x5A, 64 << 20)  # the grown buffer is really there
+    L.secedo_simmat_staging_release()
+    L.secedo_simmat_staging_release()  # releasing twice is harmless
