@@ -1693,6 +1693,21 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     caps.loci_counts = geo.cap_loci_counts;
     caps.count_limit = kCountTileLimit;
     caps.allow_counts = (allow_count_tile && !pk.stage_masks) ? 1u : 0u;
+    // Segment length of the count tile's ranges. A segment is cut greedily -- full ranges, then a remainder --, and
+    // every range costs a workgroup the same set-up and the same item slots whatever it holds: a segment that
+    // needs 1.3 ranges (C5: 8190 loci x 1.3 entries per cell block and locus against 8192 staged entries) becomes
+    // one full range and one at 29 %, 49 ranges where 34 would do. Where a full-length segment overflows the
+    // entry limit, shorter segments that hold ONE range each at 93 % (the margin covers the densest block's
+    // fluctuation; a segment that overflows all the same is cut in two) are taken if they give fewer ranges.
+    if (caps.allow_counts && n_kept && L) {
+        const double density = (double)n_kept / ((double)num_cells / B) / (double)L;  // entries per (full cell block, locus)
+        const double per_segment = density * caps.loci_counts / caps.entries_counts;  // ranges a full-length segment needs
+        if (per_segment > 1.0) {
+            const double greedy = std::ceil((double)L / caps.loci_counts) * std::ceil(per_segment);
+            const uint32_t one = std::max(64u, (uint32_t)(0.93 * caps.entries_counts / density));
+            if (one < caps.loci_counts && std::ceil((double)L / one) * 1.05 < greedy) caps.loci_counts = one;
+        }
+    }
     const uint32_t lo_loci = caps.allow_counts ? std::min(caps.loci_plain, caps.loci_counts) : caps.loci_plain;
     const uint32_t hi_loci = caps.allow_counts ? std::max(caps.loci_plain, caps.loci_counts) : caps.loci_plain;
     const uint32_t n_seg = (L + lo_loci - 1) / lo_loci;
