@@ -700,7 +700,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
 // incidence of two different cells as a single-locus pair, whatever the reads' flags:
 //
 //   * ITEMS. A thread keeps its JPT row-side entries of the range in registers, each packed with what its
-//     pairs need: {cell | base (9 bits), first column entry j (13), column entries c (8)}.
+//     pairs need: {cell | base (9 bits), first column entry j (14), column entries c (8)}.
 //   * GROUPS OF FOUR. A wave takes 64 items and pairs each with its first four column entries: four LDS
 //     reads in flight at once, straight-line code, no loop, no flag test, no branch. 79 % of the slots
 //     hold a pair when loci are sparse (c ~ Poisson(3.8)).
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_tiles(const AccumulateArgs
 // was flushing its list (26 % of a wave's life on C3).
 // ------------------------------------------------------------------------------------------------
 constexpr int COUNTS_RING = 256;     // continuation items per wave
-constexpr uint32_t IT_J_SHIFT = 9, IT_C_SHIFT = 24, IT_J_MASK = 0x1FFFu, IT_WIDE = 32;
+constexpr uint32_t IT_J_SHIFT = 9, IT_C_SHIFT = 24, IT_J_MASK = 0x3FFFu, IT_WIDE = 32;
 constexpr uint32_t IT_REC_MASK = 0x1FFu;  // cell (7 bits) | base (2 bits)
 
 // GROUP: column entries an item is paired with per pass. Measured on one MI355X (accumulate phase, ms):
@@ -732,7 +732,7 @@ constexpr uint32_t IT_REC_MASK = 0x1FFu;  // cell (7 bits) | base (2 bits)
 // the ds_add -- 0.63e9 scalar instructions per C3 launch through the ONE scalar unit of a CU, 2.3e8 branches.
 template <int B, int THREADS, int CAPJ, int CAPL, int GROUP, bool SLOT_ASM>
 __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArgs a) {
-    static_assert(CAPJ <= 8192, "13 bits of column index in an item");
+    static_assert(CAPJ <= 16384, "14 bits of column index in an item");
     static_assert(GROUP >= 1 && GROUP <= 8, "group size");
     // Rows of the LDS tile are B + 1 words apart: the lanes of a wave that share a locus add to the SAME column
     // (their common column entry) in DIFFERENT rows, and with a row stride of B words all of them would hit one

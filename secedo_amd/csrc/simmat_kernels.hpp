@@ -21,7 +21,10 @@ struct LlrModelDev {  // LlrModel of llr_table.hpp, by value into the kernel
 // to these limits. LDS per workgroup: B=64: 32 KiB tile + 12/28 KiB; B=128: 128 KiB tile + 24/28 KiB.
 constexpr uint32_t kCapJ64 = 4096, kCapL64 = 2046, kCapJ64M = 2048, kCapL64M = 2046, kCapJ64C = 4096, kCapL64C = 2046;
 constexpr uint32_t kCapJ128 = 4096, kCapL128 = 2046, kCapJ128M = 4096, kCapL128M = 2046;
-constexpr uint32_t kCapJ128C = 8192, kCapL128C = 8190;  // the 64 KiB count tile leaves room for longer ranges
+// the 64 KiB count tile leaves room for longer ranges. Entries per range, C3 pair kernel with one range per segment
+// (pack_device.hip): 6144 2.60 ms, 8192 2.34, 10240 2.33, 12288 2.24 (a range's two barriers, its staging and
+// its prefetch are paid per range; 14336 needs the rings halved and 116 VGPRs: 2.5)
+constexpr uint32_t kCapJ128C = 12288, kCapL128C = 8190;
 constexpr double kMasksThreshold = 0.05;  // stage the masks when > 5 % of the entries are multi-locus
 
 // Everything only the rare paths touch lives in HBM behind one pointer, so that the kernel's
