@@ -1727,6 +1727,17 @@ __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
         scorr[tid] = a.lut[xs * LUT_DIM + xd] - (long long)xs * d10 - (long long)xd * d01;
     }
     __syncthreads();
+    // The usual launch -- one count tile per matrix tile, one workgroup per tile -- asks for its count tile NOW: the
+    // 16 words per thread land while the flagged entries are paired (the flush below then starts with its data at
+    // hand instead of with a round trip to HBM).
+    constexpr int PRE = (B * B) / THREADS;
+    const bool prefetched = S == 1u && a.tile_wg_begin[t_local + 1] - a.tile_wg_begin[t_local] == 1u && PRE <= 16;
+    uint32_t pre[PRE <= 16 ? PRE : 1];
+    if (prefetched) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.slab) + (size_t)a.tile_wg_begin[t_local] * B * B;
+#pragma unroll
+        for (int k = 0; k < (PRE <= 16 ? PRE : 1); ++k) pre[k] = __builtin_nontemporal_load(&src[tid + (uint32_t)k * THREADS]);
+    }
     long long upd_delta = 0, pair_delta = 0;  // per lane
 #ifdef SECEDO_STAMPS
     unsigned long long dg_tests = 0, dg_tail = 0, dg_joint = 0, dg_later = 0;
@@ -1876,7 +1887,8 @@ __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
     constexpr int F = (B * B / THREADS) < 8 ? (B * B / THREADS) : 8;
     static_assert((B * B) % (THREADS * F) == 0, "whole batches");
     const uint32_t *slab32 = reinterpret_cast<const uint32_t *>(a.slab);
-    for (uint32_t c0 = tid; c0 < (uint32_t)(B * B); c0 += THREADS * F) {
+    int batch = 0;
+    for (uint32_t c0 = tid; c0 < (uint32_t)(B * B); c0 += THREADS * F, ++batch) {
         uint32_t n_same[F], n_diff[F];
         long long old[F];
 #pragma unroll
@@ -1885,7 +1897,18 @@ __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
             n_diff[f] = 0;
             old[f] = (S == 1u && !a.overwrite) ? dst[c0 + f * THREADS] : 0ll;
         }
-        for (uint32_t w = w0; w < w1; ++w) {
+        if (prefetched) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                // (cell c0 + f * THREADS = tid + (batch * F + f) * THREADS: the word pre[batch * F + f])
+                uint32_t v = 0;
+#pragma unroll
+                for (int k = 0; k < (PRE <= 16 ? PRE : 1); ++k) v = (k == batch * F + f) ? pre[k] : v;
+                n_same[f] = v & 0xFFFFu;
+                n_diff[f] = v >> 16;
+            }
+        }
+        for (uint32_t w = prefetched ? w1 : w0; w < w1; ++w) {
 #pragma unroll
             for (int f = 0; f < F; ++f) {
                 const uint32_t c = c0 + f * THREADS;
