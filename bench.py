@@ -543,6 +543,9 @@ def main():
                 roofline["wait_frac_of_wave_cycles"] = counters["SQ_WAIT_ANY"] / counters["SQ_WAVE_CYCLES"]
             if counters.get("SQ_LDS_BANK_CONFLICT") and counters.get("SQ_LDS_IDX_ACTIVE"):
                 roofline["lds_bank_conflict_frac"] = counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"]
+            if cyc and counters.get("SQ_LDS_IDX_ACTIVE"):
+                # share of the kernel's CU-cycles (256 CUs) in which a CU's LDS pipeline has an instruction in hand
+                roofline["lds_pipe_busy_frac"] = counters["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc)
             roofline["counters_source"] = "profiles/%s_counters.json" % PROFILE_ROUND
         line = {
             "metric": "cell-pair x locus updates/sec (similarity matrix)",

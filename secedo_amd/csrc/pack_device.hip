@@ -373,7 +373,7 @@ __global__ void k_id_rank(Raw in, const uint32_t *dense, const uint32_t *id_off,
 constexpr uint32_t kCibBits = 7;
 constexpr uint32_t kNoEntry = 0xFFFFFFFFu;  // low word of an entry_kc slot: the entry was dropped
 // Single-entry fast path: an S entry (the only entry of its read) needs no k -- nothing of its read is looked
-// up again -- so the low word of its entry_kc slot carries kSingle | appearance rank and its base sits above
+// up again -- so the low word of its entry_kc slot carries kSingle alone and its base sits above
 // (block, cell in block) in the high word; k_bin_place turns the rank into the tail flag.
 constexpr uint32_t kSingle = 0x80000000u;
 constexpr uint32_t kSingleBaseShift = 29;  // in the high word of entry_kc (block << 7 | cell in block below)
@@ -581,9 +581,14 @@ __global__ void k_completed(Raw in, Ranks rank, const uint32_t *rbeg, uint32_t m
 // The loci at which a flush happens are listed per chromosome (flush_loci[l0 ..), flush_count[c]).
 // (only when some id spans >= max_fragment_length -- Scalars::long_reads, set by k_read_info just
 // before: nothing reads the list otherwise, and the bookkeeping triples the cost of the serial walk).
+// Last, the first TAIL entry of the chromosome among the single-entry reads (tail_begin != null): such an entry
+// is its read's first, the appearance ranks grow with the entry index, so "never flushed" -- rank - first rank of
+// the chromosome >= flushed -- holds from one entry of the chromosome on. k_bin_place compares entry indices with
+// it instead of looking every S entry's rank up. (A TPB-ary search: three rounds over 13 M entries.)
 __global__ __launch_bounds__(TPB) void k_flush_chain(Raw in, const uint32_t *cnt, uint32_t threshold,
                                                     const Scalars *sc, uint32_t *flushed_out,
-                                                    uint32_t *flush_loci, uint32_t *flush_count) {
+                                                    uint32_t *flush_loci, uint32_t *flush_count, Ranks rank,
+                                                    const uint32_t *rbeg, uint32_t *tail_begin) {
     __shared__ uint32_t buf[2048];
     __shared__ uint32_t hits[2048];  // flush loci of the tile: the serial walk touches LDS only
     __shared__ uint32_t s_flushed, s_listed, s_hits;
@@ -627,6 +632,30 @@ __global__ __launch_bounds__(TPB) void k_flush_chain(Raw in, const uint32_t *cnt
     if (threadIdx.x == 0) {
         flushed_out[c] = s_flushed;
         flush_count[c] = s_listed;
+    }
+    if (tail_begin) {
+        __shared__ uint32_t s_first;
+        const unsigned long long want = (unsigned long long)rbeg[c] + s_flushed;  // the first rank that is never flushed
+        uint32_t lo = (uint32_t)in.locus_entry_off[l0], hi = (uint32_t)in.locus_entry_off[l1];
+        // invariant: entries before lo have a smaller rank, the entry hi (or the chromosome's end) has not
+        while (lo < hi) {  // (uniform)
+            const uint32_t step = (hi - lo + TPB - 1) / TPB;
+            const unsigned long long probe = (unsigned long long)lo + (unsigned long long)threadIdx.x * step;
+            const bool reached = probe < hi && (unsigned long long)rank((uint32_t)probe) >= want;
+            __syncthreads();
+            if (threadIdx.x == 0) s_first = TPB;
+            __syncthreads();
+            if (reached) atomicMin(&s_first, threadIdx.x);
+            __syncthreads();
+            const uint32_t first = s_first;
+            if (first == TPB) {  // none of the probes: behind the last one
+                lo = lo + ((hi - lo - 1) / step) * step + 1;
+            } else {
+                hi = lo + first * step;
+                if (first) lo = lo + (first - 1) * step + 1;
+            }
+        }
+        if (threadIdx.x == 0) tail_begin[c] = lo;
     }
 }
 
@@ -690,7 +719,7 @@ __global__ void k_keys2(Raw in, const uint32_t *sval, const unsigned long long *
                         uint32_t num_cells, uint32_t B,
                         uint32_t lbits, unsigned long long *key2, uint32_t *val2, uint32_t *t_read,
                         uint32_t *krank, uint8_t *kflags, unsigned long long *entry_kc, const uint32_t *entry_map,
-                        Scalars *sc) {
+                        uint32_t *blk_cnt_add, uint32_t L, Scalars *sc) {
     // entry_map: the pileup entry of a (compacted) entry of `in` (single-entry fast path), or null: itself
     const uint32_t n = in.n_entries;
     for (uint32_t s = blockIdx.x * TPB + threadIdx.x; s < n; s += gridDim.x * TPB) {
@@ -724,61 +753,111 @@ __global__ void k_keys2(Raw in, const uint32_t *sval, const unsigned long long *
         // counting path: back in pileup order, where the entries of a locus are adjacent; one 8-byte
         // scatter per entry carries k and (block, cell in block)
         if (entry_kc) entry_kc[e_out] = ((unsigned long long)((blk << kCibBits) | cib) << 32) | k;
+        // (single-entry fast path: k_bin_hist has counted the S entries, possibly long ago; the few kept M
+        // entries join with one scattered atomic each)
+        if (blk_cnt_add) atomicAdd(&blk_cnt_add[(size_t)blk * (L + 1) + read_locus[k]], 1u);
     }
 }
 
 // counting path, kept entries by (cell block, locus). The entries of a locus are adjacent in the
 // pileup, so a wave counts a locus' entries per cell block in LDS -- global atomics would all hit the
 // handful of addresses of the loci in flight.
-// Single-entry fast path (m_idx != null): the S entries' slots are made here -- (block, cell) from the group
-// map, validated as k_keys2 does for the M entries -- since this is the first pass over the pileup order
-// after the appearance ranks exist.
-// A workgroup takes TL consecutive loci at a time (TL a power of two, <= 64, nb * (TL + 1) words of LDS): its
-// waves count a locus each into hist[block][locus in tile], and the tile leaves as rows of TL consecutive
-// loci per block -- coalesced, where a wave writing its locus' column touched nb different cache lines for
-// 4 bytes each (6.3 M scattered stores on C3). Rows are TL + 1 words apart: the entries of one locus go to
-// many blocks and a stride of TL would put them all on one bank.
-__global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, uint32_t TL, unsigned long long *entry_kc,
-                                                 const uint32_t *m_idx, const uint32_t *unm, uint32_t num_cells,
-                                                 uint32_t B, uint32_t *blk_cnt, Scalars *sc) {
+// Single-entry fast path (m_idx != null): ONLY the S entries are counted, and their slots are made here -- (block,
+// cell) from the group map, validated as k_keys2 does for the M entries -- with nothing of the read assembly:
+// k_keys2 adds the kept M entries afterwards, and k_bin_place knows an S entry's tail flag from its index.
+// (Measured and dropped: this pass on a stream of its own beside stages 1b-4. The kernels there are not idle
+// time but memory-side work -- the id-space scan went from 104 to 169 us next to it -- and the step gained
+// nothing.)
+// A workgroup takes TL consecutive loci at a time (TL a power of two, <= 64, nb * (TL + 1) words of LDS) and counts
+// their entries -- one contiguous stretch of the pileup -- into hist[block][locus in tile], a thread per entry,
+// four entries of a thread in flight; the locus of an entry comes from the tile's offsets in LDS (a search over 65
+// words: a third of the pass' vector instructions, but reading k_entry_locus' table instead was SLOWER, 193 against
+// 167 us -- the pass is bound by the memory streams it keeps open, see below). The tile leaves as rows of TL consecutive loci per block -- coalesced, where a column per locus touched nb
+// different cache lines for 4 bytes each (6.3 M scattered stores on C3). Rows are TL + 1 words apart: the entries of
+// one locus go to many blocks and a stride of TL would put them all on one bank.
+// (Until round 3 a WAVE walked a locus at a time, sixteen loci one after the other with three dependent round trips
+// each: 180 us on C3. What the pass costs is the sum of its memory streams, measured by switching them off one at a
+// time in a twin launch into dead buffers: the 8-byte slot store 52 us, the group -> cell gather 37, the 2-byte
+// id_base read 21, a 4-byte entry -> locus read 11, the LDS atomics and the count rows nothing, the empty loop 50.)
+__device__ __forceinline__ uint32_t tile_locus(const uint32_t *s_off, uint32_t lo, uint32_t hi, uint32_t e) {
+    // last j in [lo, hi) with s_off[j] <= e (s_off[lo] <= e; empty loci share an offset with their successor)
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_off[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, uint32_t TL, unsigned long long *__restrict__ entry_kc,
+                                                 const uint32_t *__restrict__ m_idx, uint32_t num_cells,
+                                                 uint32_t B_log2, uint32_t *__restrict__ blk_cnt, Scalars *sc) {
     extern __shared__ uint32_t lds_hist[];  // nb * (TL + 1)
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, L = in.n_loci, TLP = TL + 1u;
+    __shared__ uint32_t s_off[65];          // first entry of each of the tile's loci, and the end
+    static_assert(TPB >= 65, "one thread per offset");
+    const uint32_t L = in.n_loci, TLP = TL + 1u, TL_log2 = 31u - (uint32_t)__clz((int)TL);
     const uint32_t n_tiles = (L + TL - 1u) / TL;
+    constexpr int U = 4;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint32_t l0 = tile * TL, n_l = min(TL, L - l0);
         for (uint32_t i = threadIdx.x; i < nb * TLP; i += TPB) lds_hist[i] = 0;
+        if (threadIdx.x <= n_l) s_off[threadIdx.x] = (uint32_t)in.locus_entry_off[l0 + threadIdx.x];
         __syncthreads();
-        for (uint32_t j = wv; j < n_l; j += TPB / 64) {
-            const uint32_t l = l0 + j;
-            const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
-            for (uint32_t e = e0 + lane; e < e1; e += 64u) {
-                const uint32_t mj = m_idx ? m_idx[e] : 0u;
-                if (m_idx && m_idx[e + 1] == mj) {
-                    const uint32_t ib = in.id_base(e);
-                    const uint32_t group = ib >> 2;
-                    uint32_t cell = 0;
-                    if (group >= in.n_groups) {
-                        sc->error = 1;
-                    } else {
-                        cell = in.g2p[group];
-                        if (cell >= num_cells) {
-                            sc->error = 2;
-                            cell = 0;
-                        }
-                    }
-                    const uint32_t blk = cell / B, cib = cell - blk * B;
-                    entry_kc[e] = ((unsigned long long)(((ib & 3u) << kSingleBaseShift) | (blk << kCibBits) | cib) << 32)
-                            | kSingle | (e - unm[mj]);  // (its appearance rank: Ranks)
-                    atomicAdd(&lds_hist[blk * TLP + j], 1u);
-                    continue;
+        const uint32_t eb = s_off[0], ee = s_off[n_l];
+        for (uint32_t base = eb + threadIdx.x; base < ee; base += TPB * U) {
+            uint32_t slot[U];  // block of the entry, or none
+            constexpr uint32_t kNone = 0xFFFFFFFFu;
+            if (m_idx) {
+                uint32_t m0[U], m1[U], ib[U], cell[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t e = base + (uint32_t)u * TPB;
+                    const bool in_tile = e < ee;
+                    m0[u] = in_tile ? m_idx[e] : 0u;
+                    m1[u] = in_tile ? m_idx[e + 1] : 1u;  // (outside the tile: as an M entry, skipped)
+                    ib[u] = in_tile ? in.id_base(e) : 0u;
                 }
-                const unsigned long long kc = entry_kc[e];
-                if ((uint32_t)kc != kNoEntry) atomicAdd(&lds_hist[((uint32_t)(kc >> 32) >> kCibBits) * TLP + j], 1u);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t group = ib[u] >> 2;
+                    cell[u] = 0;
+                    if (m1[u] == m0[u]) {
+                        if (group >= in.n_groups) sc->error = 1;
+                        else cell[u] = in.g2p[group];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    slot[u] = kNone;
+                    if (m1[u] != m0[u]) continue;  // an M entry: k_keys2
+                    const uint32_t e = base + (uint32_t)u * TPB;
+                    uint32_t c = cell[u];
+                    if (c >= num_cells) {
+                        sc->error = 2;
+                        c = 0;
+                    }
+                    const uint32_t blk = c >> B_log2, cib = c - (blk << B_log2);
+                    entry_kc[e] = ((unsigned long long)(((ib[u] & 3u) << kSingleBaseShift) | (blk << kCibBits) | cib) << 32)
+                            | kSingle;
+                    slot[u] = blk;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t e = base + (uint32_t)u * TPB;
+                    const unsigned long long kc = e < ee ? entry_kc[e] : (unsigned long long)kNoEntry;
+                    slot[u] = (uint32_t)kc != kNoEntry ? (uint32_t)(kc >> 32) >> kCibBits : kNone;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (slot[u] == kNone) continue;
+                const uint32_t j = tile_locus(s_off, 0u, n_l, base + (uint32_t)u * TPB);
+                atomicAdd(&lds_hist[slot[u] * TLP + j], 1u);
             }
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < nb * TL; i += TPB) {
-            const uint32_t b = i / TL, j = i & (TL - 1u);
+            const uint32_t b = i >> TL_log2, j = i & (TL - 1u);
             if (j < n_l) {
                 blk_cnt[(size_t)b * (L + 1) + l0 + j] = lds_hist[b * TLP + j];
                 if (l0 + j == L - 1) blk_cnt[(size_t)b * (L + 1) + L] = 0;  // the closing slot of the block's row
@@ -793,48 +872,44 @@ __global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, uint32_t 
 // It also finds the loci at which some cell has more than one kept entry (a bitmap over the cells per wave,
 // bm_words words each; 0: no room, every locus is flagged): only there does k_entry_records have to count the
 // entries of the same cell for the pair bound -- on sparse loci that scan of every group was 40 % of its time.
-__global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, uint32_t TL, const unsigned long long *entry_kc,
-                                                  const uint32_t *blk_off, const uint32_t *rbeg,
-                                                  const uint32_t *flushed, uint32_t B, uint32_t bm_words,
-                                                  unsigned long long *grouped, uint8_t *dupflag) {
+// The bitmap wants a locus at a time, so a wave takes a run of consecutive loci of the tile -- one contiguous stretch
+// of entries -- in chunks of 64 with the chunks of the next round already asked for (D in flight), and inside a chunk
+// goes through the loci it holds in order; a locus is closed (flag written, bitmap cleared) when the chunk that
+// holds its last entry is done.
+__global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, uint32_t TL,
+                                                  const unsigned long long *__restrict__ entry_kc,
+                                                  const uint32_t *__restrict__ blk_off, uint32_t B_log2, uint32_t bm_words,
+                                                  const uint32_t *tail_begin,
+                                                  unsigned long long *__restrict__ grouped, uint8_t *dupflag) {
     extern __shared__ uint32_t lds_hist[];  // cursors, nb * (TL + 1); then the waves' cell bitmaps
+    __shared__ uint32_t s_off[65];          // first entry of each of the tile's loci, and the end
+    __shared__ uint32_t s_tail[64];         // per locus of the tile: the first tail entry of its chromosome (S entries)
+    constexpr uint32_t NW = TPB / 64;
+    constexpr int D = 4;  // chunks of a wave in flight
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, L = in.n_loci, TLP = TL + 1u;
+    const uint32_t TL_log2 = 31u - (uint32_t)__clz((int)TL);
     uint32_t *bm = lds_hist + nb * TLP + wv * bm_words;
     for (uint32_t i = lane; i < bm_words; i += 64u) bm[i] = 0;
     const uint32_t n_tiles = (L + TL - 1u) / TL;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint32_t l0 = tile * TL, n_l = min(TL, L - l0);
         for (uint32_t i = threadIdx.x; i < nb * TL; i += TPB) {
-            const uint32_t b = i / TL, j = i & (TL - 1u);
+            const uint32_t b = i >> TL_log2, j = i & (TL - 1u);
             if (j < n_l) lds_hist[b * TLP + j] = blk_off[(size_t)b * (L + 1) + l0 + j];
         }
+        if (threadIdx.x <= n_l) s_off[threadIdx.x] = (uint32_t)in.locus_entry_off[l0 + threadIdx.x];
+        if (threadIdx.x < n_l)
+            s_tail[threadIdx.x] = tail_begin
+                    ? tail_begin[last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l0 + threadIdx.x)] : 0u;
         __syncthreads();
-        for (uint32_t j = wv; j < n_l; j += TPB / 64) {
-            const uint32_t l = l0 + j;
-            const uint32_t e0 = (uint32_t)in.locus_entry_off[l], e1 = (uint32_t)in.locus_entry_off[l + 1];
-            const uint32_t chr = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
-            const uint32_t rb = rbeg[chr], fl_chr = flushed[chr];
-            bool twice = bm_words == 0u;
-            for (uint32_t e = e0 + lane; e < e1; e += 64u) {
-                const unsigned long long kc = entry_kc[e];
-                uint32_t k = (uint32_t)kc;
-                if (k == kNoEntry) continue;
-                uint32_t cc = (uint32_t)(kc >> 32);
-                if (k & kSingle) {  // rank -> tail flag (as emit_record tests it for an M entry); base beside it
-                    k = kSingle | ((k & ~kSingle) - rb >= fl_chr ? kSingleTail : 0u) | (cc >> kSingleBaseShift);
-                    cc &= (1u << kSingleBaseShift) - 1u;
-                }
-                if (bm_words) {
-                    const uint32_t cell = (cc >> kCibBits) * B + (cc & ((1u << kCibBits) - 1u));
-                    const uint32_t bit = 1u << (cell & 31u);
-                    twice |= (atomicOr(&bm[cell >> 5], bit) & bit) != 0u;
-                }
-                const uint32_t pos = atomicAdd(&lds_hist[(cc >> kCibBits) * TLP + j], 1u);
-                // cell in block | locus << 7 above k (k_entry_records; the radix path never comes here)
-                grouped[pos] = ((unsigned long long)((cc & ((1u << kCibBits) - 1u)) | (l << kCibBits)) << 32) | k;
-            }
+        const uint32_t per_wave = (n_l + NW - 1u) / NW;
+        const uint32_t ja = min(n_l, wv * per_wave), jb = min(n_l, ja + per_wave);
+        const uint32_t E0 = s_off[ja], E1 = s_off[jb];
+        uint32_t cur = ja;                // the locus being filled (wave-uniform)
+        bool twice = bm_words == 0u;      // ... has some cell twice (per lane until the locus is closed)
+        auto close_locus = [&]() {  // every entry of locus `cur` has been placed
             const bool any_twice = __ballot(twice) != 0ull;
-            if (lane == 0u) dupflag[l] = any_twice ? 1 : 0;
+            if (lane == 0u) dupflag[l0 + cur] = any_twice ? 1 : 0;
             if (bm_words) {  // the next locus starts from an empty bitmap
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -842,7 +917,56 @@ __global__ __launch_bounds__(TPB) void k_bin_place(Raw in, uint32_t nb, uint32_t
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
+            twice = bm_words == 0u;
+            ++cur;
+        };
+        auto chunk = [&](unsigned long long kc, uint32_t base) {  // the 64 entries from `base`, loaded
+            const uint32_t e = base + lane;
+            const bool valid = e < E1;
+            const uint32_t j = valid ? tile_locus(s_off, cur, jb, e) : 0xFFFFFFFFu;
+            const uint32_t chunk_end = min(E1, base + 64u);
+            while (true) {  // (wave-uniform)
+                if (valid && j == cur) {
+                    uint32_t k = (uint32_t)kc;
+                    if (k != kNoEntry) {
+                        uint32_t cc = (uint32_t)(kc >> 32);
+                        if (k & kSingle) {  // entry index -> tail flag (k_flush_chain); base beside it
+                            k = kSingle | (e >= s_tail[cur] ? kSingleTail : 0u) | (cc >> kSingleBaseShift);
+                            cc &= (1u << kSingleBaseShift) - 1u;
+                        }
+                        if (bm_words) {
+                            const uint32_t cell = ((cc >> kCibBits) << B_log2) + (cc & ((1u << kCibBits) - 1u));
+                            const uint32_t bit = 1u << (cell & 31u);
+                            twice |= (atomicOr(&bm[cell >> 5], bit) & bit) != 0u;
+                        }
+                        const uint32_t pos = atomicAdd(&lds_hist[(cc >> kCibBits) * TLP + cur], 1u);
+                        // cell in block | locus << 7 above k (k_entry_records; the radix path never comes here)
+                        grouped[pos] = ((unsigned long long)((cc & ((1u << kCibBits) - 1u)) | ((l0 + cur) << kCibBits)) << 32) | k;
+                    }
+                }
+                if (s_off[cur + 1] > chunk_end) break;  // the locus goes on in the next chunk
+                close_locus();
+                if (cur >= jb) break;
+            }
+        };
+        unsigned long long ring[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const uint32_t e = E0 + (uint32_t)d * 64u + lane;
+            ring[d] = e < E1 ? entry_kc[e] : (unsigned long long)kNoEntry;
         }
+        for (uint32_t base = E0; base < E1; base += 64u * D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const uint32_t b = base + (uint32_t)d * 64u;
+                if (b >= E1) break;  // (wave-uniform)
+                const unsigned long long kc = ring[d];
+                const uint32_t nxt = b + 64u * D + lane;
+                ring[d] = nxt < E1 ? entry_kc[nxt] : (unsigned long long)kNoEntry;
+                chunk(kc, b);
+            }
+        }
+        while (cur < jb) close_locus();  // (a run without entries)
         __syncthreads();
     }
 }
@@ -1022,12 +1146,16 @@ __global__ __launch_bounds__(TPB) void k_ranges_compact(const uint32_t *seg_ends
 }
 
 // per locus: its chromosome and its index inside its locus range (k_records looks both up per entry)
-__global__ void k_locus_info(Raw in, const uint32_t *range_off, const Scalars *sc, uint32_t *locus_chr,
-                             uint32_t *locus_rel) {
+// (locus_rel: the range-relative locus in the low half; bit 31: some cell has two kept entries at the locus --
+// k_bin_place's flag, so that k_entry_records reads ONE table per entry)
+constexpr uint32_t kLocusDup = 0x80000000u;
+__global__ void k_locus_info(Raw in, const uint32_t *range_off, const Scalars *sc, const uint8_t *dupflag,
+                             uint32_t *locus_chr, uint32_t *locus_rel) {
     const uint32_t n_ranges = sc->num_ranges;
     for (uint32_t l = blockIdx.x * TPB + threadIdx.x; l < in.n_loci; l += gridDim.x * TPB) {
         locus_chr[l] = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
-        locus_rel[l] = l - range_off[last_le<uint32_t>(range_off, n_ranges + 1, l)];
+        locus_rel[l] = (l - range_off[last_le<uint32_t>(range_off, n_ranges + 1, l)])
+                | ((dupflag && dupflag[l]) ? kLocusDup : 0u);
     }
 }
 
@@ -1087,7 +1215,7 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
             entry_read[d] = r;  // (read only for pairs of two multi-locus reads)
         }
         entry32[d] = cib | (base << kC_BaseShift) | (tail ? kC_Tail : 0u) | (multi ? kC_Multi : 0u)
-                | (wide ? kC_Wide : 0u) | (locus_rel[l] << 16);
+                | (wide ? kC_Wide : 0u) | ((locus_rel[l] & 0xFFFFu) << 16);
         col32[d] = col32_of(cib, base);
         if (mask32)  // staged by the clustered-loci tile variant only
             mask32[d] = (masks & 0xFFu) | (((masks >> 16) & 0xFFu) << 8) | ((bases & 0xFFu) << 16)
@@ -1112,7 +1240,6 @@ struct RecordTables {  // by value: what a record needs beside the group's own e
     const uint32_t *rbeg, *flushed, *locus_chr, *locus_rel;
     uint4 *entry;
     uint32_t *entry32, *col32, *mask32, *entry_read;
-    const uint8_t *dupflag;  // per locus (k_entry_records)
 };
 
 __device__ __forceinline__ void emit_record(const RecordTables &t, uint32_t d, uint32_t k, uint32_t cib, uint32_t cell,
@@ -1196,45 +1323,50 @@ __global__ __launch_bounds__(TPB_REC) void k_entry_records(const unsigned long l
     if (threadIdx.x == 0 && d0 < n) first_cell = block_of(d0) * B;
     __syncthreads();
     const uint32_t lmask = (1u << lbits) - 1u;
-    // A thread has U entries in flight: every step of the chain entry -> group offsets / locus tables -> group
-    // members -> chromosome tables is issued for all of them before the first result is used (one entry at a
-    // time, a thread walked five dependent round trips per entry: 0.36 ms on C3).
+    // A thread has U entries in flight, and every entry keeps as few memory streams open as it can -- the pass costs
+    // what its streams cost (see k_bin_hist): its slot, ONE per-locus word (range-relative locus | duplicate flag),
+    // its two stores. Only an M entry (one in twenty on sparse loci) looks its chromosome's rank base and flush count
+    // up, and only at a locus with a duplicate cell are the group's bounds read and its members counted. (Round 2
+    // read group bounds, three per-locus tables and two per-chromosome words for every entry: 280 us on C3.)
     constexpr int U = 4;
     for (uint32_t base = d0; base < d1; base += TPB_REC * U) {
         unsigned long long mine[U];
-        uint32_t blk[U], gb[U], ge[U], chr[U], lrel[U], dup[U];
+        uint32_t blk[U], linfo[U], rb[U], fl[U], same[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t p = base + (uint32_t)u * TPB_REC + threadIdx.x;
-            mine[u] = p < d1 ? grouped[p] : 0ull;
+            mine[u] = p < d1 ? grouped[p] : (unsigned long long)kSingle;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t p = base + (uint32_t)u * TPB_REC + threadIdx.x;
             const uint32_t l = (uint32_t)(mine[u] >> (32 + kCibBits)) & lmask;
             blk[u] = p < d1 ? block_of(p) : 0u;
-            const size_t g = (size_t)blk[u] * (L + 1) + l;
-            gb[u] = blk_off[g];
-            ge[u] = blk_off[g + 1];
-            chr[u] = t.locus_chr[l];
-            lrel[u] = t.locus_rel[l];
-            dup[u] = t.dupflag[l];  // some cell has two kept entries at this locus (k_bin_place): count them
+            linfo[u] = t.locus_rel[l];
+            rb[u] = 0;
+            fl[u] = 0;
+            if (((uint32_t)mine[u] & kSingle) == 0u) {  // an M entry: its tail flag is still to be found
+                const uint32_t chr = t.locus_chr[l];
+                rb[u] = t.rbeg[chr];
+                fl[u] = t.flushed[chr];
+            }
         }
-        uint32_t rb[U], fl[U], same[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t p = base + (uint32_t)u * TPB_REC + threadIdx.x;
-            rb[u] = t.rbeg[chr[u]];
-            fl[u] = t.flushed[chr[u]];
-            const uint32_t cib = (uint32_t)(mine[u] >> 32) & ((1u << kCibBits) - 1u);
-            const uint32_t len = ge[u] - gb[u];
             same[u] = 1;
-            if (p < d1 && len > kRankScanLimit) {
-                sc->regroup = 1;
-            } else if (p < d1 && len > 1 && dup[u]) {
-                same[u] = 0;
-                for (uint32_t q = gb[u]; q < ge[u]; ++q)
-                    same[u] += ((uint32_t)(grouped[q] >> 32) & ((1u << kCibBits) - 1u)) == cib ? 1u : 0u;
+            if (p < d1 && (linfo[u] & kLocusDup)) {  // some cell has two kept entries at this locus: count mine
+                const uint32_t l = (uint32_t)(mine[u] >> (32 + kCibBits)) & lmask;
+                const uint32_t cib = (uint32_t)(mine[u] >> 32) & ((1u << kCibBits) - 1u);
+                const size_t g = (size_t)blk[u] * (L + 1) + l;
+                const uint32_t gb = blk_off[g], ge = blk_off[g + 1];
+                if (ge - gb > kRankScanLimit) {
+                    sc->regroup = 1;
+                } else if (ge - gb > 1) {
+                    same[u] = 0;
+                    for (uint32_t q = gb; q < ge; ++q)
+                        same[u] += ((uint32_t)(grouped[q] >> 32) & ((1u << kCibBits) - 1u)) == cib ? 1u : 0u;
+                }
             }
         }
 #pragma unroll
@@ -1244,7 +1376,7 @@ __global__ __launch_bounds__(TPB_REC) void k_entry_records(const unsigned long l
             const uint32_t k = (uint32_t)mine[u], cib = (uint32_t)(mine[u] >> 32) & ((1u << kCibBits) - 1u);
             const uint32_t l = (uint32_t)(mine[u] >> (32 + kCibBits)) & lmask;
             const uint32_t cell = blk[u] * B + cib;
-            emit_record(t, p, k, cib, cell, l, lrel[u], rb[u], fl[u]);
+            emit_record(t, p, k, cib, cell, l, linfo[u] & 0xFFFFu, rb[u], fl[u]);
             const uint32_t rel = cell - first_cell;
             if (rel < SLOTS) atomicAdd(&sq[rel], (unsigned long long)same[u]);
             else atomicAdd(&per_cell_sq[cell], (unsigned long long)same[u]);
@@ -1285,7 +1417,7 @@ __global__ __launch_bounds__(TPB) void k_fix_locus_rel(const uint32_t *blk_off, 
         if (l == L) continue;
         const uint32_t b = blk_off[g], e = blk_off[g + 1];
         if (b == e) continue;
-        const uint32_t lrel = locus_rel[l] << 16;
+        const uint32_t lrel = (locus_rel[l] & 0xFFFFu) << 16;
         for (uint32_t d = b; d < e; ++d) entry32[d] = (entry32[d] & 0xFFFFu) | lrel;
     }
 }
@@ -1316,7 +1448,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     // worst-case block count (64-cell blocks) for buffers sized before the tile size is chosen
     const size_t n_off_max = (size_t)((num_cells + 63) / 64) * ((size_t)L + 1);
     enum { KEY_A, KEY_B, VAL_A, VAL_B, ELOC, WORK_A, WORK_B, RUNS, CUB, TMP, MISC, BIN, ENTRY_KC,
-           M_IDX, M_ENTRY, RID_M, IDB_M, ELOC_M, DENSE_M, MARK_M, ARANK_M, DUPF };
+           M_IDX, M_ENTRY, RID_M, IDB_M, ELOC_M, DENSE_M, MARK_M, ARANK_M, DUPF, SEGS };
     auto &S = pk.scratch;
     // the counting scheme for read ids needs a table over the id space
     const size_t id_space_cap = std::min<size_t>((size_t)kIdSpaceFactor * E + 1024, (size_t)1 << 30);
@@ -1326,8 +1458,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
 
     // ---- buffers (sized up front: a re-allocation in mid-pipeline would synchronise) -----------
     // MISC: Scalars | id_max[C] | id_negmin[C] | id_base[C+1] | rbeg[C+1] | flushed[C] | cnt[L] |
-    //       locus_chr[L] | locus_rel[L] | flush_loci[L] | flush_count[C]
-    HIP_OK(S[MISC].ensure(sizeof(Scalars) + sizeof(uint32_t) * ((size_t)6 * C + 4 + (size_t)4 * L) + 64));
+    //       locus_chr[L] | locus_rel[L] | flush_loci[L] | flush_count[C] | tail_begin[C]
+    HIP_OK(S[MISC].ensure(sizeof(Scalars) + sizeof(uint32_t) * ((size_t)7 * C + 4 + (size_t)4 * L) + 64));
     Scalars *sc = S[MISC].as<Scalars>();
     uint32_t *id_max = reinterpret_cast<uint32_t *>(sc + 1);
     uint32_t *id_negmin = id_max + C;
@@ -1337,6 +1469,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *cnt = flushed + C;
     uint32_t *locus_chr = cnt + L, *locus_rel = locus_chr + L;
     uint32_t *flush_loci = locus_rel + L, *flush_count = flush_loci + L;
+    uint32_t *tail_begin = flush_count + C;
     // KEY_A: sort keys in, later mark[E+1] | arank[E+1], later the per-(block, locus) counts
     // (marks and appearance ranks, 2 (E + 1) words, with the (block, locus) counts behind them: the ranks are
     // still read when the counts are written, k_bin_hist)
@@ -1345,8 +1478,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     HIP_OK(S[KEY_B].ensure((size_t)E * 8));
     HIP_OK(S[VAL_A].ensure((size_t)E * 4));
     HIP_OK(S[VAL_B].ensure((size_t)E * 4));
-    // ELOC: entry -> locus, later the range segments (count[n_seg] | ends[n_seg * cap_loci])
-    HIP_OK(S[ELOC].ensure(std::max<size_t>((size_t)E * 4, ((size_t)2 * L + 4 * 8192 + L / 64 + 16) * 4)));
+    // ELOC: entry -> locus (the pileup's entries: the binning passes read it to the end)
+    HIP_OK(S[ELOC].ensure((size_t)E * 4 + 16));
     HIP_OK(S[WORK_A].ensure(((size_t)E + 1) * 4));
     HIP_OK(S[WORK_B].ensure(((size_t)2 * E + 2) * 4));
     // RUNS: run_start[R+1] | run_rank[R] | starts_by_rank[R], R <= E
@@ -1381,6 +1514,22 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     void *cub_tmp = S[CUB].p;
     size_t cub_cap = 0;
     HIP_OK(hipMemsetAsync(sc, 0, sizeof(Scalars) + sizeof(uint32_t) * ((size_t)3 * C + 1), stream));
+
+    if (!pk.side) {
+        HIP_OK(hipStreamCreateWithFlags(&pk.side, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&pk.ev_fork, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&pk.ev_join, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&pk.ev_offsets, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&pk.ev_flush, hipEventDisableTiming));
+    }
+    auto bin_tiles = [&](uint32_t nb_, uint32_t *TL_, uint32_t *grid_, size_t *lds_) {
+        // tiles of TL consecutive loci per workgroup: nb * (TL + 1) words of LDS, 32 KiB at most (nb <= 1024)
+        uint32_t TL = 64;
+        while (TL > 1 && (size_t)nb_ * (TL + 1) * 4 > 32768) TL >>= 1;
+        *TL_ = TL;
+        *grid_ = std::min<uint32_t>((L + TL - 1) / TL, 8192);
+        *lds_ = (size_t)nb_ * (TL + 1) * 4;
+    };
 
     // ---- 1: entries grouped by (chromosome, read id), pileup order inside a read ---------------
     const HostTrace trace;
@@ -1528,13 +1677,6 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     HIP_OK(pk.blk_off.ensure((n_off_max + 1) * 4));
     uint32_t *read_off = pk.read_off.as<uint32_t>(), *read_locus = pk.read_locus.as<uint32_t>();
     uint8_t *read_base = pk.read_base.as<uint8_t>();
-    if (!pk.side) {
-        HIP_OK(hipStreamCreateWithFlags(&pk.side, hipStreamNonBlocking));
-        HIP_OK(hipEventCreateWithFlags(&pk.ev_fork, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&pk.ev_join, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&pk.ev_offsets, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&pk.ev_flush, hipEventDisableTiming));
-    }
     // reads from the current `split` flags, then completed counts and the flush chain. The chain is
     // sequential (one lane per chromosome) and only the final gather needs its result: it runs on a
     // side stream, next to the grouping of the kept entries.
@@ -1578,7 +1720,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         HIP_OK(hipStreamWaitEvent(pk.side, pk.ev_fork, 0));
         hipLaunchKernelGGL(k_completed, dim3(blocks_for(L)), dim3(TPB), 0, pk.side, raw, ranks, rbeg, mfl, cnt, sc);
         hipLaunchKernelGGL(k_flush_chain, dim3(C), dim3(TPB), 0, pk.side, raw, cnt, 4u * num_threads, sc, flushed,
-                           flush_loci, flush_count);
+                           flush_loci, flush_count, ranks, rbeg, split_singles ? tail_begin : nullptr);
         HIP_OK(hipEventRecord(pk.ev_flush, pk.side));
         HIP_OK(hipEventRecord(pk.ev_join, pk.side));
         return std::string();
@@ -1655,6 +1797,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     }
     const StageGeometry geo = geometry(block_cells);
     const uint32_t B = block_cells, nb = (num_cells + B - 1) / B;
+    if (B != 64 && B != 128) return "block_cells must be 64 or 128";
+    const uint32_t B_log2 = B == 64 ? 6u : 7u;
     const uint32_t lbits = (uint32_t)bits_for(L - 1);
     // k_bin_place packs the locus into 25 bits at most, and bit 31 of a k marks an S entry
     if (!force_radix && (lbits + kCibBits > 32u || E >= kSingle)) {
@@ -1712,8 +1856,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     const uint32_t hi_loci = caps.allow_counts ? std::max(caps.loci_plain, caps.loci_counts) : caps.loci_plain;
     const uint32_t n_seg = (L + lo_loci - 1) / lo_loci;
     const size_t variant_stride = (size_t)n_seg * hi_loci + n_seg + 2;
-    HIP_OK(S[ELOC].ensure(std::max<size_t>((size_t)E * 4, 2 * variant_stride * 4)));
-    uint32_t *seg_count = S[ELOC].as<uint32_t>();  // entry -> locus is dead after k_csr
+    HIP_OK(S[SEGS].ensure(2 * variant_stride * 4));
+    uint32_t *seg_count = S[SEGS].as<uint32_t>();  // (not over entry -> locus: the binning passes read it)
     uint32_t *seg_ends = seg_count + n_seg;
     auto cut_ranges_on_side = [&]() -> std::string {  // call when blk_off is complete on `stream`
         HIP_OK(hipEventRecord(pk.ev_offsets, stream));
@@ -1729,10 +1873,18 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     // are dead) and base | multi flag (the grouped ids in VAL_A are dead)
     uint32_t *krank = work_a;
     uint8_t *kflags = S[VAL_A].as<uint8_t>();
+    uint32_t TL = 0, locus_grid = 0;
+    size_t lds = 0;
+    if (!force_radix) bin_tiles(nb, &TL, &locus_grid, &lds);
+    const bool hist_first = split_singles && !force_radix;  // the S entries are counted before the M entries join
+    if (hist_first)
+        hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, TL, entry_kc, m_idx, num_cells,
+                           B_log2, blk_cnt, sc);
     if (n_m)
         hipLaunchKernelGGL(k_keys2, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, sval, incl, read_locus, run_rank,
                            read_off, num_cells, B, lbits, force_radix ? key2_a : nullptr, force_radix ? val2_a : nullptr,
-                           t_read, krank, kflags, entry_kc, split_singles ? m_entry : nullptr, sc);
+                           t_read, krank, kflags, entry_kc, split_singles ? m_entry : nullptr,
+                           hist_first ? blk_cnt : nullptr, L, sc);
     trace.mark("k_keys2 launched");
     const uint32_t slice_grid = std::min<uint32_t>(2048, (n_kept + 4095) / 4096);
     if (force_radix) {
@@ -1748,13 +1900,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         const std::string err = cut_ranges_on_side();
         if (!err.empty()) return err;
     } else {
-        // tiles of TL consecutive loci per workgroup: nb * (TL + 1) words of LDS, 32 KiB at most (nb <= 1024)
-        uint32_t TL = 64;
-        while (TL > 1 && (size_t)nb * (TL + 1) * 4 > 32768) TL >>= 1;
-        const uint32_t locus_grid = std::min<uint32_t>((L + TL - 1) / TL, 8192);
-        const size_t lds = (size_t)nb * (TL + 1) * 4;
-        hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, TL, entry_kc,
-                           split_singles ? m_idx : nullptr, arank, num_cells, B, blk_cnt, sc);
+        if (!hist_first)
+            hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, TL, entry_kc, nullptr, num_cells,
+                               B_log2, blk_cnt, sc);
         trace.mark("k_bin_hist launched");
         cub_cap = S[CUB].bytes;
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
@@ -1768,7 +1916,8 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             uint32_t bm_words = (nb * B + 31) / 32;
             if (lds + (size_t)(TPB / 64) * bm_words * 4 > 49152) bm_words = 0;
             hipLaunchKernelGGL(k_bin_place, dim3(locus_grid), dim3(TPB), lds + (size_t)(TPB / 64) * bm_words * 4, stream,
-                               raw, nb, TL, entry_kc, blk_off, rbeg, flushed, B, bm_words, grouped, dupflag);
+                               raw, nb, TL, entry_kc, blk_off, B_log2, bm_words, split_singles ? tail_begin : nullptr,
+                               grouped, dupflag);
         }
     }
     // the locus ranges were cut for both sets of limits on the side stream (after the flush chain): pick
@@ -1779,7 +1928,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
                            caps, pk.range_off.as<uint32_t>(), per_cell_sq, n_kept ? nb * B : 0u, -1, sc);
         if (n_kept) {
             hipLaunchKernelGGL(k_locus_info, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, pk.range_off.as<uint32_t>(),
-                               sc, locus_chr, locus_rel);
+                               sc, nullptr, locus_chr, locus_rel);
             hipLaunchKernelGGL(k_records, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, raw, key2_b, val2_b, n_kept,
                                t_read, read_off, read_locus, read_base, krank, kflags, rbeg, flushed, locus_chr,
                                locus_rel, B, lbits, pk.entry.as<uint4>(), pk.entry32.as<uint32_t>(),
@@ -1796,11 +1945,11 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
                            caps, pk.range_off.as<uint32_t>(), per_cell_sq, 0u, assumed, sc);
         if (n_kept) {
             hipLaunchKernelGGL(k_locus_info, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, pk.range_off.as<uint32_t>(),
-                               sc, locus_chr, locus_rel);
+                               sc, dupflag, locus_chr, locus_rel);
             const RecordTables tables{t_read, read_off, read_locus, read_base, krank, kflags, rbeg, flushed, locus_chr,
                                       locus_rel, pk.entry.as<uint4>(), pk.entry32.as<uint32_t>(),
                                       pk.col32.as<uint32_t>(), pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr,
-                                      pk.entry_read.as<uint32_t>(), dupflag};
+                                      pk.entry_read.as<uint32_t>()};
             const unsigned long long *grouped = key_b;
             hipLaunchKernelGGL(k_entry_records, dim3(std::min<uint32_t>(1u << 16, (n_kept + 4095) / 4096)), dim3(TPB_REC),
                                0, stream, grouped, blk_off, n_kept, nb, L, B, lbits, tables, per_cell_sq, sc);
@@ -1817,7 +1966,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
                            caps, pk.range_off.as<uint32_t>(), per_cell_sq, 0u, 0, sc);
         if (n_kept) {
             hipLaunchKernelGGL(k_locus_info, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, pk.range_off.as<uint32_t>(),
-                               sc, locus_chr, locus_rel);
+                               sc, nullptr, locus_chr, locus_rel);
             hipLaunchKernelGGL(k_fix_locus_rel, dim3(blocks_for(n_off)), dim3(TPB), 0, stream, blk_off, nb, L, locus_rel,
                                pk.entry32.as<uint32_t>());
         }
