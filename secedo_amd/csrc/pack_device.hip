@@ -1232,58 +1232,78 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
 // the entries of the same cell: an entry of a cell with n entries at the locus adds n to the cell's sum, n of
 // them n^2 -- the Cauchy-Schwarz pair bound. (A thread per GROUP instead read the tables once per group but
 // walked its entries one after the other, a chain of gathers per thread: 7.4 ms on C3 against 2.7.)
+// What the record of a kept M entry k needs of its read, made where the read's entries are adjacent (the per-read
+// lists, k ascending) instead of in binned order, where it is a chain of five dependent gathers per entry -- a
+// twentieth of the entries on sparse loci, but every wave of the record pass holds a few and waited for them
+// (90 us of its 280 on C3). m_rec[k] = {base, tail, overflow flags as in an entry's meta word | kRecMulti | kRecWide,
+// window masks, window bases, read index}; k_entry_records adds the cell and the locus.
+constexpr uint32_t kRecMulti = 1u << 30, kRecWide = 1u << 31;
+__global__ void k_m_records(Raw in, uint32_t n_kept_m, const uint32_t *t_read, const uint32_t *read_off,
+                            const uint32_t *read_locus, const uint8_t *read_base, const uint32_t *krank,
+                            const uint8_t *kflags, const uint32_t *rbeg, const uint32_t *flushed, uint4 *m_rec) {
+    for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_kept_m; k += gridDim.x * TPB) {
+        const uint32_t fl = kflags[k], l = read_locus[k];
+        const bool multi = (fl & 4u) != 0u;
+        const uint32_t chr = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
+        const bool tail = krank[k] - rbeg[chr] >= flushed[chr];
+        // the read's list of kept entries: only a multi-locus read has neighbours to look for
+        uint32_t r = 0, lo = k, hi = k + 1;
+        if (multi) {
+            r = t_read[k];
+            lo = read_off[r];
+            hi = read_off[r + 1];
+        }
+        uint32_t meta = ((fl & 3u) << kMetaBaseShift) | (tail ? kMetaTail : 0u) | (multi ? kRecMulti : 0u);
+        uint32_t masks = 0, bases = 0;
+        for (uint32_t j = k; j-- > lo;) {
+            const uint32_t dist = l - read_locus[j];
+            if (dist > kNarrowWindow) meta |= kRecWide;
+            if (dist > kWindow) {
+                meta |= kMetaPrevOvf;
+                break;
+            }
+            masks |= 1u << (dist - 1);
+        }
+        for (uint32_t j = k + 1; j < hi; ++j) {
+            const uint32_t dist = read_locus[j] - l;
+            if (dist > kNarrowWindow) meta |= kRecWide;
+            if (dist > kWindow) {
+                meta |= kMetaNextOvf;
+                break;
+            }
+            masks |= 1u << (16 + dist - 1);
+            bases |= (uint32_t)(read_base[j] & 1u) << (dist - 1);
+            bases |= (uint32_t)((read_base[j] >> 1) & 1u) << (16 + dist - 1);
+        }
+        m_rec[k] = make_uint4(meta, masks, bases, r);
+    }
+}
+
 struct RecordTables {  // by value: what a record needs beside the group's own entries
-    const uint32_t *t_read, *read_off, *read_locus;
-    const uint8_t *read_base;
-    const uint32_t *krank;
-    const uint8_t *kflags;
-    const uint32_t *rbeg, *flushed, *locus_chr, *locus_rel;
+    const uint4 *m_rec;  // per kept M entry (k_m_records)
+    const uint32_t *locus_rel;
     uint4 *entry;
     uint32_t *entry32, *col32, *mask32, *entry_read;
 };
 
-__device__ __forceinline__ void emit_record(const RecordTables &t, uint32_t d, uint32_t k, uint32_t cib, uint32_t cell,
-                                            uint32_t l, uint32_t lrel, uint32_t rb, uint32_t fl_chr) {
-    uint32_t base;
-    bool multi = false, tail;
+// rec: the M entry's m_rec word group, loaded by the caller (all zero for an S entry)
+__device__ __forceinline__ void emit_record(const RecordTables &t, uint32_t d, uint32_t k, uint4 rec, uint32_t cib,
+                                            uint32_t cell, uint32_t l, uint32_t lrel) {
+    uint32_t base, meta, masks = 0, bases = 0, r = 0;
+    bool multi = false, wide = false, tail;
     if (k & kSingle) {  // single-entry fast path: all there is to know came along (k_bin_place)
         base = k & 3u;
         tail = (k & kSingleTail) != 0u;
+        meta = cell | (base << kMetaBaseShift) | (tail ? kMetaTail : 0u);
     } else {
-        const uint32_t fl = t.kflags[k];
-        base = fl & 3u;
-        multi = (fl & 4u) != 0u;
-        tail = t.krank[k] - rb >= fl_chr;
-    }
-    // the read's list of kept entries: only a multi-locus read has neighbours to look for
-    uint32_t r = 0, lo = k, hi = k + 1;
-    if (multi) {
-        r = t.t_read[k];
-        lo = t.read_off[r];
-        hi = t.read_off[r + 1];
-    }
-    uint32_t meta = cell | (base << kMetaBaseShift) | (tail ? kMetaTail : 0u);
-    uint32_t masks = 0, bases = 0;
-    bool wide = false;
-    for (uint32_t j = k; j-- > lo;) {
-        const uint32_t dist = l - t.read_locus[j];
-        if (dist > kNarrowWindow) wide = true;
-        if (dist > kWindow) {
-            meta |= kMetaPrevOvf;
-            break;
-        }
-        masks |= 1u << (dist - 1);
-    }
-    for (uint32_t j = k + 1; j < hi; ++j) {
-        const uint32_t dist = t.read_locus[j] - l;
-        if (dist > kNarrowWindow) wide = true;
-        if (dist > kWindow) {
-            meta |= kMetaNextOvf;
-            break;
-        }
-        masks |= 1u << (16 + dist - 1);
-        bases |= (uint32_t)(t.read_base[j] & 1u) << (dist - 1);
-        bases |= (uint32_t)((t.read_base[j] >> 1) & 1u) << (16 + dist - 1);
+        base = (rec.x >> kMetaBaseShift) & 3u;
+        tail = (rec.x & kMetaTail) != 0u;
+        multi = (rec.x & kRecMulti) != 0u;
+        wide = (rec.x & kRecWide) != 0u;
+        meta = cell | (rec.x & ~(kRecMulti | kRecWide));
+        masks = rec.y;
+        bases = rec.z;
+        r = rec.w;
     }
     // the 16-byte record and the read index serve the flagged entries only (see k_records)
     if (multi || tail) {
@@ -1323,15 +1343,20 @@ __global__ __launch_bounds__(TPB_REC) void k_entry_records(const unsigned long l
     if (threadIdx.x == 0 && d0 < n) first_cell = block_of(d0) * B;
     __syncthreads();
     const uint32_t lmask = (1u << lbits) - 1u;
-    // A thread has U entries in flight, and every entry keeps as few memory streams open as it can -- the pass costs
-    // what its streams cost (see k_bin_hist): its slot, ONE per-locus word (range-relative locus | duplicate flag),
-    // its two stores. Only an M entry (one in twenty on sparse loci) looks its chromosome's rank base and flush count
-    // up, and only at a locus with a duplicate cell are the group's bounds read and its members counted. (Round 2
-    // read group bounds, three per-locus tables and two per-chromosome words for every entry: 280 us on C3.)
+    // A thread has U entries in flight, and an entry's chain of dependent reads is as short as it can be: its slot,
+    // then ONE per-locus word (range-relative locus | duplicate flag) and, for an M entry (one in twenty on sparse
+    // loci), the 16 bytes k_m_records made of its read; only at a locus with a duplicate cell are the group's bounds
+    // read and its members counted. (Round 2 read group bounds, three per-locus tables and two per-chromosome words
+    // for every entry and walked the read's lists here: 280 us on C3; switching the pieces off one at a time in a
+    // twin launch showed 92 us for the per-locus level of the chain, 90 for the M entries' five levels, 126 for
+    // the stores, 20 for the block search. Staging the slice's per-locus words in LDS -- the slots are in (block,
+    // locus) order, a slice covers 2000 consecutive loci -- was measured SLOWER, 197 against 176 us: two more
+    // dependent reads and two barriers in front of every slice.)
     constexpr int U = 4;
     for (uint32_t base = d0; base < d1; base += TPB_REC * U) {
         unsigned long long mine[U];
-        uint32_t blk[U], linfo[U], rb[U], fl[U], same[U];
+        uint32_t blk[U], linfo[U], same[U];
+        uint4 rec[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t p = base + (uint32_t)u * TPB_REC + threadIdx.x;
@@ -1343,13 +1368,8 @@ __global__ __launch_bounds__(TPB_REC) void k_entry_records(const unsigned long l
             const uint32_t l = (uint32_t)(mine[u] >> (32 + kCibBits)) & lmask;
             blk[u] = p < d1 ? block_of(p) : 0u;
             linfo[u] = t.locus_rel[l];
-            rb[u] = 0;
-            fl[u] = 0;
-            if (((uint32_t)mine[u] & kSingle) == 0u) {  // an M entry: its tail flag is still to be found
-                const uint32_t chr = t.locus_chr[l];
-                rb[u] = t.rbeg[chr];
-                fl[u] = t.flushed[chr];
-            }
+            rec[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (((uint32_t)mine[u] & kSingle) == 0u) rec[u] = t.m_rec[(uint32_t)mine[u]];  // an M entry
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1376,7 +1396,7 @@ __global__ __launch_bounds__(TPB_REC) void k_entry_records(const unsigned long l
             const uint32_t k = (uint32_t)mine[u], cib = (uint32_t)(mine[u] >> 32) & ((1u << kCibBits) - 1u);
             const uint32_t l = (uint32_t)(mine[u] >> (32 + kCibBits)) & lmask;
             const uint32_t cell = blk[u] * B + cib;
-            emit_record(t, p, k, cib, cell, l, linfo[u] & 0xFFFFu, rb[u], fl[u]);
+            emit_record(t, p, k, rec[u], cib, cell, l, linfo[u] & 0xFFFFu);
             const uint32_t rel = cell - first_cell;
             if (rel < SLOTS) atomicAdd(&sq[rel], (unsigned long long)same[u]);
             else atomicAdd(&per_cell_sq[cell], (unsigned long long)same[u]);
@@ -1817,6 +1837,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     uint32_t *t_read = S[TMP].as<uint32_t>();
     unsigned long long *key2_a = S[BIN].as<unsigned long long>();
     unsigned long long *key2_b = key2_a + nk;
+    uint4 *m_rec = S[BIN].as<uint4>();  // counting path (no binning keys): 16 bytes per kept M entry, k_m_records
     unsigned long long *per_cell_sq = key2_b + nk;  // nb * B entries
     uint32_t *val2_a = reinterpret_cast<uint32_t *>(per_cell_sq + (size_t)nb * B + 1);
     uint32_t *val2_b = val2_a + nk;
@@ -1909,6 +1930,11 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         trace.mark("offset scan launched");
         const std::string err = cut_ranges_on_side();
         if (!err.empty()) return err;
+        if (kept_m) {  // behind the flush chain and the range cutting, beside the placing pass
+            hipLaunchKernelGGL(k_m_records, dim3(blocks_for(kept_m)), dim3(TPB), 0, pk.side, raw, kept_m, t_read, read_off,
+                               read_locus, read_base, krank, kflags, rbeg, flushed, m_rec);
+            HIP_OK(hipEventRecord(pk.ev_join, pk.side));
+        }
         if (n_kept) {
             unsigned long long *grouped = key_b;  // the sorted entry keys are dead after k_dup_rule
             HIP_OK(hipStreamWaitEvent(stream, pk.ev_flush, 0));  // the S entries' tail flags
@@ -1946,8 +1972,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         if (n_kept) {
             hipLaunchKernelGGL(k_locus_info, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, pk.range_off.as<uint32_t>(),
                                sc, dupflag, locus_chr, locus_rel);
-            const RecordTables tables{t_read, read_off, read_locus, read_base, krank, kflags, rbeg, flushed, locus_chr,
-                                      locus_rel, pk.entry.as<uint4>(), pk.entry32.as<uint32_t>(),
+            const RecordTables tables{m_rec, locus_rel, pk.entry.as<uint4>(), pk.entry32.as<uint32_t>(),
                                       pk.col32.as<uint32_t>(), pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr,
                                       pk.entry_read.as<uint32_t>()};
             const unsigned long long *grouped = key_b;
