@@ -370,6 +370,194 @@ __global__ void k_id_rank(Raw in, const uint32_t *dense, const uint32_t *id_off,
     }
 }
 
+// ---- stage 1 of the single-entry fast path: which ids repeat, and the reads of those that do ------------------
+// Only WHICH ids occur more than once is wanted of all entries; how often and where only of the few that do. So the
+// entries do not count their id, they swap themselves into its slot: whoever finds a predecessor there flags the
+// predecessor and itself (every entry of a repeated id ends up flagged whatever the order of arrival) and keeps the
+// predecessor as a link. The flags are a byte per entry IN PILEUP ORDER: numbering the M entries is a pass over
+// 13 MB (k_flag_count, k_flag_scan, k_compact_m) where a scan that gathers hist[dense[e]] took 155 us on C3; and the
+// links are the reads: the last holder of a slot walks back through its id's entries (k_chain_len / k_chain_write),
+// no offsets over the id space (104 us), no histogram of the repeated ids.
+constexpr uint32_t kFlagBlock = 4096;      // entries per workgroup of the numbering passes
+constexpr uint32_t kChainLimit = 1024;     // entries of one id beyond which the attempt is void (Scalars::regroup: radix sorts)
+__global__ void k_id_last(Raw in, const uint32_t *entry_locus, const uint32_t *id_base, const uint32_t *id_negmin,
+                          const Scalars *sc, uint32_t *dense, uint32_t *last, uint32_t *prev_e, uint8_t *multi,
+                          uint8_t *has_pred) {
+    if (sc->id_exceeded) return;  // the table is too small: no flags, no M entries; the caller starts over
+    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < in.n_entries; e += gridDim.x * TPB) {
+        const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, entry_locus[e]);
+        const uint32_t d = id_base[c] + (in.read_ids[e] - ~id_negmin[c]);
+        dense[e] = d;
+        const uint32_t prev = atomicExch(&last[d], e + 1u);
+        if (prev) {
+            multi[e] = 1;
+            has_pred[e] = 1;
+            prev_e[e] = prev - 1u;
+            multi[prev - 1u] = 1;
+        }
+    }
+}
+// flags per block of kFlagBlock entries (the flag array is zero-padded to whole blocks)
+__global__ __launch_bounds__(TPB) void k_flag_count(const uint8_t *multi, uint32_t *block_sum) {
+    __shared__ uint32_t part[TPB / 64];
+    static_assert(kFlagBlock == TPB * 16, "a thread takes 16 consecutive flags");
+    const uint4 w = reinterpret_cast<const uint4 *>(multi + (size_t)blockIdx.x * kFlagBlock)[threadIdx.x];
+    uint32_t n = ((w.x * 0x01010101u) >> 24) + ((w.y * 0x01010101u) >> 24) + ((w.z * 0x01010101u) >> 24)
+            + ((w.w * 0x01010101u) >> 24);
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        for (int w2 = 1; w2 < TPB / 64; ++w2) n += part[w2];
+        block_sum[blockIdx.x] = n;
+    }
+}
+// exclusive offsets of the blocks (one workgroup; 3000 blocks on C3), the number of M entries
+__global__ __launch_bounds__(TPB) void k_flag_scan(const uint32_t *block_sum, uint32_t n_blocks, uint32_t *block_off,
+                                                  uint32_t *m_idx_end, Scalars *sc) {
+    __shared__ uint32_t part[TPB / 64];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0u) carry = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < n_blocks; base += TPB) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_blocks ? block_sum[i] : 0u;
+        uint32_t incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= (uint32_t)off) incl += up;
+        }
+        if (lane == 63u) part[wv] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t w2 = 0; w2 < wv; ++w2) before += part[w2];
+        if (i < n_blocks) block_off[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == TPB - 1) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0u) {
+        *m_idx_end = carry;  // m_idx[E]
+        sc->n_multi_id = carry;
+    }
+}
+// m_idx = exclusive scan of the flags (entry e is an M entry iff m_idx[e + 1] != m_idx[e]) and the list of the M
+// entries; k_m_fields, once their number is known, copies them out as a compacted pileup of their own and finds
+// which of them holds its id's slot (the head its read is walked from)
+__global__ __launch_bounds__(TPB) void k_compact_m(Raw in, const uint8_t *multi, const uint32_t *block_off,
+                                                  uint32_t *m_idx, uint32_t *m_entry) {
+    __shared__ uint32_t part[TPB / 64];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t e0 = blockIdx.x * kFlagBlock + threadIdx.x * 16u;
+    const uint4 w = reinterpret_cast<const uint4 *>(multi + (size_t)blockIdx.x * kFlagBlock)[threadIdx.x];
+    const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mine += (words[i] * 0x01010101u) >> 24;
+    uint32_t incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if (lane >= (uint32_t)off) incl += up;
+    }
+    if (lane == 63u) part[wv] = incl;
+    __syncthreads();
+    uint32_t j = block_off[blockIdx.x] + incl - mine;
+    for (uint32_t w2 = 0; w2 < wv; ++w2) j += part[w2];
+    const uint32_t n = in.n_entries;
+    // m_idx leaves through LDS: a thread's 16 consecutive words, stored from registers, were 16 stores of 64 lanes
+    // 64 bytes apart (250 us on C3); rows of 17 words keep the transposing writes off one bank
+    __shared__ uint32_t tile[TPB * 17];
+    {
+        uint32_t jj = j;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            tile[threadIdx.x * 17u + (uint32_t)i] = jj;
+            jj += (words[i >> 2] >> ((i & 3) * 8)) & 1u;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t i = (uint32_t)k * TPB + threadIdx.x;  // position in the block
+        const uint32_t e = blockIdx.x * kFlagBlock + i;
+        if (e < n) m_idx[e] = tile[(i >> 4) * 17u + (i & 15u)];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t e = e0 + (uint32_t)i;
+        if (e >= n) break;  // (the padding holds no flags)
+        if ((words[i >> 2] >> ((i & 3) * 8)) & 1u) m_entry[j++] = e;
+    }
+}
+__global__ void k_m_fields(Raw in, const uint32_t *eloc, const uint32_t *dense, const uint32_t *last,
+                           const uint32_t *m_entry, uint32_t n_m, uint32_t *rid_m, uint32_t *idb_m, uint32_t *eloc_m,
+                           uint32_t *head_m) {
+    for (uint32_t j = blockIdx.x * TPB + threadIdx.x; j < n_m; j += gridDim.x * TPB) {
+        const uint32_t e = m_entry[j];
+        rid_m[j] = in.read_ids[e];
+        idb_m[j] = in.id_base(e);
+        eloc_m[j] = eloc[e];
+        head_m[j] = last[dense[e]] == e + 1u ? 1u : 0u;
+    }
+}
+// the reads of the M entries from the links: the head of an id counts its entries ...
+__global__ void k_chain_len(const uint32_t *m_entry, const uint32_t *head_m, uint32_t n_m, const uint32_t *prev_e,
+                            const uint8_t *has_pred, uint32_t *len_m, Scalars *sc) {
+    for (uint32_t j = blockIdx.x * TPB + threadIdx.x; j <= n_m; j += gridDim.x * TPB) {
+        uint32_t n = 0;
+        if (j < n_m && head_m[j]) {
+            uint32_t e = m_entry[j];
+            n = 1;
+            while (has_pred[e]) {  // (to the end whatever the length: what follows needs every M entry in a read)
+                e = prev_e[e];
+                ++n;
+            }
+            if (n > kChainLimit) sc->regroup = 1;  // one thread per read does not suit such reads: the caller sorts
+        }
+        len_m[j] = n;
+    }
+}
+// ... and, its read's place known (the exclusive sums of the counts), lists them: members[] holds the M indices of
+// the read in the order of the walk, every member learns where its read starts and how long it is
+__global__ void k_chain_write(const uint32_t *m_entry, const uint32_t *head_m, uint32_t n_m, const uint32_t *prev_e,
+                              const uint8_t *has_pred, const uint32_t *m_idx, const uint32_t *len_m,
+                              const uint32_t *goff, uint32_t *members, uint32_t *g_begin, uint32_t *g_len) {
+    for (uint32_t j = blockIdx.x * TPB + threadIdx.x; j < n_m; j += gridDim.x * TPB) {
+        if (!head_m[j]) continue;
+        const uint32_t b = goff[j], n = len_m[j];
+        uint32_t e = m_entry[j], m = j;
+        for (uint32_t i = 0; i < n; ++i) {
+            members[b + i] = m;
+            g_begin[m] = b;
+            g_len[m] = n;
+            if (i + 1 < n) {
+                e = prev_e[e];
+                m = m_idx[e];
+            }
+        }
+    }
+}
+// pileup order inside a read (the M indices grow with the pileup): a member's rank is the number of smaller members.
+// skey: the read's first position stands for its id (equal keys <=> same read is all the stages behind need).
+// (A read beyond kChainLimit keeps the order of the walk -- the attempt is void, but every position holds an entry.)
+__global__ void k_chain_rank(Raw sub, const uint32_t *members, const uint32_t *g_begin, const uint32_t *g_len,
+                             const uint32_t *eloc_m, uint32_t n_m, unsigned long long *skey, uint32_t *sval,
+                             uint32_t *sloc) {
+    for (uint32_t p = blockIdx.x * TPB + threadIdx.x; p < n_m; p += gridDim.x * TPB) {
+        const uint32_t m = members[p];
+        const uint32_t b = g_begin[m], n = g_len[m];
+        uint32_t rank = p - b;
+        if (n <= kChainLimit) {
+            rank = 0;
+            for (uint32_t q = b; q < b + n; ++q) rank += members[q] < m ? 1u : 0u;
+        }
+        skey[b + rank] = b;
+        sval[b + rank] = m;
+        sloc[b + rank] = sloc_pack(eloc_m[m], sub.id_base(m));
+    }
+}
+
 constexpr uint32_t kCibBits = 7;
 constexpr uint32_t kNoEntry = 0xFFFFFFFFu;  // low word of an entry_kc slot: the entry was dropped
 // Single-entry fast path: an S entry (the only entry of its read) needs no k -- nothing of its read is looked
@@ -380,44 +568,12 @@ constexpr uint32_t kSingleBaseShift = 29;  // in the high word of entry_kc (bloc
 constexpr uint32_t kSingleTail = 4u;       // in the low word of a grouped S entry: kSingle | tail | base
 
 // ---- the single-entry fast path ---------------------------------------------------------------------
-// With sparse loci nine reads in ten have ONE entry (the id histogram says which), and for those the whole
+// With sparse loci nine reads in ten have ONE entry (k_id_last says which), and for those the whole
 // read assembly -- scatter, rank, duplicate rule, per-read lists, per-read info -- is the identity. Only the
 // entries of ids that occur more than once ("M entries") go through it, as a compacted pileup of their own
 // (the kernels below see a Raw whose entry arrays are the compacted copies); the others ("S entries") meet
 // them again at the appearance-rank scan (every S entry is the first and only entry of its read) and at
 // the binning.
-struct IsMultiId {  // input of the scan that numbers the M entries: 1 where the entry's id occurs again
-    const uint32_t *dense, *hist;
-    uint32_t n;
-    const Scalars *sc;
-    __device__ __forceinline__ uint32_t operator()(uint32_t e) const {
-        // (sc->id_exceeded: the id table was too small and dense[] was not written; the attempt is void)
-        return (e < n && sc->id_exceeded == 0u && hist[dense[e]] > 1u) ? 1u : 0u;
-    }
-};
-// m_idx = exclusive scan of the flags: entry e is an M entry iff m_idx[e + 1] != m_idx[e]
-__global__ void k_compact_m(Raw in, const uint32_t *eloc, const uint32_t *dense, const uint32_t *m_idx,
-                            uint32_t *m_entry, uint32_t *rid_m, uint32_t *idb_m, uint32_t *eloc_m,
-                            uint32_t *dense_m, Scalars *sc) {
-    const uint32_t n = in.n_entries;
-    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < n; e += gridDim.x * TPB) {
-        const uint32_t j = m_idx[e];
-        if (m_idx[e + 1] == j) continue;
-        m_entry[j] = e;
-        rid_m[j] = in.read_ids[e];
-        idb_m[j] = in.id_base(e);
-        eloc_m[j] = eloc[e];
-        dense_m[j] = dense[e];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc->n_multi_id = m_idx[n];
-}
-struct MultiOnly {  // histogram of the ids that occur more than once (input of the offset scan)
-    const uint32_t *hist;
-    __device__ __forceinline__ uint32_t operator()(uint32_t d) const {
-        const uint32_t h = hist[d];
-        return h > 1u ? h : 0u;
-    }
-};
 // Appearance rank of a pileup entry = marked entries before it. Single-entry fast path: every S entry is
 // marked, so rank(e) = e - (unmarked M entries before e) = e - unm[m_idx[e]], with unm the exclusive prefix of
 // (1 - mark) over the M entries only -- a scan over 5 % of the pileup (C3) instead of one over all of it.
@@ -1496,7 +1652,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     HIP_OK(S[KEY_A].ensure(std::max<size_t>((size_t)E * 8, ((size_t)2 * E + 4 + n_off_max + 1) * 4)));
     // KEY_B: sorted keys, later (counting path) the kept entries grouped by (block, locus)
     HIP_OK(S[KEY_B].ensure((size_t)E * 8));
-    HIP_OK(S[VAL_A].ensure((size_t)E * 4));
+    HIP_OK(S[VAL_A].ensure(std::max<size_t>(E, 64) * 4));
     HIP_OK(S[VAL_B].ensure((size_t)E * 4));
     // ELOC: entry -> locus (the pileup's entries: the binning passes read it to the end)
     HIP_OK(S[ELOC].ensure((size_t)E * 4 + 16));
@@ -1596,25 +1752,29 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         uint32_t *hist = work_a, *id_off = work_b, *grouped = val_a;
         uint32_t *dense = S[KEY_A].as<uint32_t>();  // the radix path's unsorted keys live here
         HIP_OK(hipMemsetAsync(hist, 0, (id_space + 1) * 4, stream));
-        hipLaunchKernelGGL(k_id_hist, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_base, id_negmin, sc,
-                           dense, hist);
+        uint32_t *prev_e = work_b;  // (the offsets over the id space are the general path's)
+        uint8_t *has_pred = nullptr;
         if (split_singles) {
-            // the entries of ids that occur more than once, as a compacted pileup of their own (see k_classify)
+            // which ids repeat (k_id_last), the entries of those as a compacted pileup of their own
+            const size_t padded = ((size_t)E + kFlagBlock - 1) / kFlagBlock * kFlagBlock + 16;
+            const uint32_t n_flag_blocks = (uint32_t)((padded - 16) / kFlagBlock);
             HIP_OK(S[M_IDX].ensure(((size_t)E + 2) * 4));
             m_idx = S[M_IDX].as<uint32_t>();
-            HIP_OK(S[MARK_M].ensure(((size_t)E + 2) * 4));
-            {
-                hipcub::CountingInputIterator<uint32_t> entries(0u);
-                hipcub::TransformInputIterator<uint32_t, IsMultiId, hipcub::CountingInputIterator<uint32_t>> flags(
-                        entries, IsMultiId{dense, hist, E, sc});
-                cub_cap = S[CUB].bytes;
-                HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, flags, m_idx, (int)E + 1, stream));
-            }
-            for (int a : {M_ENTRY, RID_M, IDB_M, ELOC_M, DENSE_M, ARANK_M}) HIP_OK(S[a].ensure((size_t)E * 4 + 16));
+            HIP_OK(S[MARK_M].ensure(std::max(((size_t)E + 2) * 4, 2 * padded)));
+            uint8_t *multi = S[MARK_M].as<uint8_t>();  // (the marks of the M entries come later: k_dup_mark)
+            has_pred = multi + padded;
+            HIP_OK(hipMemsetAsync(multi, 0, 2 * padded, stream));
+            hipLaunchKernelGGL(k_id_last, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_base, id_negmin, sc,
+                               dense, hist, prev_e, multi, has_pred);
+            for (int a : {M_ENTRY, RID_M, IDB_M, ELOC_M, ARANK_M}) HIP_OK(S[a].ensure((size_t)E * 4 + 16));
+            // (the reads of the M entries, at most half of all entries: len[n_m+1] | goff[n_m+1] | begin | len | members)
+            HIP_OK(S[DENSE_M].ensure(((size_t)5 * (E / 2 + 1) + 8) * 4));
             m_entry = S[M_ENTRY].as<uint32_t>();
-            uint32_t *dense_m = S[DENSE_M].as<uint32_t>();
-            hipLaunchKernelGGL(k_compact_m, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, dense, m_idx, m_entry,
-                               S[RID_M].as<uint32_t>(), S[IDB_M].as<uint32_t>(), S[ELOC_M].as<uint32_t>(), dense_m, sc);
+            uint32_t *block_sum = grouped, *block_off = grouped + n_flag_blocks + 1;  // (VAL_A: 2 words per 4096 entries)
+            hipLaunchKernelGGL(k_flag_count, dim3(n_flag_blocks), dim3(TPB), 0, stream, multi, block_sum);
+            hipLaunchKernelGGL(k_flag_scan, dim3(1), dim3(TPB), 0, stream, block_sum, n_flag_blocks, block_off, m_idx + E,
+                               sc);
+            hipLaunchKernelGGL(k_compact_m, dim3(n_flag_blocks), dim3(TPB), 0, stream, raw, multi, block_off, m_idx, m_entry);
             // read-back 1b: how many entries take the general path (sizes every launch over them)
             HIP_OK(read_scalars(pk, stream, sc, nullptr, &hsc, nullptr));
             if (hsc.error == 3) return "positions must be strictly increasing within a chromosome";
@@ -1631,30 +1791,36 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
                 n_m = E;
                 m_idx = nullptr;
                 m_entry = nullptr;
+                // (the id slots hold entry numbers, the general path wants counts)
+                HIP_OK(hipMemsetAsync(hist, 0, (id_space + 1) * 4, stream));
             }
         }
         if (split_singles) {
-            uint32_t *dense_m = S[DENSE_M].as<uint32_t>();
             sub = raw;
             sub.read_ids = S[RID_M].as<uint32_t>();
             sub.id_base16 = nullptr;
             sub.id_base32 = S[IDB_M].as<uint32_t>();
             sub.n_entries = n_m;
             sub_eloc = S[ELOC_M].as<uint32_t>();
-            cub_cap = S[CUB].bytes;
-            {
-                hipcub::CountingInputIterator<uint32_t> ids(0u);
-                hipcub::TransformInputIterator<uint32_t, MultiOnly, hipcub::CountingInputIterator<uint32_t>> multi_hist(
-                        ids, MultiOnly{hist});
-                HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, multi_hist, id_off, (int)(id_space + 1), stream));
-            }
             if (n_m) {
-                hipLaunchKernelGGL(k_id_scatter, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, dense_m, n_m, id_off, sc,
-                                   hist, grouped);
-                hipLaunchKernelGGL(k_id_rank, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, dense_m, id_off, grouped,
-                                   sub_eloc, key_b, val_b, sloc, sc);
+                // the reads of the M entries, from the links k_id_last left
+                uint32_t *len_m = S[DENSE_M].as<uint32_t>(), *goff = len_m + n_m + 1, *g_begin = goff + n_m + 1;
+                uint32_t *g_len = g_begin + n_m, *members = g_len + n_m;
+                uint32_t *head_m = S[ARANK_M].as<uint32_t>();  // (the M entries' ranks come later: k_arank_m)
+                hipLaunchKernelGGL(k_m_fields, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, raw, eloc, dense, hist, m_entry, n_m,
+                                   S[RID_M].as<uint32_t>(), S[IDB_M].as<uint32_t>(), S[ELOC_M].as<uint32_t>(), head_m);
+                hipLaunchKernelGGL(k_chain_len, dim3(blocks_for((uint64_t)n_m + 1)), dim3(TPB), 0, stream, m_entry, head_m, n_m,
+                                   prev_e, has_pred, len_m, sc);
+                cub_cap = S[CUB].bytes;
+                HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, len_m, goff, (int)n_m + 1, stream));
+                hipLaunchKernelGGL(k_chain_write, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, m_entry, head_m, n_m, prev_e,
+                                   has_pred, m_idx, len_m, goff, members, g_begin, g_len);
+                hipLaunchKernelGGL(k_chain_rank, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, members, g_begin, g_len,
+                                   sub_eloc, n_m, key_b, val_b, sloc);
             }
         } else {
+            hipLaunchKernelGGL(k_id_hist, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_base, id_negmin, sc,
+                               dense, hist);
             cub_cap = S[CUB].bytes;
             HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, hist, id_off, (int)(id_space + 1), stream));
             hipLaunchKernelGGL(k_id_scatter, dim3(blocks_for(E)), dim3(TPB), 0, stream, dense, E, id_off, sc, hist,
