@@ -251,10 +251,19 @@ __global__ __launch_bounds__(TPB) void k_id_range(Raw in, const uint32_t *entry_
         }
         const uint32_t seg_end = (c + 1 < in.n_chr) ? min(e1, c_end) : e1;
         uint32_t hi = 0, neg = 0;
-        for (uint32_t e = cur + threadIdx.x; e < seg_end; e += TPB) {
-            const uint32_t id = in.read_ids[e];
-            hi = max(hi, id);
-            neg = max(neg, ~id);
+        // (eight loads of a thread in flight: one at a time, the kernel was 49 us of waiting on C3)
+        for (uint32_t e = cur + threadIdx.x; e < seg_end; e += TPB * 8) {
+            uint32_t id[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t eu = e + (uint32_t)u * TPB;
+                id[u] = eu < seg_end ? in.read_ids[eu] : in.read_ids[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                hi = max(hi, id[u]);
+                neg = max(neg, ~id[u]);
+            }
         }
         for (int off = 32; off > 0; off >>= 1) {
             hi = max(hi, (uint32_t)__shfl_down(hi, off));
@@ -413,8 +422,10 @@ __global__ __launch_bounds__(TPB) void k_flag_count(const uint8_t *multi, uint32
     }
 }
 // exclusive offsets of the blocks (one workgroup; 3000 blocks on C3), the number of M entries
-__global__ __launch_bounds__(TPB) void k_flag_scan(const uint32_t *block_sum, uint32_t n_blocks, uint32_t *block_off,
-                                                  uint32_t *m_idx_end, Scalars *sc) {
+constexpr int TPB_SCAN = 1024;
+__global__ __launch_bounds__(TPB_SCAN) void k_flag_scan(const uint32_t *block_sum, uint32_t n_blocks, uint32_t *block_off,
+                                                       uint32_t *m_idx_end, Scalars *sc) {
+    constexpr int TPB = TPB_SCAN;  // (this kernel's own)
     __shared__ uint32_t part[TPB / 64];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0u) carry = 0;
@@ -1772,7 +1783,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             m_entry = S[M_ENTRY].as<uint32_t>();
             uint32_t *block_sum = grouped, *block_off = grouped + n_flag_blocks + 1;  // (VAL_A: 2 words per 4096 entries)
             hipLaunchKernelGGL(k_flag_count, dim3(n_flag_blocks), dim3(TPB), 0, stream, multi, block_sum);
-            hipLaunchKernelGGL(k_flag_scan, dim3(1), dim3(TPB), 0, stream, block_sum, n_flag_blocks, block_off, m_idx + E,
+            hipLaunchKernelGGL(k_flag_scan, dim3(1), dim3(TPB_SCAN), 0, stream, block_sum, n_flag_blocks, block_off, m_idx + E,
                                sc);
             hipLaunchKernelGGL(k_compact_m, dim3(n_flag_blocks), dim3(TPB), 0, stream, raw, multi, block_off, m_idx, m_entry);
             // read-back 1b: how many entries take the general path (sizes every launch over them)
