@@ -1331,7 +1331,7 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
                           const uint32_t *t_read, const uint32_t *read_off, const uint32_t *read_locus,
                           const uint8_t *read_base, const uint32_t *krank, const uint8_t *kflags, const uint32_t *rbeg,
                           const uint32_t *flushed, const uint32_t *locus_chr, const uint32_t *locus_rel, uint32_t B,
-                          uint32_t lbits, uint4 *entry, uint32_t *entry32, uint32_t *col32, uint32_t *mask32,
+                          uint32_t lbits, uint4 *entry, uint32_t *entry32, uint32_t *mask32,
                           uint32_t *entry_read) {
     for (uint32_t d = blockIdx.x * TPB + threadIdx.x; d < n; d += gridDim.x * TPB) {
         const unsigned long long key = skey2[d];
@@ -1383,7 +1383,6 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
         }
         entry32[d] = cib | (base << kC_BaseShift) | (tail ? kC_Tail : 0u) | (multi ? kC_Multi : 0u)
                 | (wide ? kC_Wide : 0u) | ((locus_rel[l] & 0xFFFFu) << 16);
-        col32[d] = col32_of(cib, base);
         if (mask32)  // staged by the clustered-loci tile variant only
             mask32[d] = (masks & 0xFFu) | (((masks >> 16) & 0xFFu) << 8) | ((bases & 0xFFu) << 16)
                     | (((bases >> 16) & 0xFFu) << 24);
@@ -1450,7 +1449,7 @@ struct RecordTables {  // by value: what a record needs beside the group's own e
     const uint4 *m_rec;  // per kept M entry (k_m_records)
     const uint32_t *locus_rel;
     uint4 *entry;
-    uint32_t *entry32, *col32, *mask32, *entry_read;
+    uint32_t *entry32, *mask32, *entry_read;
 };
 
 // rec: the M entry's m_rec word group, loaded by the caller (all zero for an S entry)
@@ -1477,7 +1476,6 @@ __device__ __forceinline__ void emit_record(const RecordTables &t, uint32_t d, u
         t.entry[d] = make_uint4(meta, masks, bases, l);
         t.entry_read[d] = r;
     }
-    t.col32[d] = col32_of(cib, base);
     t.entry32[d] = cib | (base << kC_BaseShift) | (tail ? kC_Tail : 0u) | (multi ? kC_Multi : 0u)
             | (wide ? kC_Wide : 0u) | (lrel << 16);
     if (t.mask32)
@@ -1868,7 +1866,6 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     HIP_OK(pk.range_off.ensure(((size_t)L + 2) * 4));
     HIP_OK(pk.entry.ensure((size_t)E * 16));
     HIP_OK(pk.entry32.ensure((size_t)E * 4));
-    HIP_OK(pk.col32.ensure((size_t)E * 4));
     HIP_OK(pk.mask32.ensure((size_t)E * 4));
     HIP_OK(pk.entry_read.ensure((size_t)E * 4));
     HIP_OK(pk.blk_off.ensure((n_off_max + 1) * 4));
@@ -2135,7 +2132,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             hipLaunchKernelGGL(k_records, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, raw, key2_b, val2_b, n_kept,
                                t_read, read_off, read_locus, read_base, krank, kflags, rbeg, flushed, locus_chr,
                                locus_rel, B, lbits, pk.entry.as<uint4>(), pk.entry32.as<uint32_t>(),
-                               pk.col32.as<uint32_t>(), pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr, pk.entry_read.as<uint32_t>());
+                               pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr, pk.entry_read.as<uint32_t>());
         }
     } else {
         // Counting path: the entries stay in k_bin_place's order and one pass, a thread per (block, locus)
@@ -2150,7 +2147,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             hipLaunchKernelGGL(k_locus_info, dim3(blocks_for(L)), dim3(TPB), 0, stream, raw, pk.range_off.as<uint32_t>(),
                                sc, dupflag, locus_chr, locus_rel);
             const RecordTables tables{m_rec, locus_rel, pk.entry.as<uint4>(), pk.entry32.as<uint32_t>(),
-                                      pk.col32.as<uint32_t>(), pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr,
+                                      pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr,
                                       pk.entry_read.as<uint32_t>()};
             const unsigned long long *grouped = key_b;
             hipLaunchKernelGGL(k_entry_records, dim3(std::min<uint32_t>(1u << 16, (n_kept + 4095) / 4096)), dim3(TPB_REC),
@@ -2223,7 +2220,7 @@ std::string pack_pileup_device(const DeviceFlatPileup &in, uint32_t num_cells, u
         if (poison_level() >= 2) {  // debugging aid: nothing may depend on what the buffers held
             if (hipStreamSynchronize(stream) != hipSuccess || (out->side && hipStreamSynchronize(out->side) != hipSuccess))
                 return "poison: synchronise failed";
-            DeviceArena *outputs[] = {&out->blk_off, &out->entry32, &out->col32, &out->mask32, &out->entry,
+            DeviceArena *outputs[] = {&out->blk_off, &out->entry32, &out->mask32, &out->entry,
                                       &out->entry_read, &out->range_off, &out->read_off, &out->read_locus, &out->read_base};
             for (DeviceArena *a : outputs)
                 if (a->p && hipMemset(a->p, 0xA5, a->bytes) != hipSuccess) return "poison: memset failed";

@@ -46,7 +46,7 @@ struct DeviceArena {
 
 // The packed pileup in HBM: the arrays of PackedPileup, device resident
 struct DevicePacked {
-    DeviceArena blk_off, entry32, col32, mask32, entry, entry_read, range_off, read_off, read_locus, read_base;
+    DeviceArena blk_off, entry32, mask32, entry, entry_read, range_off, read_off, read_locus, read_base;
     DeviceArena scratch[24];  // temporaries, kept between calls to avoid re-allocation
     uint32_t num_cells = 0, block_cells = 0, num_blocks = 0, num_loci = 0, num_ranges = 0;
     uint64_t num_entries = 0, num_reads = 0, pair_bound = 0, multi_entries = 0;

@@ -57,9 +57,10 @@ constexpr uint32_t kWindow = 16;
 //   bit 11    wide: the read reaches beyond the 8-locus windows of mask32 -> use the full Entry
 //   bits 16-31 locus - first locus of the entry's locus range
 constexpr uint32_t kC_BaseShift = 7;
-// col32: an entry as the column side of accumulate_counts stages it -- byte offset of the cell's column in a
+// col32: an entry as the column side of accumulate_counts stages it in LDS -- byte offset of the cell's column in a
 // tile row (cell in block * 4) in the low half, the base in the byte above: address and base test are one
-// sub-dword operand each
+// sub-dword operand each. (Made of entry32 when a range is staged; until round 3 the packing wrote a second copy
+// of every entry in this form.)
 constexpr uint32_t col32_of(uint32_t cell_in_block, uint32_t base) { return (cell_in_block << 2) | (base << 16); }
 constexpr uint32_t kC_Tail = 1u << 9;
 constexpr uint32_t kC_Multi = 1u << 10;
@@ -97,7 +98,6 @@ struct PackedPileup {
     // entry of block b at locus l, blk_off[b * (L+1) + L] the end of block b
     std::vector<uint32_t> blk_off;
     std::vector<uint32_t> entry32;     // compact form
-    std::vector<uint32_t> col32;       // column-side form (col32_of)
     std::vector<uint32_t> mask32;      // prev8 | next8 << 8 | next_b0 << 16 | next_b1 << 24
     std::vector<Entry> entry;          // full form (pairs of two multi reads beyond mask32)
     std::vector<uint32_t> entry_read;  // per entry: index of its live read (slow path only)

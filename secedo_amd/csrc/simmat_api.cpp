@@ -538,7 +538,6 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
         }
         HIP_TRY(arena_upload(pk.blk_off, hp_pk.blk_off));
         HIP_TRY(arena_upload(pk.entry32, hp_pk.entry32));
-        HIP_TRY(arena_upload(pk.col32, hp_pk.col32));
         HIP_TRY(arena_upload(pk.mask32, hp_pk.mask32));
         HIP_TRY(arena_upload(pk.entry, hp_pk.entry));
         HIP_TRY(arena_upload(pk.entry_read, hp_pk.entry_read));
@@ -772,7 +771,6 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
     a.blk_off = h->pk.blk_off.as<uint32_t>();
     a.stride = h->pk.num_loci + 1;
     a.entry32 = h->pk.entry32.as<uint32_t>();
-    a.col32 = h->pk.col32.as<uint32_t>();
     a.mask32 = h->pk.mask32.as<uint32_t>();
     a.entry = h->pk.entry.as<uint4>();
     a.range_off = h->pk.range_off.as<uint32_t>();

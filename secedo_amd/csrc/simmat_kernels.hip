@@ -744,7 +744,8 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
     constexpr int OPT = (CAPL + 1 + THREADS - 1) / THREADS;  // staged offsets per thread
     constexpr int RING = COUNTS_RING;
 
-    // LDS: [ tile | sJ CAPJ u32 (col32_of: column byte offset | base << 16) | sOff CAPL+2 u16 | per wave: ring ]
+    // LDS: [ tile | sJ CAPJ u32 (col32_of: column byte offset | base << 16, made of entry32 when a range is staged: a
+    // copy of the entries in that form cost the packing a 4-byte store per entry) | sOff CAPL+2 u16 | per wave: ring ]
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t *tile32 = reinterpret_cast<uint32_t *>(lds_raw);
     uint32_t *sJ = reinterpret_cast<uint32_t *>(lds_raw + TILE_BYTES);
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
         // offset tid * 4 is loop-invariant, k * THREADS * 4 goes in the scalar offset).
         if (n_staged) {
             const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<uint32_t *>(a.col32 + n_jb), 0, (int)((n_je - n_jb) * 4u), 0x00020000);
+                    const_cast<uint32_t *>(a.entry32 + n_jb), 0, (int)((n_je - n_jb) * 4u), 0x00020000);
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<uint32_t *>(offJ + n_la), 0, (int)((n_lb - n_la + 1u) * 4u), 0x00020000);
 #pragma unroll
@@ -967,7 +968,8 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
                 // entries and OPT * THREADS offsets, so every store is inside them, and nothing reads those slots)
                 static_assert(JPT * THREADS <= CAPJ && OPT * THREADS <= CAPL + 2, "unconditional staging stores");
 #pragma unroll
-                for (int k = 0; k < JPT; ++k) sJ[tid + k * THREADS] = pJ[k];
+                for (int k = 0; k < JPT; ++k)  // the column side's form of an entry: col32_of(cell in block, base)
+                    sJ[tid + k * THREADS] = ((pJ[k] & C_CELL) << 2) | ((pJ[k] << (16 - C_BASE_SHIFT)) & 0x30000u);
 #pragma unroll
                 for (int k = 0; k < OPT; ++k) sOff[tid + k * THREADS] = (uint16_t)(pO[k] - jb);
             }

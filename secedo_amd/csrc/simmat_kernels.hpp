@@ -46,7 +46,6 @@ struct AccumulateArgs {
     const uint32_t *blk_off;   // num_blocks * stride
     uint32_t stride;           // num_loci + 1
     const uint32_t *entry32;   // compact entries
-    const uint32_t *col32;     // the same entries as accumulate_counts stages its column side (col32_of)
     const uint32_t *mask32;    // 8-locus windows
     const uint4 *entry;        // full entries (Entry), for locus ranges too deep to stage
     const uint32_t *range_off; // num_ranges + 1 locus boundaries
