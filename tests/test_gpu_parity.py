@@ -752,4 +752,37 @@ def test_staging_buffers_are_handed_to_one_caller_at_a_time():
     assert L.secedo_simmat_staging_acquire(bigger, again) == 0
     C.memset(again[3], 0x5A, 64 << 20)  # the grown buffer is really there
     L.secedo_simmat_staging_release()
-    L.secedo_simmat_staging_release()  # releasing twice is harmless
+    L.secedo_simmat_staging_release()  # releasing twice is harmless@pytest.mark.gpu
+def test_a_read_id_with_thousands_of_entries():
+    """The single-entry fast path finds the reads of the repeated ids by walking the links between their entries, one
+    thread per read: an id with more entries than that suits (kChainLimit = 1024, pack_device.hip) voids the attempt
+    and the packing falls back to the radix sorts. One id present at 1600 consecutive loci among single-locus reads
+    (the reference keeps such a read alive while max_fragment_length covers it, similarity_matrix.cpp:376-403)."""
+    rng = np.random.default_rng(83)
+    n = 40
+    rows, rid, pos = [], 1, 5000
+    for l in range(1600):
+        pos += 1
+        ents = [(0, 3, l % 4 if l % 7 else (l + 1) % 4)]
+        for _ in range(int(rng.integers(20, 40))):
+            ents.append((rid, int(rng.integers(0, n)), int(rng.integers(0, 4)) if rng.random() < 0.2 else l % 4))
+            rid += 1
+        rows.append((pos, ents))
+    for k in range(4):  # far loci: everything above completes and is flushed
+        pos += 20000
+        rows.append((pos, [(rid + k, 1, 0)]))
+    p = from_rows([rows])
+    ref = ob.oracle_compute(p, n, 6000, None, 0.01, 0.5, 0.01, 2, "ADD_MIN")
+    u_ref, pairs_ref = ob.oracle_last_updates(), ob.oracle_last_read_pairs()
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        plan.set_packing("device")
+        plan.prepare(p, n, 6000, None, 2)
+        assert plan.used_device_packing
+        acc = plan.new_acc()
+        plan.accumulate(acc, 0.01, 0.5, 0.01)
+        got = plan.finalize(acc, "ADD_MIN").cpu().numpy()
+        assert plan.last_counts() == (u_ref, pairs_ref)
+    assert gu.normwise_err(got, ref) <= TOL
+
+
+
