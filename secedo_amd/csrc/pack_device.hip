@@ -381,28 +381,80 @@ __global__ void k_id_rank(Raw in, const uint32_t *dense, const uint32_t *id_off,
 
 // ---- stage 1 of the single-entry fast path: which ids repeat, and the reads of those that do ------------------
 // Only WHICH ids occur more than once is wanted of all entries; how often and where only of the few that do. So the
-// entries do not count their id, they swap themselves into its slot: whoever finds a predecessor there flags the
-// predecessor and itself (every entry of a repeated id ends up flagged whatever the order of arrival) and keeps the
-// predecessor as a link. The flags are a byte per entry IN PILEUP ORDER: numbering the M entries is a pass over
-// 13 MB (k_flag_count, k_flag_scan, k_compact_m) where a scan that gathers hist[dense[e]] took 155 us on C3; and the
-// links are the reads: the last holder of a slot walks back through its id's entries (k_chain_len / k_chain_write),
-// no offsets over the id space (104 us), no histogram of the repeated ids.
+// entries do not count their id and they need no atomic: every entry STORES its number in its id's slot (k_id_store:
+// one of the entries of an id wins, whichever), then every entry looks whether the slot holds its own number
+// (k_id_check): if not, its id occurs again -- it flags itself and the winner, so every entry of a repeated id ends up
+// flagged, and the winner stands for the read. Two passes of plain coalesced stores and loads (the ids of
+// neighbouring entries are neighbours) where one atomic per entry took 185-220 us on C3 (device-scope atomics are
+// executed at the memory side), and the 48 MB table needs no zeroing: a slot is read only by entries that wrote it.
+// The flags are a byte per entry IN PILEUP ORDER: numbering the M entries is a pass over 13 MB (k_flag_count,
+// k_flag_scan, k_compact_m) where a scan that gathers hist[dense[e]] took 155 us; the reads of the M entries are
+// the groups of equal winner (k_m_fields counts them per winner, a scan over the M entries, k_group_scatter,
+// k_group_rank): no offsets over the id space (104 us), no histogram of the repeated ids.
 constexpr uint32_t kFlagBlock = 4096;      // entries per workgroup of the numbering passes
-constexpr uint32_t kChainLimit = 1024;     // entries of one id beyond which the attempt is void (Scalars::regroup: radix sorts)
-__global__ void k_id_last(Raw in, const uint32_t *entry_locus, const uint32_t *id_base, const uint32_t *id_negmin,
-                          const Scalars *sc, uint32_t *dense, uint32_t *last, uint32_t *prev_e, uint8_t *multi,
-                          uint8_t *has_pred) {
+__global__ void k_id_store(Raw in, const uint32_t *entry_locus, const uint32_t *id_base, const uint32_t *id_negmin,
+                           const Scalars *sc, uint32_t *dense, uint32_t *last) {
     if (sc->id_exceeded) return;  // the table is too small: no flags, no M entries; the caller starts over
-    for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < in.n_entries; e += gridDim.x * TPB) {
-        const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, entry_locus[e]);
-        const uint32_t d = id_base[c] + (in.read_ids[e] - ~id_negmin[c]);
-        dense[e] = d;
-        const uint32_t prev = atomicExch(&last[d], e + 1u);
-        if (prev) {
-            multi[e] = 1;
-            has_pred[e] = 1;
-            prev_e[e] = prev - 1u;
-            multi[prev - 1u] = 1;
+    // the chromosome of an entry: a search over the chromosomes' first loci, then two per-chromosome words -- from LDS
+    // (from global memory the search was a chain of log2(C) dependent loads in front of every store: 156 us on C3)
+    constexpr uint32_t kChrLds = 1024;
+    __shared__ uint32_t s_first[kChrLds + 1], s_base[kChrLds], s_min[kChrLds];
+    const bool in_lds = in.n_chr <= kChrLds;
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i <= in.n_chr; i += TPB) s_first[i] = in.chr_locus_off[i];
+        for (uint32_t i = threadIdx.x; i < in.n_chr; i += TPB) {
+            s_base[i] = id_base[i];
+            s_min[i] = ~id_negmin[i];
+        }
+        __syncthreads();
+    }
+    constexpr int U = 4;  // entries of a thread in flight
+    const uint32_t n = in.n_entries, stride = gridDim.x * TPB;
+    for (uint32_t e0 = blockIdx.x * TPB + threadIdx.x; e0 < n; e0 += stride * U) {
+        uint32_t l[U], id[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t e = e0 + (uint32_t)u * stride;
+            l[u] = e < n ? entry_locus[e] : 0u;
+            id[u] = e < n ? in.read_ids[e] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t e = e0 + (uint32_t)u * stride;
+            if (e >= n) break;
+            uint32_t d;
+            if (in_lds) {
+                const uint32_t c = last_le<uint32_t>(s_first, in.n_chr + 1, l[u]);
+                d = s_base[c] + (id[u] - s_min[c]);
+            } else {
+                const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l[u]);
+                d = id_base[c] + (id[u] - ~id_negmin[c]);
+            }
+            dense[e] = d;
+            last[d] = e + 1u;
+        }
+    }
+}
+__global__ void k_id_check(uint32_t n, const Scalars *sc, const uint32_t *dense, const uint32_t *last, uint8_t *multi) {
+    if (sc->id_exceeded) return;
+    constexpr int U = 4;  // entries of a thread in flight
+    const uint32_t stride = gridDim.x * TPB;
+    for (uint32_t e0 = blockIdx.x * TPB + threadIdx.x; e0 < n; e0 += stride * U) {
+        uint32_t d[U], w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t e = e0 + (uint32_t)u * stride;
+            d[u] = e < n ? dense[e] : dense[e0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = last[d[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t e = e0 + (uint32_t)u * stride;
+            if (e < n && w[u] != e + 1u) {
+                multi[e] = 1;
+                multi[w[u] - 1u] = 1;
+            }
         }
     }
 }
@@ -502,64 +554,43 @@ __global__ __launch_bounds__(TPB) void k_compact_m(Raw in, const uint8_t *multi,
     }
 }
 __global__ void k_m_fields(Raw in, const uint32_t *eloc, const uint32_t *dense, const uint32_t *last,
-                           const uint32_t *m_entry, uint32_t n_m, uint32_t *rid_m, uint32_t *idb_m, uint32_t *eloc_m,
-                           uint32_t *head_m) {
+                           const uint32_t *m_idx, const uint32_t *m_entry, uint32_t n_m, uint32_t *rid_m,
+                           uint32_t *idb_m, uint32_t *eloc_m, uint32_t *winner_m, uint32_t *count_m) {
     for (uint32_t j = blockIdx.x * TPB + threadIdx.x; j < n_m; j += gridDim.x * TPB) {
         const uint32_t e = m_entry[j];
         rid_m[j] = in.read_ids[e];
         idb_m[j] = in.id_base(e);
         eloc_m[j] = eloc[e];
-        head_m[j] = last[dense[e]] == e + 1u ? 1u : 0u;
+        const uint32_t w = m_idx[last[dense[e]] - 1u];  // the M index of the entry that stands for this entry's id
+        winner_m[j] = w;
+        atomicAdd(&count_m[w], 1u);
     }
 }
-// the reads of the M entries from the links: the head of an id counts its entries ...
-__global__ void k_chain_len(const uint32_t *m_entry, const uint32_t *head_m, uint32_t n_m, const uint32_t *prev_e,
-                            const uint8_t *has_pred, uint32_t *len_m, Scalars *sc) {
-    for (uint32_t j = blockIdx.x * TPB + threadIdx.x; j <= n_m; j += gridDim.x * TPB) {
-        uint32_t n = 0;
-        if (j < n_m && head_m[j]) {
-            uint32_t e = m_entry[j];
-            n = 1;
-            while (has_pred[e]) {  // (to the end whatever the length: what follows needs every M entry in a read)
-                e = prev_e[e];
-                ++n;
-            }
-            if (n > kChainLimit) sc->regroup = 1;  // one thread per read does not suit such reads: the caller sorts
-        }
-        len_m[j] = n;
-    }
-}
-// ... and, its read's place known (the exclusive sums of the counts), lists them: members[] holds the M indices of
-// the read in the order of the walk, every member learns where its read starts and how long it is
-__global__ void k_chain_write(const uint32_t *m_entry, const uint32_t *head_m, uint32_t n_m, const uint32_t *prev_e,
-                              const uint8_t *has_pred, const uint32_t *m_idx, const uint32_t *len_m,
-                              const uint32_t *goff, uint32_t *members, uint32_t *g_begin, uint32_t *g_len) {
+// the entries of a read next to each other (goff: exclusive sums of the counts; the counts are taken down again)
+__global__ void k_group_scatter(const uint32_t *winner_m, uint32_t n_m, const uint32_t *goff, uint32_t *count_m,
+                                uint32_t *members, uint32_t *g_begin, uint32_t *g_len) {
     for (uint32_t j = blockIdx.x * TPB + threadIdx.x; j < n_m; j += gridDim.x * TPB) {
-        if (!head_m[j]) continue;
-        const uint32_t b = goff[j], n = len_m[j];
-        uint32_t e = m_entry[j], m = j;
-        for (uint32_t i = 0; i < n; ++i) {
-            members[b + i] = m;
-            g_begin[m] = b;
-            g_len[m] = n;
-            if (i + 1 < n) {
-                e = prev_e[e];
-                m = m_idx[e];
-            }
-        }
+        const uint32_t w = winner_m[j];
+        const uint32_t b = goff[w], n = goff[w + 1] - b;
+        members[b + atomicSub(&count_m[w], 1u) - 1u] = j;
+        g_begin[j] = b;
+        g_len[j] = n;
     }
 }
 // pileup order inside a read (the M indices grow with the pileup): a member's rank is the number of smaller members.
 // skey: the read's first position stands for its id (equal keys <=> same read is all the stages behind need).
-// (A read beyond kChainLimit keeps the order of the walk -- the attempt is void, but every position holds an entry.)
-__global__ void k_chain_rank(Raw sub, const uint32_t *members, const uint32_t *g_begin, const uint32_t *g_len,
+// (A read beyond kRankScanLimit keeps the order of the scatter and raises Scalars::regroup -- the attempt is void,
+// the caller sorts --, but every position holds an entry.)
+__global__ void k_group_rank(Raw sub, const uint32_t *members, const uint32_t *g_begin, const uint32_t *g_len,
                              const uint32_t *eloc_m, uint32_t n_m, unsigned long long *skey, uint32_t *sval,
-                             uint32_t *sloc) {
+                             uint32_t *sloc, Scalars *sc) {
     for (uint32_t p = blockIdx.x * TPB + threadIdx.x; p < n_m; p += gridDim.x * TPB) {
         const uint32_t m = members[p];
         const uint32_t b = g_begin[m], n = g_len[m];
         uint32_t rank = p - b;
-        if (n <= kChainLimit) {
+        if (n > kRankScanLimit) {
+            sc->regroup = 1;
+        } else {
             rank = 0;
             for (uint32_t q = b; q < b + n; ++q) rank += members[q] < m ? 1u : 0u;
         }
@@ -579,7 +610,7 @@ constexpr uint32_t kSingleBaseShift = 29;  // in the high word of entry_kc (bloc
 constexpr uint32_t kSingleTail = 4u;       // in the low word of a grouped S entry: kSingle | tail | base
 
 // ---- the single-entry fast path ---------------------------------------------------------------------
-// With sparse loci nine reads in ten have ONE entry (k_id_last says which), and for those the whole
+// With sparse loci nine reads in ten have ONE entry (k_id_check says which), and for those the whole
 // read assembly -- scatter, rank, duplicate rule, per-read lists, per-read info -- is the identity. Only the
 // entries of ids that occur more than once ("M entries") go through it, as a compacted pileup of their own
 // (the kernels below see a Raw whose entry arrays are the compacted copies); the others ("S entries") meet
@@ -1760,24 +1791,23 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     if (counting) {
         uint32_t *hist = work_a, *id_off = work_b, *grouped = val_a;
         uint32_t *dense = S[KEY_A].as<uint32_t>();  // the radix path's unsorted keys live here
-        HIP_OK(hipMemsetAsync(hist, 0, (id_space + 1) * 4, stream));
-        uint32_t *prev_e = work_b;  // (the offsets over the id space are the general path's)
-        uint8_t *has_pred = nullptr;
+        if (!split_singles) HIP_OK(hipMemsetAsync(hist, 0, (id_space + 1) * 4, stream));
         if (split_singles) {
-            // which ids repeat (k_id_last), the entries of those as a compacted pileup of their own
+            // which ids repeat (k_id_store, k_id_check), the entries of those as a compacted pileup of their own
             const size_t padded = ((size_t)E + kFlagBlock - 1) / kFlagBlock * kFlagBlock + 16;
             const uint32_t n_flag_blocks = (uint32_t)((padded - 16) / kFlagBlock);
             HIP_OK(S[M_IDX].ensure(((size_t)E + 2) * 4));
             m_idx = S[M_IDX].as<uint32_t>();
-            HIP_OK(S[MARK_M].ensure(std::max(((size_t)E + 2) * 4, 2 * padded)));
+            HIP_OK(S[MARK_M].ensure(std::max(((size_t)E + 2) * 4, padded)));
             uint8_t *multi = S[MARK_M].as<uint8_t>();  // (the marks of the M entries come later: k_dup_mark)
-            has_pred = multi + padded;
-            HIP_OK(hipMemsetAsync(multi, 0, 2 * padded, stream));
-            hipLaunchKernelGGL(k_id_last, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_base, id_negmin, sc,
-                               dense, hist, prev_e, multi, has_pred);
+            HIP_OK(hipMemsetAsync(multi, 0, padded, stream));
+            hipLaunchKernelGGL(k_id_store, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_base, id_negmin, sc,
+                               dense, hist);
+            hipLaunchKernelGGL(k_id_check, dim3(blocks_for(E)), dim3(TPB), 0, stream, E, sc, dense, hist, multi);
             for (int a : {M_ENTRY, RID_M, IDB_M, ELOC_M, ARANK_M}) HIP_OK(S[a].ensure((size_t)E * 4 + 16));
-            // (the reads of the M entries, at most half of all entries: len[n_m+1] | goff[n_m+1] | begin | len | members)
-            HIP_OK(S[DENSE_M].ensure(((size_t)5 * (E / 2 + 1) + 8) * 4));
+            // (the reads of the M entries, at most half of all entries:
+            // count[n_m+1] | goff[n_m+1] | winner | begin | len | members)
+            HIP_OK(S[DENSE_M].ensure(((size_t)6 * (E / 2 + 1) + 8) * 4));
             m_entry = S[M_ENTRY].as<uint32_t>();
             uint32_t *block_sum = grouped, *block_off = grouped + n_flag_blocks + 1;  // (VAL_A: 2 words per 4096 entries)
             hipLaunchKernelGGL(k_flag_count, dim3(n_flag_blocks), dim3(TPB), 0, stream, multi, block_sum);
@@ -1812,20 +1842,19 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             sub.n_entries = n_m;
             sub_eloc = S[ELOC_M].as<uint32_t>();
             if (n_m) {
-                // the reads of the M entries, from the links k_id_last left
-                uint32_t *len_m = S[DENSE_M].as<uint32_t>(), *goff = len_m + n_m + 1, *g_begin = goff + n_m + 1;
-                uint32_t *g_len = g_begin + n_m, *members = g_len + n_m;
-                uint32_t *head_m = S[ARANK_M].as<uint32_t>();  // (the M entries' ranks come later: k_arank_m)
-                hipLaunchKernelGGL(k_m_fields, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, raw, eloc, dense, hist, m_entry, n_m,
-                                   S[RID_M].as<uint32_t>(), S[IDB_M].as<uint32_t>(), S[ELOC_M].as<uint32_t>(), head_m);
-                hipLaunchKernelGGL(k_chain_len, dim3(blocks_for((uint64_t)n_m + 1)), dim3(TPB), 0, stream, m_entry, head_m, n_m,
-                                   prev_e, has_pred, len_m, sc);
+                // the reads of the M entries: the groups of equal winner
+                uint32_t *count_m = S[DENSE_M].as<uint32_t>(), *goff = count_m + n_m + 1, *winner_m = goff + n_m + 1;
+                uint32_t *g_begin = winner_m + n_m, *g_len = g_begin + n_m, *members = g_len + n_m;
+                HIP_OK(hipMemsetAsync(count_m, 0, ((size_t)n_m + 1) * 4, stream));
+                hipLaunchKernelGGL(k_m_fields, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, raw, eloc, dense, hist, m_idx, m_entry,
+                                   n_m, S[RID_M].as<uint32_t>(), S[IDB_M].as<uint32_t>(), S[ELOC_M].as<uint32_t>(), winner_m,
+                                   count_m);
                 cub_cap = S[CUB].bytes;
-                HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, len_m, goff, (int)n_m + 1, stream));
-                hipLaunchKernelGGL(k_chain_write, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, m_entry, head_m, n_m, prev_e,
-                                   has_pred, m_idx, len_m, goff, members, g_begin, g_len);
-                hipLaunchKernelGGL(k_chain_rank, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, members, g_begin, g_len,
-                                   sub_eloc, n_m, key_b, val_b, sloc);
+                HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, count_m, goff, (int)n_m + 1, stream));
+                hipLaunchKernelGGL(k_group_scatter, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, winner_m, n_m, goff, count_m,
+                                   members, g_begin, g_len);
+                hipLaunchKernelGGL(k_group_rank, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, members, g_begin, g_len,
+                                   sub_eloc, n_m, key_b, val_b, sloc, sc);
             }
         } else {
             hipLaunchKernelGGL(k_id_hist, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_base, id_negmin, sc,
