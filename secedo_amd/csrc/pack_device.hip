@@ -988,13 +988,20 @@ __device__ __forceinline__ uint32_t tile_locus(const uint32_t *s_off, uint32_t l
 
 __global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, uint32_t TL, unsigned long long *__restrict__ entry_kc,
                                                  const uint32_t *__restrict__ m_idx, uint32_t num_cells,
-                                                 uint32_t B_log2, uint32_t *__restrict__ blk_cnt, Scalars *sc) {
-    extern __shared__ uint32_t lds_hist[];  // nb * (TL + 1)
+                                                 uint32_t B_log2, uint32_t *__restrict__ blk_cnt, Scalars *sc,
+                                                 uint32_t g2p_lds) {
+    extern __shared__ uint32_t lds_hist[];  // nb * (TL + 1); then (g2p_lds) the group -> cell map as 16-bit words
     __shared__ uint32_t s_off[65];          // first entry of each of the tile's loci, and the end
     static_assert(TPB >= 65, "one thread per offset");
     const uint32_t L = in.n_loci, TLP = TL + 1u, TL_log2 = 31u - (uint32_t)__clz((int)TL);
     const uint32_t n_tiles = (L + TL - 1u) / TL;
     constexpr int U = 4;
+    // the group -> cell map from LDS (a workgroup then takes several tiles): the gather from global memory was 37
+    // of this pass' 170 us on C3
+    uint16_t *s_g2p = reinterpret_cast<uint16_t *>(lds_hist + nb * TLP);
+    if (g2p_lds) {
+        for (uint32_t i = threadIdx.x; i < in.n_groups; i += TPB) s_g2p[i] = (uint16_t)min(in.g2p[i], 0xFFFFu);
+    }
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint32_t l0 = tile * TL, n_l = min(TL, L - l0);
         for (uint32_t i = threadIdx.x; i < nb * TLP; i += TPB) lds_hist[i] = 0;
@@ -1020,7 +1027,7 @@ __global__ __launch_bounds__(TPB) void k_bin_hist(Raw in, uint32_t nb, uint32_t 
                     cell[u] = 0;
                     if (m1[u] == m0[u]) {
                         if (group >= in.n_groups) sc->error = 1;
-                        else cell[u] = in.g2p[group];
+                        else cell[u] = g2p_lds ? (uint32_t)s_g2p[group] : in.g2p[group];
                     }
                 }
 #pragma unroll
@@ -2101,9 +2108,15 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     size_t lds = 0;
     if (!force_radix) bin_tiles(nb, &TL, &locus_grid, &lds);
     const bool hist_first = split_singles && !force_radix;  // the S entries are counted before the M entries join
-    if (hist_first)
-        hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, TL, entry_kc, m_idx, num_cells,
-                           B_log2, blk_cnt, sc);
+    if (hist_first) {
+        // (the group -> cell map rides in LDS if it fits beside the tile: 2 bytes per group)
+        static const bool g2p_allowed = [] { const char *e = std::getenv("SECEDO_PACK_G2P_LDS"); return !(e && std::atoi(e) == 0); }();
+        const size_t g2p_bytes = ((size_t)in.n_groups * 2 + 15) / 16 * 16;
+        const bool g2p_lds = g2p_allowed && num_cells <= 0xFFFFu && lds + g2p_bytes <= 49152;
+        hipLaunchKernelGGL(k_bin_hist, dim3(g2p_lds ? std::min<uint32_t>(locus_grid, 1024) : locus_grid), dim3(TPB),
+                           lds + (g2p_lds ? g2p_bytes : 0), stream, raw, nb, TL, entry_kc, m_idx, num_cells, B_log2, blk_cnt,
+                           sc, g2p_lds ? 1u : 0u);
+    }
     if (n_m)
         hipLaunchKernelGGL(k_keys2, dim3(blocks_for(n_m)), dim3(TPB), 0, stream, sub, sval, incl, read_locus, run_rank,
                            read_off, num_cells, B, lbits, force_radix ? key2_a : nullptr, force_radix ? val2_a : nullptr,
@@ -2126,7 +2139,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     } else {
         if (!hist_first)
             hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, TL, entry_kc, nullptr, num_cells,
-                               B_log2, blk_cnt, sc);
+                               B_log2, blk_cnt, sc, 0u);
         trace.mark("k_bin_hist launched");
         cub_cap = S[CUB].bytes;
         HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
