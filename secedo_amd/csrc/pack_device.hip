@@ -329,13 +329,44 @@ __global__ void k_sorted_locus(Raw in, const uint32_t *sval, const uint32_t *ent
         sloc[s] = sloc_pack(entry_locus[sval[s]], in.id_base(sval[s]));
 }
 
+// The dense id of an entry: its chromosome (a search over the chromosomes' first loci), then two per-chromosome words.
+// From LDS when the tables fit: from global memory the search is a chain of log2(C) dependent loads in front of
+// whatever the kernel does with the id (k_id_store: 156 -> 117 us on C3).
+constexpr uint32_t kChrLds = 1024;
+struct ChrTables {
+    uint32_t first[kChrLds + 1], base[kChrLds], min_id[kChrLds];
+};
+__device__ __forceinline__ bool chr_tables_load(const Raw &in, const uint32_t *id_base, const uint32_t *id_negmin,
+                                                ChrTables &t) {  // (all threads; ends with a barrier)
+    const bool in_lds = in.n_chr <= kChrLds;
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i <= in.n_chr; i += blockDim.x) t.first[i] = in.chr_locus_off[i];
+        for (uint32_t i = threadIdx.x; i < in.n_chr; i += blockDim.x) {
+            t.base[i] = id_base[i];
+            t.min_id[i] = ~id_negmin[i];
+        }
+    }
+    __syncthreads();
+    return in_lds;
+}
+__device__ __forceinline__ uint32_t dense_id(const Raw &in, const uint32_t *id_base, const uint32_t *id_negmin,
+                                             const ChrTables &t, bool in_lds, uint32_t locus, uint32_t id) {
+    if (in_lds) {
+        const uint32_t c = last_le<uint32_t>(t.first, in.n_chr + 1, locus);
+        return t.base[c] + (id - t.min_id[c]);
+    }
+    const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, locus);
+    return id_base[c] + (id - ~id_negmin[c]);
+}
+
 // counting path, entries by (chromosome, read id) through the dense numbering
 __global__ void k_id_hist(Raw in, const uint32_t *entry_locus, const uint32_t *id_base, const uint32_t *id_negmin,
                           const Scalars *sc, uint32_t *dense, uint32_t *hist) {
     if (sc->id_exceeded) return;  // the table is too small: the caller starts over (k_id_rank)
+    __shared__ ChrTables tables;
+    const bool in_lds = chr_tables_load(in, id_base, id_negmin, tables);
     for (uint32_t e = blockIdx.x * TPB + threadIdx.x; e < in.n_entries; e += gridDim.x * TPB) {
-        const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, entry_locus[e]);
-        const uint32_t d = id_base[c] + (in.read_ids[e] - ~id_negmin[c]);
+        const uint32_t d = dense_id(in, id_base, id_negmin, tables, in_lds, entry_locus[e], in.read_ids[e]);
         dense[e] = d;
         atomicAdd(&hist[d], 1u);
     }
@@ -395,19 +426,8 @@ constexpr uint32_t kFlagBlock = 4096;      // entries per workgroup of the numbe
 __global__ void k_id_store(Raw in, const uint32_t *entry_locus, const uint32_t *id_base, const uint32_t *id_negmin,
                            const Scalars *sc, uint32_t *dense, uint32_t *last) {
     if (sc->id_exceeded) return;  // the table is too small: no flags, no M entries; the caller starts over
-    // the chromosome of an entry: a search over the chromosomes' first loci, then two per-chromosome words -- from LDS
-    // (from global memory the search was a chain of log2(C) dependent loads in front of every store: 156 us on C3)
-    constexpr uint32_t kChrLds = 1024;
-    __shared__ uint32_t s_first[kChrLds + 1], s_base[kChrLds], s_min[kChrLds];
-    const bool in_lds = in.n_chr <= kChrLds;
-    if (in_lds) {
-        for (uint32_t i = threadIdx.x; i <= in.n_chr; i += TPB) s_first[i] = in.chr_locus_off[i];
-        for (uint32_t i = threadIdx.x; i < in.n_chr; i += TPB) {
-            s_base[i] = id_base[i];
-            s_min[i] = ~id_negmin[i];
-        }
-        __syncthreads();
-    }
+    __shared__ ChrTables tables;
+    const bool in_lds = chr_tables_load(in, id_base, id_negmin, tables);
     constexpr int U = 4;  // entries of a thread in flight
     const uint32_t n = in.n_entries, stride = gridDim.x * TPB;
     for (uint32_t e0 = blockIdx.x * TPB + threadIdx.x; e0 < n; e0 += stride * U) {
@@ -422,14 +442,7 @@ __global__ void k_id_store(Raw in, const uint32_t *entry_locus, const uint32_t *
         for (int u = 0; u < U; ++u) {
             const uint32_t e = e0 + (uint32_t)u * stride;
             if (e >= n) break;
-            uint32_t d;
-            if (in_lds) {
-                const uint32_t c = last_le<uint32_t>(s_first, in.n_chr + 1, l[u]);
-                d = s_base[c] + (id[u] - s_min[c]);
-            } else {
-                const uint32_t c = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l[u]);
-                d = id_base[c] + (id[u] - ~id_negmin[c]);
-            }
+            const uint32_t d = dense_id(in, id_base, id_negmin, tables, in_lds, l[u], id[u]);
             dense[e] = d;
             last[d] = e + 1u;
         }
