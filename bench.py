@@ -46,6 +46,65 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PROFILE_ROUND = "r03"   # profiles/<round>_*.json: the counter-derived inputs of the roofline record
 
 
+def _pmc_pass(counters, program, out_dir, timeout):
+    """One rocprofv3 --pmc pass (counters only, the program directly behind `--`) in a child process; returns
+    {kernel name: {counter: per-dispatch average}} from every counter_collection.csv the pass left."""
+    import csv
+    import glob
+    env = dict(os.environ, SECEDO_BENCH_NO_CHILD="1", TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out_dir, "--"] + list(program)
+    subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+    acc = {}
+    for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                acc.setdefault(row["Kernel_Name"], {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+
+
+def live_counters(args, kernel_needle, kernel_ms):
+    """HBM bytes per launch and the SQ / LDS counters of the dominant kernel, measured in THIS run: rocprofv3 --pmc passes
+    over a short child run of this same script (separate passes, counters only -- the HBM recipe of MI355X_MICROARCH.md:
+    FETCH_SIZE and WRITE_SIZE each on its own, both calibrated on a known 1 GiB stream in the same run). Returns
+    (traffic record, counters record) in the shape of profiles/<round>_traffic.json / _counters.json, or (None, None)
+    when no profiler is at hand (the caller falls back to the committed files and says so)."""
+    import shutil
+    import tempfile
+    calib = os.path.join(ROOT, "tools", "fetch_calib.bin")
+    if os.environ.get("SECEDO_BENCH_NO_CHILD") or not shutil.which("rocprofv3") or not os.path.exists(calib):
+        return None, None
+    child = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "3", "--warmup", "1",
+             "--repeats", "1", "--no-cpu-baseline"] + (["--clustered"] if args.clustered else [])
+    tmp = tempfile.mkdtemp(prefix="secedo_pmc_", dir="/tmp")
+    try:
+        GIB_KIB = float(1 << 20)
+        pick = lambda table, needle: next(v for k, v in table.items() if needle in k)
+        cal_f = _pmc_pass(["FETCH_SIZE"], [calib], os.path.join(tmp, "cf"), 120)
+        cal_w = _pmc_pass(["WRITE_SIZE"], [calib], os.path.join(tmp, "cw"), 120)
+        f4 = pick(cal_f, "read4")["FETCH_SIZE"] / GIB_KIB
+        w16 = pick(cal_w, "write16")["WRITE_SIZE"] / GIB_KIB
+        fetch = pick(_pmc_pass(["FETCH_SIZE"], child, os.path.join(tmp, "f"), 600), kernel_needle)["FETCH_SIZE"]
+        write = pick(_pmc_pass(["WRITE_SIZE"], child, os.path.join(tmp, "w"), 600), kernel_needle)["WRITE_SIZE"]
+        traffic = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+                   "hbm_bytes_per_launch": (fetch / f4 + write / w16) * 1024.0,
+                   "calibration": {"FETCH_SIZE_per_true_KiB_read_4B_per_lane": f4,
+                                   "WRITE_SIZE_per_true_KiB_write_16B_per_lane": w16},
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this run, calibrated in this run"}
+        counters = {}
+        for group in (["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                       "SQ_INSTS_VALU", "SQ_INSTS_SALU"],
+                      ["SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS",
+                       "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_VALU"]):
+            counters.update(pick(_pmc_pass(group, child, os.path.join(tmp, "s" + group[0]), 600), kernel_needle))
+        counters["kernel_cycles"] = kernel_ms * 1e-3 * 2.4e9  # this run's HIP-event duration x the shader clock
+        counters["source"] = "rocprofv3 --pmc, two passes of this run"
+        return traffic, counters
+    except (OSError, subprocess.SubprocessError, StopIteration, KeyError, ValueError, ZeroDivisionError):
+        return None, None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def lds_atomic_peak():
     """Peak of the instruction the pair kernel is bound by -- random-address ds_add_u32 -- in 1e9 atomics/s for
     the whole chip: measured live by tools/lds_atomic_bench.bin (a child process, < 1 s; built by make) where it
@@ -136,6 +195,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--clustered", action="store_true", help="gap_max=300 variant (~2.8 loci/read)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="take roofline.traffic and the SQ counters from profiles/ instead of measuring them in this run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 "
                          "flow on a box with fewer GPUs than ranks)")
@@ -501,6 +562,12 @@ def main():
                 traffic_rec = rec
             else:
                 counters = rec
+        counters_live = False
+        if world == 1 and not args.no_cpu_baseline and not args.no_live_counters:
+            # (the full default command only: four child runs of about ten seconds each)
+            live_t, live_c = live_counters(args, plan.pair_kernel, pair_ms if pair_ms else kern_ms)
+            if live_t and live_c:
+                traffic_rec, counters, counters_live = live_t, live_c, True
         E, L, N = plan.num_entries, plan.num_loci, n_cells
         local_updates = best["local_updates"]
         # this rank's launch: its tiles of the whole pileup, or all tiles of its chromosomes
@@ -524,7 +591,8 @@ def main():
             "accumulate_phase_ms": kern_ms, "kernel_ms_last_timed_step": best["last_ms"],
             # HBM bytes of the dominant kernel per launch, and the fraction of the HBM peak they amount to
             "traffic": traffic_rec["hbm_bytes_per_launch"] if traffic_rec else None,
-            "traffic_source": ("profiles/%s_traffic.json (%s)" % (PROFILE_ROUND, traffic_rec.get("source", "rocprofv3 --pmc")))
+            "traffic_source": (traffic_rec.get("source") if counters_live else
+                               "profiles/%s_traffic.json (%s)" % (PROFILE_ROUND, traffic_rec.get("source", "rocprofv3 --pmc")))
             if traffic_rec else None,
             "hbm_frac_measured": (traffic_rec["hbm_bytes_per_launch"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS)
             if traffic_rec else None,
@@ -546,7 +614,8 @@ def main():
             if cyc and counters.get("SQ_LDS_IDX_ACTIVE"):
                 # share of the kernel's CU-cycles (256 CUs) in which a CU's LDS pipeline has an instruction in hand
                 roofline["lds_pipe_busy_frac"] = counters["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc)
-            roofline["counters_source"] = "profiles/%s_counters.json" % PROFILE_ROUND
+            roofline["counters_source"] = (counters.get("source") if counters_live
+                                           else "profiles/%s_counters.json" % PROFILE_ROUND)
         line = {
             "metric": "cell-pair x locus updates/sec (similarity matrix)",
             "value": updates * args.steps / elapsed,
