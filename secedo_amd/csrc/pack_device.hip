@@ -423,47 +423,62 @@ __global__ void k_id_rank(Raw in, const uint32_t *dense, const uint32_t *id_off,
 // the groups of equal winner (k_m_fields counts them per winner, a scan over the M entries, k_group_scatter,
 // k_group_rank): no offsets over the id space (104 us), no histogram of the repeated ids.
 constexpr uint32_t kFlagBlock = 4096;      // entries per workgroup of the numbering passes
+// (a thread takes four consecutive entries, 16 bytes per lane and stream; `vec`: the caller's read-id array is 16-byte
+// aligned -- the tables of this file are)
 __global__ void k_id_store(Raw in, const uint32_t *entry_locus, const uint32_t *id_base, const uint32_t *id_negmin,
-                           const Scalars *sc, uint32_t *dense, uint32_t *last) {
+                           const Scalars *sc, uint32_t *dense, uint32_t *last, int vec) {
     if (sc->id_exceeded) return;  // the table is too small: no flags, no M entries; the caller starts over
     __shared__ ChrTables tables;
     const bool in_lds = chr_tables_load(in, id_base, id_negmin, tables);
-    constexpr int U = 4;  // entries of a thread in flight
     const uint32_t n = in.n_entries, stride = gridDim.x * TPB;
-    for (uint32_t e0 = blockIdx.x * TPB + threadIdx.x; e0 < n; e0 += stride * U) {
-        uint32_t l[U], id[U];
+    for (uint32_t q = blockIdx.x * TPB + threadIdx.x; q < (n + 3u) / 4u; q += stride) {
+        const uint32_t e0 = q * 4u;
+        uint32_t l[4], id[4], d[4];
+        if (vec && e0 + 4u <= n) {
+            const uint4 lv = reinterpret_cast<const uint4 *>(entry_locus)[q];
+            const uint4 iv = reinterpret_cast<const uint4 *>(in.read_ids)[q];
+            l[0] = lv.x, l[1] = lv.y, l[2] = lv.z, l[3] = lv.w;
+            id[0] = iv.x, id[1] = iv.y, id[2] = iv.z, id[3] = iv.w;
+        } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t e = e0 + (uint32_t)u * stride;
-            l[u] = e < n ? entry_locus[e] : 0u;
-            id[u] = e < n ? in.read_ids[e] : 0u;
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t e = min(e0 + (uint32_t)u, n - 1u);
+                l[u] = entry_locus[e];
+                id[u] = in.read_ids[e];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t e = e0 + (uint32_t)u * stride;
-            if (e >= n) break;
-            const uint32_t d = dense_id(in, id_base, id_negmin, tables, in_lds, l[u], id[u]);
-            dense[e] = d;
-            last[d] = e + 1u;
+        for (int u = 0; u < 4; ++u) d[u] = dense_id(in, id_base, id_negmin, tables, in_lds, l[u], id[u]);
+        if (e0 + 4u <= n) {
+            reinterpret_cast<uint4 *>(dense)[q] = make_uint4(d[0], d[1], d[2], d[3]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) last[d[u]] = e0 + (uint32_t)u + 1u;
+        } else {
+            for (uint32_t u = 0; e0 + u < n; ++u) {
+                dense[e0 + u] = d[u];
+                last[d[u]] = e0 + u + 1u;
+            }
         }
     }
 }
 __global__ void k_id_check(uint32_t n, const Scalars *sc, const uint32_t *dense, const uint32_t *last, uint8_t *multi) {
     if (sc->id_exceeded) return;
-    constexpr int U = 4;  // entries of a thread in flight
     const uint32_t stride = gridDim.x * TPB;
-    for (uint32_t e0 = blockIdx.x * TPB + threadIdx.x; e0 < n; e0 += stride * U) {
-        uint32_t d[U], w[U];
+    for (uint32_t q = blockIdx.x * TPB + threadIdx.x; q < (n + 3u) / 4u; q += stride) {
+        const uint32_t e0 = q * 4u;
+        uint32_t d[4], w[4];
+        if (e0 + 4u <= n) {
+            const uint4 dv = reinterpret_cast<const uint4 *>(dense)[q];
+            d[0] = dv.x, d[1] = dv.y, d[2] = dv.z, d[3] = dv.w;
+        } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t e = e0 + (uint32_t)u * stride;
-            d[u] = e < n ? dense[e] : dense[e0];
+            for (int u = 0; u < 4; ++u) d[u] = dense[min(e0 + (uint32_t)u, n - 1u)];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) w[u] = last[d[u]];
+        for (int u = 0; u < 4; ++u) w[u] = last[d[u]];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t e = e0 + (uint32_t)u * stride;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t e = e0 + (uint32_t)u;
             if (e < n && w[u] != e + 1u) {
                 multi[e] = 1;
                 multi[w[u] - 1u] = 1;
@@ -1821,9 +1836,9 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             HIP_OK(S[MARK_M].ensure(std::max(((size_t)E + 2) * 4, padded)));
             uint8_t *multi = S[MARK_M].as<uint8_t>();  // (the marks of the M entries come later: k_dup_mark)
             HIP_OK(hipMemsetAsync(multi, 0, padded, stream));
-            hipLaunchKernelGGL(k_id_store, dim3(blocks_for(E)), dim3(TPB), 0, stream, raw, eloc, id_base, id_negmin, sc,
-                               dense, hist);
-            hipLaunchKernelGGL(k_id_check, dim3(blocks_for(E)), dim3(TPB), 0, stream, E, sc, dense, hist, multi);
+            hipLaunchKernelGGL(k_id_store, dim3(blocks_for((E + 3) / 4)), dim3(TPB), 0, stream, raw, eloc, id_base, id_negmin,
+                               sc, dense, hist, (reinterpret_cast<uintptr_t>(raw.read_ids) & 15u) == 0 ? 1 : 0);
+            hipLaunchKernelGGL(k_id_check, dim3(blocks_for((E + 3) / 4)), dim3(TPB), 0, stream, E, sc, dense, hist, multi);
             for (int a : {M_ENTRY, RID_M, IDB_M, ELOC_M, ARANK_M}) HIP_OK(S[a].ensure((size_t)E * 4 + 16));
             // (the reads of the M entries, at most half of all entries:
             // count[n_m+1] | goff[n_m+1] | winner | begin | len | members)
