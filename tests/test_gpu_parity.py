@@ -753,6 +753,28 @@ def test_staging_buffers_are_handed_to_one_caller_at_a_time():
     C.memset(again[3], 0x5A, 64 << 20)  # the grown buffer is really there
     L.secedo_simmat_staging_release()
     L.secedo_simmat_staging_release()  # releasing twice is harmless@pytest.mark.gpu
+def test_more_chromosomes_than_the_lds_tables_hold():
+    """The kernels that turn (chromosome, read id) into a dense id keep the per-chromosome tables in LDS up to 1024
+    chromosomes (kChrLds, pack_device.hip) and search global memory beyond: 1100 chromosomes of a few loci each, sparse
+    (single-entry fast path) and clustered (general path)."""
+    n = 50
+    for gap, cov, loci, mfl, T in ((2000, 30, 4, 1000, 2), (40, 6, 40, 150, 1)):
+        p = random_pileup(91 + gap, n, 1100, loci, cov, gap)
+        ref = ob.oracle_compute(p, n, mfl, None, 0.01, 0.5, 0.01, T, "ADD_MIN")
+        counts = (ob.oracle_last_updates(), ob.oracle_last_read_pairs())
+        assert counts[0] > 100000
+        with secedo_amd.SimilarityMatrixPlan(0) as plan:
+            plan.set_packing("device")
+            plan.prepare(p, n, mfl, None, T)
+            assert plan.used_device_packing
+            acc = plan.new_acc()
+            plan.accumulate(acc, 0.01, 0.5, 0.01)
+            got = plan.finalize(acc, "ADD_MIN").cpu().numpy()
+            assert plan.last_counts() == counts
+        assert gu.normwise_err(got, ref) <= TOL
+
+
+@pytest.mark.gpu
 def test_a_read_id_with_thousands_of_entries():
     """The single-entry fast path finds the reads of the repeated ids by walking the links between their entries, one
     thread per read: an id with more entries than that suits (kChainLimit = 1024, pack_device.hip) voids the attempt
