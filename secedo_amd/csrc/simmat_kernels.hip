@@ -1776,66 +1776,75 @@ __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
         const long long dg_b1 = __builtin_readcyclecounter();
         dg_loads += dg_b1 - dg_b0;
 #endif
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t p = base + (uint32_t)u * THREADS + tid;
-            const uint4 P = A1[u];
-            const uint32_t row1 = (P.x & 0xFFFFu) - I * B;
-            const bool multi1 = P.y != 0u || (P.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
-            for (uint32_t q = qa[u]; q < qb[u]; ++q) {
+        // One flagged column entry q against the flagged row entry p (P its record, Q the column entry's).
+        auto pair_pq = [&](const uint4 P, uint32_t p, const uint4 Q, uint32_t q) {
+            const uint32_t row1 = (P.x & 0xFFFFu) - I * B, row2 = (Q.x & 0xFFFFu) - J * B;
+            if (diag && row1 == row2) return;  // same cell (:215)
 #ifdef SECEDO_STAMPS
-                const long long dg_q0 = __builtin_readcyclecounter();
+            ++dg_tests;
 #endif
-                const uint4 Q = a.flag_rec[q];
-                const uint32_t row2 = (Q.x & 0xFFFFu) - J * B;
+            const bool multi1 = P.y != 0u || (P.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
+            const bool tails = (P.x & Q.x & (1u << 18)) != 0u;  // both never flushed: no pair at all
+            const bool multi2 = Q.y != 0u || (Q.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
+            if (!tails && !(multi1 && multi2)) return;
+            // (inside a diagonal tile either orientation is read back: the finalize kernels add both)
+            unsigned long long *cell = &corr[row1 * B + row2];
+            const bool same = (((P.x ^ Q.x) >> 16) & 3u) == 0u;
+            if (tails) {
+                atomicAdd(cell, (unsigned long long)(-(same ? d10 : d01)));
+                --upd_delta;
+                --pair_delta;
 #ifdef SECEDO_STAMPS
-                dg_sink += row2;
-                __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                dg_qwait += __builtin_readcyclecounter() - dg_q0;
+                ++dg_tail;
+#endif
+                return;
+            }
+            // (the order of the two entries does not matter to joint_counts)
+            const uint32_t jc = joint_counts(a.slow, a.flag_idx, P, Q, p, q);
+            const uint32_t xs = (jc >> 15) & 0xFFFFu, xd = jc & 0x7FFFu;
+            if ((jc & kJointOwned) == 0u) {
+                --pair_delta;  // counted at their first shared locus
+#ifdef SECEDO_STAMPS
+                ++dg_later;
+#endif
+                return;
+            }
+            if (xs + xd < 2u) return;  // this locus only: the plain term is the whole term
+            long long term;
+            if (xs < (uint32_t)SLUT_DIM && xd < (uint32_t)SLUT_DIM) {
+                term = scorr[xs * SLUT_DIM + xd];
+            } else {
+                const long long joint = (xs < (uint32_t)LUT_DIM && xd < (uint32_t)LUT_DIM)
+                        ? a.lut[xs * LUT_DIM + xd] : llr_fixed_device(a.slow, xs, xd);
+                term = joint - (long long)xs * d10 - (long long)xd * d01;
+            }
+            atomicAdd(cell, (unsigned long long)term);
+#ifdef SECEDO_STAMPS
+            ++dg_joint;
+#endif
+        };
+        // The column lists of TWO row entries advance together: a wave walks a list as long as its longest lane
+        // needs, one memory round trip per step, so six lists one after the other cost the sum of six maxima (48
+        // steps on C3 where the average list has 2.8 entries); in pairs it is three maxima of two, with two records
+        // in flight per lane. (All six together -- 24 more registers -- was measured no faster in round 2.)
+        static_assert(U % 2 == 0, "lists in pairs");
+#pragma unroll
+        for (int u = 0; u < U; u += 2) {
+            const uint32_t pA = base + (uint32_t)u * THREADS + tid, pB = pA + THREADS;
+            uint32_t qA = qa[u], qB = qa[u + 1];
+            const uint32_t eA = qb[u], eB = qb[u + 1];
+            while (qA < eA || qB < eB) {
+                const bool hA = qA < eA, hB = qB < eB;
+                uint4 QA = make_uint4(0, 0, 0, 0), QB = make_uint4(0, 0, 0, 0);
+                if (hA) QA = a.flag_rec[qA];
+                if (hB) QB = a.flag_rec[qB];
+#ifdef SECEDO_STAMPS
                 ++dg_qiter;
 #endif
-                if (diag && row1 == row2) continue;  // same cell (:215)
-#ifdef SECEDO_STAMPS
-                ++dg_tests;
-#endif
-                const bool tails = (P.x & Q.x & (1u << 18)) != 0u;  // both never flushed: no pair at all
-                const bool multi2 = Q.y != 0u || (Q.x & (META_PREV_OVF | META_NEXT_OVF)) != 0u;
-                if (!tails && !(multi1 && multi2)) continue;
-                // (inside a diagonal tile either orientation is read back: the finalize kernels add both)
-                unsigned long long *cell = &corr[row1 * B + row2];
-                const bool same = (((P.x ^ Q.x) >> 16) & 3u) == 0u;
-                if (tails) {
-                    atomicAdd(cell, (unsigned long long)(-(same ? d10 : d01)));
-                    --upd_delta;
-                    --pair_delta;
-#ifdef SECEDO_STAMPS
-                    ++dg_tail;
-#endif
-                    continue;
-                }
-                // (the order of the two entries does not matter to joint_counts)
-                const uint32_t jc = joint_counts(a.slow, a.flag_idx, P, Q, p, q);
-                const uint32_t xs = (jc >> 15) & 0xFFFFu, xd = jc & 0x7FFFu;
-                if ((jc & kJointOwned) == 0u) {
-                    --pair_delta;  // counted at their first shared locus
-#ifdef SECEDO_STAMPS
-                    ++dg_later;
-#endif
-                    continue;
-                }
-                if (xs + xd < 2u) continue;  // this locus only: the plain term is the whole term
-                long long term;
-                if (xs < (uint32_t)SLUT_DIM && xd < (uint32_t)SLUT_DIM) {
-                    term = scorr[xs * SLUT_DIM + xd];
-                } else {
-                    const long long joint = (xs < (uint32_t)LUT_DIM && xd < (uint32_t)LUT_DIM)
-                            ? a.lut[xs * LUT_DIM + xd] : llr_fixed_device(a.slow, xs, xd);
-                    term = joint - (long long)xs * d10 - (long long)xd * d01;
-                }
-                atomicAdd(cell, (unsigned long long)term);
-#ifdef SECEDO_STAMPS
-                ++dg_joint;
-#endif
+                if (hA) pair_pq(A1[u], pA, QA, qA);
+                if (hB) pair_pq(A1[u + 1], pB, QB, qB);
+                qA += hA ? 1u : 0u;
+                qB += hB ? 1u : 0u;
             }
         }
     }
