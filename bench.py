@@ -79,12 +79,12 @@ def live_counters(args, kernel_needle, kernel_ms):
     try:
         GIB_KIB = float(1 << 20)
         pick = lambda table, needle: next(v for k, v in table.items() if needle in k)
-        cal_f = _pmc_pass(["FETCH_SIZE"], [calib], os.path.join(tmp, "cf"), 120)
-        cal_w = _pmc_pass(["WRITE_SIZE"], [calib], os.path.join(tmp, "cw"), 120)
+        cal_f = _pmc_pass(["FETCH_SIZE"], [calib], os.path.join(tmp, "cf"), 60)
+        cal_w = _pmc_pass(["WRITE_SIZE"], [calib], os.path.join(tmp, "cw"), 60)
         f4 = pick(cal_f, "read4")["FETCH_SIZE"] / GIB_KIB
         w16 = pick(cal_w, "write16")["WRITE_SIZE"] / GIB_KIB
-        fetch = pick(_pmc_pass(["FETCH_SIZE"], child, os.path.join(tmp, "f"), 600), kernel_needle)["FETCH_SIZE"]
-        write = pick(_pmc_pass(["WRITE_SIZE"], child, os.path.join(tmp, "w"), 600), kernel_needle)["WRITE_SIZE"]
+        fetch = pick(_pmc_pass(["FETCH_SIZE"], child, os.path.join(tmp, "f"), 180), kernel_needle)["FETCH_SIZE"]
+        write = pick(_pmc_pass(["WRITE_SIZE"], child, os.path.join(tmp, "w"), 180), kernel_needle)["WRITE_SIZE"]
         traffic = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
                    "hbm_bytes_per_launch": (fetch / f4 + write / w16) * 1024.0,
                    "calibration": {"FETCH_SIZE_per_true_KiB_read_4B_per_lane": f4,
@@ -95,7 +95,7 @@ def live_counters(args, kernel_needle, kernel_ms):
                        "SQ_INSTS_VALU", "SQ_INSTS_SALU"],
                       ["SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS",
                        "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_VALU"]):
-            counters.update(pick(_pmc_pass(group, child, os.path.join(tmp, "s" + group[0]), 600), kernel_needle))
+            counters.update(pick(_pmc_pass(group, child, os.path.join(tmp, "s" + group[0]), 180), kernel_needle))
         counters["kernel_cycles"] = kernel_ms * 1e-3 * 2.4e9  # this run's HIP-event duration x the shader clock
         counters["source"] = "rocprofv3 --pmc, two passes of this run"
         return traffic, counters
