@@ -61,7 +61,7 @@ for it in range(N):
         ref, raw = ob.oracle_compute(p, n, mfl, g2p, 0.01, 0.5, 0.02, T, norm, want_raw=True)
         counts_ref = (ob.oracle_last_updates(), ob.oracle_last_read_pairs())
         ob.set_direct_llr_sum(True)
-        _, raw_direct = ob.oracle_compute(p, n, mfl, g2p, 0.01, 0.5, 0.02, T, norm, want_raw=True)
+        ref_direct, raw_direct = ob.oracle_compute(p, n, mfl, g2p, 0.01, 0.5, 0.02, T, norm, want_raw=True)
     finally:
         ob.set_exact_binomials(False)
         ob.set_direct_llr_sum(False)
@@ -76,7 +76,13 @@ for it in range(N):
     tol_ref = TOL + 2.0 * cancel
     # (EXPONENTIATE maps an absolute error of the raw matrix to at most a quarter of it in a matrix whose maximum is
     # about 1/2: relative to the raw maximum that is a factor max|raw| / 2)
-    tol_norm = tol_ref * (max(1.0, float(np.max(np.abs(raw)))) if norm == "EXPONENTIATE" else 1.0)
+    exp_factor = max(1.0, float(np.max(np.abs(raw)))) if norm == "EXPONENTIATE" else 1.0
+    # (the normalised matrix: a division by the maximum, or an exponential, carries the reference's cancellation on in
+    # its own way -- SCALE_MAX_1 divides by an entry that has it too --, so its allowance is measured on the normalised
+    # matrices of the two oracle modes, not taken over from the raw ones)
+    finite = np.all(np.isfinite(ref)) and np.all(np.isfinite(ref_direct))
+    cancel_norm = gu.normwise_err(ref, ref_direct) if finite else cancel
+    tol_norm = (TOL + 2.0 * max(cancel, cancel_norm)) * exp_factor
     problems = []
     fixed_point = ""
     try:
@@ -104,6 +110,8 @@ for it in range(N):
         if np.all(np.isfinite(ref)) and not (norm == "EXPONENTIATE" and np.max(np.abs(raw)) > 30):
             if gu.normwise_err(got, ref) > tol_norm:
                 problems.append("normalised %.3g" % gu.normwise_err(got, ref))
+            if finite and gu.normwise_err(got, ref_direct) > TOL * exp_factor:
+                problems.append("normalised vs direct sums %.3g" % gu.normwise_err(got, ref_direct))
         if not np.array_equal(got, got.T, equal_nan=True):
             problems.append("not symmetric")
     except Exception as exc:  # noqa: BLE001
