@@ -1,9 +1,12 @@
 // pack_device.hip -- device-side packing of the raw flat pileup (see pack_device.hpp).
 //
 // Pipeline (every step a kernel or a hipCUB scan on `stream`; 3 scalar read-backs):
-//   1  entry -> locus; entries grouped by (chromosome, read id) in pileup order -- histogram over the
-//      dense id space, scan, scatter with an atomic cursor, rank inside the (short) group; the hipCUB
-//      radix sort when the ids are sparse or a group is too long for that
+//   1  entry -> locus; entries grouped by (chromosome, read id) in pileup order. Sparse loci (most reads have one
+//      entry): every entry stores its number in its id's slot and checks whether the slot still holds it -- the
+//      entries of repeated ids ("M entries") are flagged, numbered, compacted and grouped by the entry that won
+//      their slot; the others are their reads. Otherwise: histogram over the dense id space, scan, scatter with an
+//      atomic cursor, rank inside the (short) group; the hipCUB radix sort when the ids are sparse or a group is
+//      too long for that
 //   2  duplicate-position rule per (read, locus) group (reference: similarity_matrix.cpp:387-395);
 //      reads = runs of equal key, cut further where a flush erases a read that outlives
 //      max_fragment_length (:368-371, :379-382; k_split_update, iterated with step 4)
