@@ -1561,11 +1561,14 @@ __global__ __launch_bounds__(256) void wide_pairs(const WideArgs a) {
     for (int side = 0; side < (diag ? 1 : 2); ++side) {
         const uint32_t bw = side ? J : I, bo = side ? I : J;
         const uint32_t *off_o = a.blk_off + (size_t)bo * a.stride;
-        for (uint32_t k = a.wide_off[bw] + threadIdx.x; k < a.wide_off[bw + 1]; k += 256) {
+        // (a WAVE per wide entry, its lanes over the other block's entries of the locus: a thread per wide entry walked
+        // them one after the other, each with the slow path's chain of gathers behind it -- 91 us for the 22 wide
+        // entries per block of C2 clustered)
+        for (uint32_t k = a.wide_off[bw] + (threadIdx.x >> 6); k < a.wide_off[bw + 1]; k += 4) {
             const uint32_t ew = a.wide_list[k];
             const uint32_t rw = a.entry32[ew];
             const uint32_t l = a.entry[ew].w;  // (every wide entry is multi-locus: it has its 16-byte record)
-            for (uint32_t eo = off_o[l]; eo < off_o[l + 1]; ++eo) {
+            for (uint32_t eo = off_o[l] + (threadIdx.x & 63u); eo < off_o[l + 1]; eo += 64u) {
                 const uint32_t ro = a.entry32[eo];
                 if (ro & C_WIDE) {
                     if (side == 1) continue;          // wide x wide: side 0 has it
