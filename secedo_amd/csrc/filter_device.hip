@@ -42,6 +42,7 @@ struct FilterIn {
     const uint32_t *id_to_pos;
     uint32_t n_groups;
     uint32_t n_loci;
+    uint64_t n_entries;
     __device__ __forceinline__ uint32_t id_base(uint64_t e) const {
         return id_base16 ? (uint32_t)id_base16[e] : id_base32[e];
     }
@@ -53,28 +54,60 @@ __device__ __forceinline__ void sort4(uint32_t c[4]) {
 #undef CSWAP
 }
 
-// decision[l]: 0 drop, 1 keep, 2 unsure (host decides); in_count[l]: entries of the sub-cluster;
-// counts4[l]: the four base counts (for the host's second look)
-__global__ __launch_bounds__(TPB) void k_decide(FilterIn in, double theta, Thresholds th, uint32_t *decision,
-                                               uint32_t *in_count, uint4 *counts4, uint32_t *n_unsure) {
+// in_count[l]: entries of the sub-cluster; counts4[l]: the four base counts. One wave per locus.
+// (The verdict is k_verdict's, a THREAD per locus: taken here by lane 0 of the locus' wave, its dozen fp64 logarithms
+// and powers ran on one lane in 64 and were most of the 140 us this kernel took on C3.)
+__global__ __launch_bounds__(TPB) void k_decide(FilterIn in, uint32_t *in_count, uint4 *counts4) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
     for (uint32_t l = wave; l < in.n_loci; l += n_waves) {
         const uint64_t e0 = in.locus_entry_off[l], e1 = in.locus_entry_off[l + 1];
         uint32_t c[4] = {0, 0, 0, 0};
-        for (uint64_t e = e0 + lane; e < e1; e += 64) {
-            const uint32_t v = in.id_base(e);
-            const uint32_t g = v >> 2;
-            if (g < in.n_groups && in.id_to_pos[g] != kNoPos) c[v & 3u]++;
+        if (in.id_base16 && (reinterpret_cast<uintptr_t>(in.id_base16) & 7u) == 0u) {
+            // four 2-byte entries per lane and load: a wave takes 256 entries of the locus at a time (2 bytes per lane,
+            // 64 entries at a time, the kernel ran at 1.1 TB/s of its one input stream)
+            for (uint64_t a = e0 & ~3ull; a < e1; a += 256) {
+                const uint64_t e = a + (uint64_t)lane * 4u;
+                if (e >= e1) continue;
+                uint32_t v4[4];
+                if (e + 4u <= in.n_entries) {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(in.id_base16 + e);
+                    v4[0] = w.x & 0xFFFFu, v4[1] = w.x >> 16, v4[2] = w.y & 0xFFFFu, v4[3] = w.y >> 16;
+                } else {  // (the last entries of the pileup: nothing is read behind the array)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v4[u] = e + (uint64_t)u < in.n_entries ? in.id_base16[e + (uint64_t)u] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (e + (uint64_t)u < e0 || e + (uint64_t)u >= e1) continue;
+                    const uint32_t g = v4[u] >> 2;
+                    if (g < in.n_groups && in.id_to_pos[g] != kNoPos) c[v4[u] & 3u]++;
+                }
+            }
+        } else {
+            for (uint64_t e = e0 + lane; e < e1; e += 64) {
+                const uint32_t v = in.id_base(e);
+                const uint32_t g = v >> 2;
+                if (g < in.n_groups && in.id_to_pos[g] != kNoPos) c[v & 3u]++;
+            }
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             for (int off = 32; off > 0; off >>= 1) c[b] += __shfl_down(c[b], off);
         }
         if (lane != 0) continue;
-        const uint32_t coverage = c[0] + c[1] + c[2] + c[3];
-        in_count[l] = coverage;
+        in_count[l] = c[0] + c[1] + c[2] + c[3];
         counts4[l] = make_uint4(c[0], c[1], c[2], c[3]);
+    }
+}
+
+// decision[l]: 0 drop, 1 keep, 2 unsure (host decides)
+__global__ __launch_bounds__(TPB) void k_verdict(uint32_t n_loci, double theta, Thresholds th, const uint4 *counts4,
+                                                uint32_t *decision, uint32_t *n_unsure) {
+    for (uint32_t l = blockIdx.x * TPB + threadIdx.x; l < n_loci; l += gridDim.x * TPB) {
+        const uint4 c4 = counts4[l];
+        uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+        const uint32_t coverage = c[0] + c[1] + c[2] + c[3];
         uint32_t verdict = 0;
         if (coverage > 65535u) {
             verdict = UNSURE;  // the reference counts in uint16 and wraps: leave it to the host
@@ -190,7 +223,7 @@ std::string filter_device(const DeviceFlatPileup &in, double theta, uint32_t cel
         return std::string();
     }
     FilterIn fin{in.chr_locus_off, in.n_chr, in.locus_pos, in.locus_entry_off, in.read_ids, in.id_base16,
-                 in.id_base32, in.group_id_to_pos, in.n_groups, L};
+                 in.id_base32, in.group_id_to_pos, in.n_groups, L, in.n_entries};
     Thresholds th;
     for (int i = 0; i < 20; ++i) th.k[i] = kSignificanceThresholds[cell_proportion][i];
 
@@ -212,7 +245,8 @@ std::string filter_device(const DeviceFlatPileup &in, double theta, uint32_t cel
 
     HIP_OK(hipMemsetAsync(n_unsure, 0, 4, stream));
     const uint32_t wave_grid = static_cast<uint32_t>(std::min<uint64_t>(((uint64_t)L * 64 + TPB - 1) / TPB, 1u << 15));
-    hipLaunchKernelGGL(k_decide, dim3(wave_grid), dim3(TPB), 0, stream, fin, theta, th, decision, in_count, counts4, n_unsure);
+    hipLaunchKernelGGL(k_decide, dim3(wave_grid), dim3(TPB), 0, stream, fin, in_count, counts4);
+    hipLaunchKernelGGL(k_verdict, dim3(blocks_for(L)), dim3(TPB), 0, stream, L, theta, th, counts4, decision, n_unsure);
     // Ranks of the kept loci and entries. The verdicts are assumed final (a locus whose statistic touches
     // its threshold is rare): weights, scans and ONE read-back of {unsure, kept loci, kept entries}; only
     // if a locus was unsure is it decided on the host and the ranking redone.
