@@ -130,10 +130,11 @@ def reference_digest(workload, clustered, n_entries, rates, mfl, threads):
     """Sampled entries of the COMPILED REFERENCE's output for this workload (tests/golden/c?_reference_digest.npz,
     written by oracle/gen_golden.py from oracle/_ref in the build container), if the parameters are the digest's."""
     import numpy as np
-    if clustered or workload not in ("C2", "C3"):
+    if workload not in ("C2", "C3"):
         return None
+    name = "%s%s_reference_digest.npz" % (workload.lower(), "_clustered" if clustered else "")
     try:
-        z = np.load(os.path.join(ROOT, "tests", "golden", "%s_reference_digest.npz" % workload.lower()))
+        z = np.load(os.path.join(ROOT, "tests", "golden", name))
     except OSError:
         return None
     want = [mfl, rates[0], rates[1], rates[2], threads, 0]

@@ -157,12 +157,20 @@ uint64_t secedo_simmat_num_loci(const secedo_simmat_t *handle);
  * memory) and longest read after prepare(), the ranks sum the vectors and take the maximum (the exact bound
  * of the union) and the maximum of the read lengths, and every rank sets both before accumulate(), ranks with
  * an empty shard included. (0, 0) restores the handle's own; so does setting a pileup of other sizes or
- * arrays. set_pair_bound sets the first alone. scale_log2() is the scale of the last accumulate(). */
+ * arrays. set_pair_bound sets the first alone. scale_log2() is the scale of the last accumulate().
+ * ORDER: the bounds belong to the pileup the handle holds WHEN THEY ARE SET -- set them after set_pileup /
+ * prepare, never before (bounds set first are taken away by the set_pileup that follows), and set them again
+ * when the pileup is set from other arrays (a fresh copy of equal data counts as another pileup: the handle
+ * knows a pileup by its sizes and the address of its entry array). scale_bounds_state() tells which holds:
+ * 0 = no bounds set (the handle's own scale), 1 = bounds in force for the pileup held, 2 = bounds were set and a
+ * later pileup took them away -- a caller that adds accumulators across handles must not accumulate in state 2
+ * (secedo_amd.distributed.chromosome_sharded_accumulate refuses to). */
 uint64_t secedo_simmat_pair_bound(const secedo_simmat_t *handle);
 uint32_t secedo_simmat_max_read_entries(const secedo_simmat_t *handle);
 int secedo_simmat_cell_squares(secedo_simmat_t *handle, uint64_t *d_out /* num_cells, device */, void *stream);
 int secedo_simmat_set_scale_bounds(secedo_simmat_t *handle, uint64_t pair_bound, uint32_t max_read_entries);
 int secedo_simmat_set_pair_bound(secedo_simmat_t *handle, uint64_t pair_bound);
+int secedo_simmat_scale_bounds_state(const secedo_simmat_t *handle);
 int secedo_simmat_scale_log2(const secedo_simmat_t *handle);
 
 int secedo_simmat_zero_acc(secedo_simmat_t *handle, int64_t *d_acc, void *stream);

@@ -336,6 +336,49 @@ def c3_reference_run():
     print("c3_reference_digest: max %.6f sum %.6f  (reference took %.0f s)" % (np.max(np.abs(out)), np.sum(out), dt))
 
 
+def clustered_reference_runs(which=("C2", "C3")):
+    """SURVEY.md section 8d "also run each with gap_max=300": the clustered-loci variants of configs 2 and 3
+    (SYNTH-v1 seed 42, gap_max 300: about 2.8 loci per read, T = 8, ADD_MIN) through the compiled reference
+    ONCE each (C2 clustered: 5.4e8 updates, about a minute; C3 clustered: 2.5e10 updates, tens of minutes -- only
+    when named: `python oracle/gen_golden.py c2_clustered_reference_run` / `c3_clustered_reference_run`), kept
+    as digests like c3_reference_run(): sha256, maximum, sum, 128-row block sums and sampled entries (uniform,
+    inside diagonal 64- and 128-cell tiles, in the last cell block, in the first cell block)."""
+    import hashlib
+    import time
+    from secedo_amd.synth import CONFIGS, synth_config
+    for name in which:
+        n = CONFIGS[name][0]
+        p = synth_config(name, clustered=True)
+        t0 = time.time()
+        out = ob.ref_compute(p, n, 1000, None, 0.01, 0.5, 0.01, 8, "ADD_MIN")
+        dt = time.time() - t0
+        rng = np.random.default_rng(2026 + n)
+        k = 1000 if n <= 1000 else 3000
+        ii = [rng.integers(0, n, size=k)]
+        jj = [rng.integers(0, n, size=k)]
+        for edge in (64, 128):                                        # same cell block on both sides
+            blk = rng.integers(0, (n + edge - 1) // edge, size=500)
+            ii.append(np.minimum(blk * edge + rng.integers(0, edge, size=500), n - 1))
+            jj.append(np.minimum(blk * edge + rng.integers(0, edge, size=500), n - 1))
+        last0 = (n - 1) // 128 * 128                                  # a cell of the last block
+        ii.append(rng.integers(last0, n, size=500)); jj.append(rng.integers(0, n, size=500))
+        ii.append(rng.integers(0, n, size=500)); jj.append(rng.integers(0, 64, size=500))
+        ii = np.concatenate(ii); jj = np.concatenate(jj)
+        swap = rng.random(len(ii)) < 0.5
+        ii, jj = np.where(swap, jj, ii), np.where(swap, ii, jj)
+        row_block_sums = np.add.reduceat(out.sum(axis=1), np.arange(0, n, 128))
+        np.savez_compressed(os.path.join(GOLDEN, "%s_clustered_reference_digest.npz" % name.lower()),
+                            sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest(), dtype=np.uint8),
+                            max_abs=np.float64(np.max(np.abs(out))), total=np.float64(np.sum(out)),
+                            row_block_sums=row_block_sums,
+                            sample_i=ii.astype(np.uint32), sample_j=jj.astype(np.uint32), sample_v=out[ii, jj],
+                            n_entries=np.uint64(p.n_entries), n_loci=np.uint64(p.n_loci),
+                            reference_seconds=np.float64(dt),
+                            params=np.asarray([n, 1000, 0.01, 0.5, 0.01, 8, 0], dtype=np.float64))
+        print("%s_clustered_reference_digest: max %.6f sum %.6f  (reference took %.0f s)" % (
+            name.lower(), np.max(np.abs(out)), np.sum(out), dt), flush=True)
+
+
 def filter_cases():
     """Locus filter (Filter::filter / is_significant) vectors from the compiled reference."""
     rng = np.random.default_rng(7)
@@ -553,6 +596,10 @@ def main():
             fn()
     if "c3_reference_run" in only:   # five minutes of the reference: only when asked for by name
         c3_reference_run()
+    if "c2_clustered_reference_run" in only:
+        clustered_reference_runs(("C2",))
+    if "c3_clustered_reference_run" in only:   # tens of minutes of the reference
+        clustered_reference_runs(("C3",))
 
 
 if __name__ == "__main__":

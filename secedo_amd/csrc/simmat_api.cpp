@@ -120,6 +120,7 @@ struct secedo_simmat {
     uint64_t pair_bound_override = 0;
     uint32_t max_shared_override = 0;
     uint64_t pileup_identity = 0, override_identity = 0;
+    bool override_dropped = false;  // bounds were in force and another pileup took them away (scale_bounds_state 2)
     secedo::LlrModel model;
     secedo::LlrTable table;
     secedo::SlowPathArgs slow_host;
@@ -291,6 +292,7 @@ static void note_pileup(secedo_simmat *h, uint32_t n_chr, uint64_t n_loci, uint6
         id = (id ^ v) * 0x100000001b3ull;
     h->pileup_identity = id | 1ull;
     if (h->override_identity != h->pileup_identity) {
+        if (h->pair_bound_override || h->max_shared_override) h->override_dropped = true;
         h->pair_bound_override = 0;
         h->max_shared_override = 0;
         h->override_identity = 0;
@@ -609,7 +611,13 @@ int secedo_simmat_set_scale_bounds(secedo_simmat_t *h, uint64_t pair_bound, uint
     h->pair_bound_override = pair_bound;
     h->max_shared_override = max_read_entries;
     h->override_identity = (pair_bound || max_read_entries) ? h->pileup_identity : 0;
+    h->override_dropped = false;
     return SECEDO_OK;
+}
+int secedo_simmat_scale_bounds_state(const secedo_simmat_t *h) {
+    if (!h) return 0;
+    if ((h->pair_bound_override || h->max_shared_override) && h->override_identity == h->pileup_identity) return 1;
+    return h->override_dropped ? 2 : 0;
 }
 int secedo_simmat_set_pair_bound(secedo_simmat_t *h, uint64_t pair_bound) {
     return secedo_simmat_set_scale_bounds(h, pair_bound, h ? h->max_shared_override : 0);

@@ -1134,36 +1134,73 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
 // accumulate_tiles<MASKS> flattens a batch's pairs over the lanes and then walks, per pair, a chain of
 // dependent LDS reads (owner strip -> row record -> row mask -> column entry -> column mask -> table): one
 // pair per lane and trip, nothing in flight beside it. Here the row side lives in registers as in
-// accumulate_counts -- a thread keeps its JPT row entries of the range as items {entry bits, first column
-// entry, count} plus the entry's window mask --, a wave pairs 64 items with GROUP column entries each, the
-// column entry and its mask arrive in ONE 8-byte LDS read, issued for the next item before the current one
-// is paired, and the value comes out of ONE unconditional table read: with x_s / x_d counted over the
-// windows' shared loci plus this locus, D(1,0) and D(0,1) are table entries like the joint terms. Longer
-// items go through the wave's ring (item and mask), 32 or more column entries are paired by the whole wave.
-// A pair of two multi-locus reads is owned by its first shared locus (prev masks disjoint), as before;
-// reads whose window overflowed (C_WIDE) need the 16-byte records and the entry indices: pileups that have
-// any keep to accumulate_tiles (launch_accumulate).
+// accumulate_counts -- a thread keeps its JPT row entries of the range as items --, a wave pairs 64 items with
+// GROUP column entries each, the column entry arrives in ONE 8-byte LDS read, issued for the next item before
+// the current one is paired, and the value comes out of ONE unconditional table read. Longer items go through
+// the wave's ring, 32 or more column entries are paired by the whole wave.
+//
+// Round 4: the words a pair is decided from. Both sides are converted once (the column side on its way into
+// LDS, the row side when the items are built) into
+//   x = prev8 | tail << 8 | dead << 9 | base << 16 | (column: cell << 26; row: next8 << 24)
+//   y = the bases of the read at the 8 next loci as four one-hot planes of 8 bits (plane b, bit d: the read
+//       covers the locus d + 1 behind this one with base b; no bit where it does not cover it)
+// so that the loci two reads share behind this one are popc(S1 & y2) (S1 = the row read's next8 in all four
+// planes) and the ones with equal bases popc(y1 & y2): one AND and one population count each, where the two
+// bit planes of mask32 took an XOR, two shifts, an OR, two ANDs and two counts. The base at THIS locus is a
+// byte of its own in x (one byte compare), and x1 & x2 yields in one AND what ownership (prev8: an earlier
+// shared locus owns the pair) and the exclusions (both reads never flushed, :407-408; a column entry whose
+// read reaches beyond its windows: wide_pairs has its pairs, a row entry of that kind gets no item) need --
+// masks of single-locus reads are empty, so no "both multi-locus" test is left. The table is indexed by
+// (x_s, shared next loci). 47 -> 19 vector instructions per slot (C3 clustered 47.6 -> see DESIGN.md).
+// A pair of two multi-locus reads is owned by its first shared locus (prev masks disjoint), as before.
 // ------------------------------------------------------------------------------------------------
 constexpr int MASKS_RING = 128;
-constexpr uint32_t MK_J_SHIFT = 12, MK_J_MASK = 0xFFFu, MK_C_SHIFT = 24, MK_REC_MASK = 0xFFFu;
+constexpr uint32_t MASKS_ROW_Q(int B) { return (uint32_t)B + 1u; }
+constexpr uint32_t MK_J_MASK = 0xFFFu, MK_ROW_SHIFT = 12, MK_ROW_MASK = 0x7Fu, MK_C_SHIFT = 24;
+// x: [15:0] column: cell * 8 (the byte offset in a tile row), row: next8; [23:16] prev8; [24] tail; [26] dead;
+//    [31:28] the base at this locus, one-hot
+constexpr uint32_t MX_PREV = 0xFFu << 16, MX_TAIL = 1u << 24, MX_DEAD = 1u << 26, MX_BASE = 0xFu << 28;
+constexpr int MLUT_STRIDE = 11;  // table row = x_s (0 .. 9), column = shared next loci (0 .. 8)
+constexpr int MLUT_WORDS = 10 * MLUT_STRIDE;
+
+// mask32 -> the four one-hot base planes of the 8 next loci: next8, b0, b1 each spread over the four bytes, then
+// byte p keeps the loci whose (b0, b1) spell p
+__device__ __forceinline__ uint32_t masks_planes(uint32_t m) {
+    const uint32_t n4 = __builtin_amdgcn_perm(m, m, 0x01010101u);
+    const uint32_t b0 = __builtin_amdgcn_perm(m, m, 0x02020202u) ^ 0x00FF00FFu;
+    const uint32_t b1 = __builtin_amdgcn_perm(m, m, 0x03030303u) ^ 0x0000FFFFu;
+    return n4 & b0 & b1;
+}
+// entry32 / mask32 -> x without its low half: prev8, tail (bit 9 -> 24), wide (bit 11 -> 26), the base one-hot
+__device__ __forceinline__ uint32_t masks_flags(uint32_t e, uint32_t m) {
+    const uint32_t base = (e >> C_BASE_SHIFT) & 3u;
+    return ((m & 0xFFu) << 16) | ((e & (C_TAIL | C_WIDE)) << 15) | (0x10000000u << base);
+}
+static_assert((C_TAIL << 15) == MX_TAIL && (C_WIDE << 15) == MX_DEAD, "flag positions");
 
 template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
 __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs a) {
     static_assert(CAPJ <= 4096, "12 bits of column index in an item");
-    static_assert(GROUP >= 1 && GROUP <= 4, "group size");
-    constexpr size_t TILE_BYTES = (size_t)B * B * 8;
+        static_assert(GROUP >= 1 && GROUP <= 4, "group size");
+    // rows of the int64 tile are B + 1 words apart: lanes that share a locus hold the same column entry and
+    // different rows, and with a row stride of 512 bytes they all met in one pair of banks (52 % of the LDS
+    // cycles were conflict cycles on C3 clustered, 22 % since); the flush takes the skew out again
+    constexpr uint32_t ROW_Q = MASKS_ROW_Q(B);
+    constexpr size_t TILE_BYTES = (size_t)B * ROW_Q * 8;
     constexpr int WAVES = THREADS / 64;
     constexpr int JPT = (CAPJ + THREADS - 1) / THREADS;      // staged / held entries per thread
     constexpr int OPT = (CAPL + 1 + THREADS - 1) / THREADS;  // staged offsets per thread
     constexpr int RING = MASKS_RING;
 
-    // LDS: [ tile | sJ CAPJ x {entry bits, window mask} | sOff CAPL+2 u16 | sLut | per wave: ring of {item, mask} ]
+    // LDS: [ tile | sJ CAPJ x {x, y} | sOff CAPL+2 u16 | sLut | per wave: ring of {item, x1}, ring of y1 ]
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long *tile64 = reinterpret_cast<unsigned long long *>(lds_raw);
     uint2 *sJ = reinterpret_cast<uint2 *>(lds_raw + TILE_BYTES);
     uint16_t *sOff = reinterpret_cast<uint16_t *>(sJ + CAPJ);
     long long *sLut = reinterpret_cast<long long *>(sOff + CAPL + 2);
-    uint2 *ring = reinterpret_cast<uint2 *>(sLut + SLUT_DIM * SLUT_DIM) + (threadIdx.x >> 6) * RING;
+    uint2 *ring = reinterpret_cast<uint2 *>(sLut + MLUT_WORDS) + (threadIdx.x >> 6) * RING;
+    uint32_t *ring_y = reinterpret_cast<uint32_t *>(reinterpret_cast<uint2 *>(sLut + MLUT_WORDS) + WAVES * RING)
+            + (threadIdx.x >> 6) * RING;
 
     const uint32_t t_local = a.wg_tile[blockIdx.x];
     const uint32_t t = a.tile_ids ? a.tile_ids[t_local] : a.tile_begin + t_local;
@@ -1199,12 +1236,17 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
         row_begin = __builtin_amdgcn_readfirstlane(row_begin);
         row_end = __builtin_amdgcn_readfirstlane(row_end);
     }
-    for (uint32_t i = tid; i < B * B; i += THREADS) tile64[i] = 0ull;
-    for (uint32_t i = tid; i < SLUT_DIM * SLUT_DIM; i += THREADS) sLut[i] = a.lut[(i / SLUT_DIM) * LUT_DIM + (i % SLUT_DIM)];
+    for (uint32_t i = tid; i < B * ROW_Q; i += THREADS) tile64[i] = 0ull;
+    // the table by (x_s, shared next loci n): D(x_s, n + 1 - x_s); x_s > n + 1 cannot occur
+    for (uint32_t i = tid; i < (uint32_t)MLUT_WORDS; i += THREADS) {
+        const uint32_t xs = i / MLUT_STRIDE, n = i % MLUT_STRIDE;
+        sLut[i] = (n <= 8u && xs <= n + 1u) ? a.lut[xs * LUT_DIM + (n + 1u - xs)] : 0ll;
+    }
 
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.acc) + (size_t)t * B * B;
+    const bool slot_asm = a.masks_slot_asm != 0u;   // (SECEDO_MASKS_SLOT_ASM=0: the compiler's slot, for A/B runs)
     unsigned long long n_updates = 0, n_pairs = 0;  // per lane
-    uint32_t upd_lane = 0, skip_lane = 0;           // this lane's incidences / not-owned incidences in the range
+    uint32_t upd_lane = 0, add_lane = 0;            // this lane's incidences / owned incidences in the range
     uint32_t ring_head = 0, ring_tail = 0;          // wave-uniform, free-running
 
     // the next range, in flight in registers while the current one is paired
@@ -1270,80 +1312,172 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
         prefetch_rows();
     }
 
-    // GROUP (row entry, column entry) incidences per lane: `rec` / `m1` the row entry's bits and window mask,
-    // w2[u] = {column entry bits, its window mask}, a lane takes part in slot u iff c > u. Every condition is a
-    // bit test on plain words, combined without short circuits (as `a && b` the compiler had wrapped them in
-    // exec-masked regions, four exec switches per slot), and the counters are per lane (an add with the
-    // condition as carry instead of a scalar population count per slot). Phase 1 decides who pairs, who owns, and
-    // the table index; phase 2 reads the table (all GROUP reads in flight together); phase 3 adds.
-    const uint32_t off_diagonal = DIAG ? 0u : 1u;
-    auto pair_group = [&](uint32_t rec, uint32_t m1, const uint2 (&w2)[GROUP], uint32_t c) {
-        const uint32_t row = (rec & C_CELL) * (uint32_t)B;
-        uint32_t idx[GROUP], cell[GROUP];
+    // GROUP (row entry, column entry) incidences per lane: `item` = {first column entry, row cell, count}, x1 / y1
+    // the row entry's words, w2[u] = the column entry's, a lane takes part in slot u iff c > u. Every condition is
+    // a compare on plain words combined without short circuits (as `a && b` the compiler had wrapped them in
+    // exec-masked regions), and the counters are per lane (an add with the condition as carry). Phase 1 decides
+    // who pairs, who owns, and the table index; phase 2 reads the table (all GROUP reads in flight together);
+    // phase 3 adds.
+    auto pair_group = [&](auto diag_tag, uint32_t item, uint32_t x1, uint32_t y1, const uint2 (&w2)[GROUP], uint32_t c) {
+        constexpr bool DG = decltype(diag_tag)::value;  // a diagonal tile: equal cells do not pair (:215)
+        const uint32_t rcell = (item >> MK_ROW_SHIFT) & MK_ROW_MASK;
+        const uint32_t row_bytes = rcell * (ROW_Q * 8u);
+        const uint32_t s1 = __builtin_amdgcn_perm(x1, x1, 0u);  // the row read's next8 in all four planes
+        uint32_t lut_idx[GROUP], cell_off[GROUP];
         bool add[GROUP];
 #pragma unroll
         for (int u = 0; u < GROUP; ++u) {
-            const uint32_t w = w2[u].x, m2 = w2[u].y;
-            const uint32_t x = rec ^ w, both = rec & w;
-            // reads both never flushed do not pair (:407-408); a pair with a read that reaches beyond its windows
-            // is left to wide_pairs; in a diagonal tile equal cells do not pair (:215)
-            const uint32_t bad = (both & C_TAIL) | ((rec | w) & C_WIDE);
-            const uint32_t cells_differ = (x & C_CELL) | off_diagonal;
-            const bool act = (c > (uint32_t)u) & (bad == 0u) & (cells_differ != 0u);
+            const uint32_t wx = w2[u].x, wy = w2[u].y;
+            const uint32_t fz = x1 & wx;
+            // reads both never flushed do not pair (:407-408); a column entry whose read reaches beyond its windows
+            // is left to wide_pairs (row entries of that kind have no item)
+            bool act = (c > (uint32_t)u) & ((fz & (MX_TAIL | MX_DEAD)) == 0u);
+            if (DG) act &= (wx & 0xFFFFu) != rcell * 8u;
+            // two multi-locus reads: the pair belongs to their first shared locus; x_s over the loci they share
+            // behind this one plus this locus. (A single-locus read has empty masks: it shares this locus only.)
+            const bool addu = act & ((fz & MX_PREV) == 0u);
+            const uint32_t n = __popc(s1 & wy);
+            const uint32_t xs = __popc(y1 & wy) + __popc(fz & MX_BASE);
+            lut_idx[u] = xs * (uint32_t)MLUT_STRIDE + n;  // x_s <= n + 1 <= 9: inside the table
+            cell_off[u] = row_bytes + (wx & 0xFFFFu);
+            add[u] = addu;
             upd_lane += act ? 1u : 0u;
-            const uint32_t differ = (x >> C_BASE_SHIFT) & 3u ? 1u : 0u;
-            // two multi-locus reads: the pair belongs to their first shared locus; x_s / x_d over the shared loci
-            // of the two windows behind this one, plus this locus. Anything else shares this locus only.
-            const uint32_t joint = 0u - ((both >> 10) & 1u);  // C_MULTI on both: all ones
-            const uint32_t mm = m1 & m2 & joint;
-            const bool owner = (mm & 0xFFu) == 0u;
-            const uint32_t shared = (mm >> 8) & 0xFFu;
-            const uint32_t y = m1 ^ m2;
-            const uint32_t nd = __popc(((y >> 16) | (y >> 24)) & shared);
-            const uint32_t xd = nd + differ;
-            const uint32_t xs = __popc(shared) - nd + 1u - differ;
-            idx[u] = xs * SLUT_DIM + xd;  // x_s + x_d <= 9: inside the table, whatever an idle lane holds
-            cell[u] = row + (w & C_CELL);
-            add[u] = act & owner;
-            skip_lane += (act & !owner) ? 1u : 0u;
+            add_lane += addu ? 1u : 0u;
         }
         long long v[GROUP];
 #pragma unroll
-        for (int u = 0; u < GROUP; ++u) v[u] = sLut[idx[u]];
+        for (int u = 0; u < GROUP; ++u) v[u] = sLut[lut_idx[u]];
 #pragma unroll
         for (int u = 0; u < GROUP; ++u)
-            if (add[u]) atomicAdd(&tile64[cell[u]], (unsigned long long)v[u]);
+            if (add[u])
+                atomicAdd(reinterpret_cast<unsigned long long *>(lds_raw + cell_off[u]), (unsigned long long)v[u]);
+    };
+    // The same three slots of an off-diagonal tile (all but one in num_blocks) by hand: 15 vector instructions a
+    // slot where the compiler's code above has about 30 (it rebuilds lane masks from predicates for the per-lane
+    // counters and spends three instructions on each address). Phase 1, per slot: the three ANDs, the counts,
+    // x_s * 11 + n, the table read -- all three reads in flight; phase 2, per slot: who pairs (no tail / dead bit:
+    // the masked word below 1 << 24) and who owns (the masked word zero) as two compares of ONE masked word,
+    // the per-lane counters as adds with the condition as carry, the tile address as row + low half of the
+    // column word (SDWA), the add under exec = owners. lgkmcnt: LDS returns in order, so after the three reads
+    // "at most two outstanding" means the oldest read is back, and so on down the slots (each ds_add takes the
+    // place of the read just consumed); operations the compiler has in flight from before are older and only make
+    // the waits stricter; the compiler does not see this block's LDS operations (as in accumulate_counts).
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds_raw);
+    constexpr uint32_t LUT_OFF = (uint32_t)(TILE_BYTES + (size_t)CAPJ * 8 + ((size_t)CAPL + 2) * 2);
+    static_assert(LUT_OFF < 65536u, "the table's place as the offset field of ds_read");
+    auto pair_group3_asm = [&](uint32_t item, uint32_t x1, uint32_t y1, const uint2 (&w2)[GROUP], uint32_t c) {
+        const uint32_t rcell = (item >> MK_ROW_SHIFT) & MK_ROW_MASK;
+        const uint32_t row_addr = lds_base + rcell * (ROW_Q * 8u);
+        const uint32_t s1 = __builtin_amdgcn_perm(x1, x1, 0u);
+        const unsigned long long in0 = __ballot(c > 0u), in1 = __ballot(c > 1u), in2 = __ballot(c > 2u);
+        uint32_t a0, a1, a2, l0, l1, l2, t;
+        unsigned long long v0, v1, v2, sm, saved;
+#define MASKS_P1(A, L, V, WX, WY)                                        \
+        "v_and_b32 %[" A "], %[x1], %[" WX "]\n\t"                        \
+        "v_and_b32 %[t], %[y1], %[" WY "]\n\t"                            \
+        "v_and_b32 %[" L "], %[s1], %[" WY "]\n\t"                        \
+        "v_bcnt_u32_b32 %[t], %[t], 0\n\t"                                \
+        "v_bcnt_u32_b32 %[" L "], %[" L "], 0\n\t"                        \
+        "v_cmp_lt_u32_e32 vcc, 0x0fffffff, %[" A "]\n\t"                  \
+        "v_addc_co_u32_e64 %[t], vcc, 0, %[t], vcc\n\t"                   \
+        "v_mad_u32_u24 %[" L "], %[t], 11, %[" L "]\n\t"                  \
+        "v_lshl_add_u32 %[" L "], %[" L "], 3, %[ldsb]\n\t"               \
+        "ds_read_b64 %[" V "], %[" L "] offset:%[lutoff]\n\t"
+#define MASKS_P2(A, L, V, WX, IN)                                        \
+        "v_and_b32 %[t], 0x05ff0000, %[" A "]\n\t"                        \
+        "v_cmp_gt_u32_e32 vcc, 0x01000000, %[t]\n\t"                      \
+        "s_and_b64 %[sm], vcc, %[" IN "]\n\t"                             \
+        "v_addc_co_u32_e64 %[upd], vcc, 0, %[upd], %[sm]\n\t"             \
+        "v_cmp_eq_u32_e32 vcc, 0, %[t]\n\t"                               \
+        "s_and_b64 %[sm], vcc, %[" IN "]\n\t"                             \
+        "v_addc_co_u32_e64 %[adds], vcc, 0, %[adds], %[sm]\n\t"           \
+        "v_add_u32_sdwa %[" L "], %[row], %[" WX "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t" \
+        "s_waitcnt lgkmcnt(2)\n\t"                                        \
+        "s_and_saveexec_b64 %[saved], %[sm]\n\t"                          \
+        "ds_add_u64 %[" L "], %[" V "]\n\t"                               \
+        "s_mov_b64 exec, %[saved]\n\t"
+        asm volatile(MASKS_P1("a0", "l0", "v0", "wx0", "wy0") MASKS_P1("a1", "l1", "v1", "wx1", "wy1")
+                     MASKS_P1("a2", "l2", "v2", "wx2", "wy2")
+                     MASKS_P2("a0", "l0", "v0", "wx0", "in0") MASKS_P2("a1", "l1", "v1", "wx1", "in1")
+                     MASKS_P2("a2", "l2", "v2", "wx2", "in2")
+                     : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [l0] "=&v"(l0), [l1] "=&v"(l1), [l2] "=&v"(l2),
+                       [t] "=&v"(t), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [sm] "=&s"(sm), [saved] "=&s"(saved),
+                       [upd] "+v"(upd_lane), [adds] "+v"(add_lane)
+                     : [x1] "v"(x1), [y1] "v"(y1), [s1] "v"(s1), [row] "v"(row_addr), [ldsb] "s"(lds_base),
+                       [wx0] "v"(w2[0].x), [wy0] "v"(w2[0].y), [wx1] "v"(w2[1 % GROUP].x), [wy1] "v"(w2[1 % GROUP].y),
+                       [wx2] "v"(w2[2 % GROUP].x), [wy2] "v"(w2[2 % GROUP].y), [in0] "s"(in0), [in1] "s"(in1), [in2] "s"(in2),
+                       [lutoff] "n"(LUT_OFF)
+                     : "vcc", "memory");
+#undef MASKS_P1
+#undef MASKS_P2
     };
     auto group_load = [&](uint32_t item, uint2 (&w2)[GROUP]) {
-        const uint2 *p = sJ + ((item >> MK_J_SHIFT) & MK_J_MASK);
+        const uint2 *p = sJ + (item & MK_J_MASK);
         // (lanes with fewer than GROUP read on inside the staging area or the offsets behind it: idle in those slots)
 #pragma unroll
         for (int u = 0; u < GROUP; ++u) w2[u] = p[u];
     };
-    auto group_pair = [&](uint32_t item, uint32_t m1, const uint2 (&w2)[GROUP]) {
-        const uint32_t c = item >> MK_C_SHIFT;
-        const unsigned long long more = __ballot(c > (uint32_t)GROUP);
-        pair_group(item & MK_REC_MASK, m1, w2, c);
+    auto pair_dispatch = [&](uint32_t item, uint32_t x1, uint32_t y1, const uint2 (&w2)[GROUP], uint32_t c) {
+        if (DIAG) pair_group(std::true_type{}, item, x1, y1, w2, c);
+        else if (GROUP == 3 && slot_asm) pair_group3_asm(item, x1, y1, w2, c);
+        else pair_group(std::false_type{}, item, x1, y1, w2, c);
+    };
+    // `more`: the lanes whose item goes on, `adv` column entries further
+    auto ring_push = [&](unsigned long long more, uint32_t item, uint32_t x1, uint32_t y1, uint32_t adv) {
         if (more) {
             if (__builtin_amdgcn_inverse_ballot_w64(more)) {
-                const uint32_t slot = ring_tail + __builtin_amdgcn_mbcnt_hi(
-                        (uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
-                ring[slot & (RING - 1)] = make_uint2(item + ((uint32_t)GROUP << MK_J_SHIFT) - ((uint32_t)GROUP << MK_C_SHIFT), m1);
+                const uint32_t slot = (ring_tail + __builtin_amdgcn_mbcnt_hi(
+                        (uint32_t)(more >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u))) & (RING - 1);
+                ring[slot] = make_uint2(item + adv - (adv << MK_C_SHIFT), x1);
+                ring_y[slot] = y1;
             }
             ring_tail += (uint32_t)__popcll(more);
         }
     };
-    auto drain_one = [&]() {  // one batch from the ring (up to 64 items)
+    // An item of the primary batches takes TWO rounds of GROUP column entries in line before what is left of it
+    // goes to the ring (the second round's entries are requested before the first is paired): with 5.8 column
+    // entries per item on C3 clustered 80 % of the items went through the ring once and 35 % twice, and a trip
+    // through the ring costs about as many instructions as two slots.
+    auto group_pair = [&](uint32_t item, uint32_t x1, uint32_t y1, const uint2 (&w2)[GROUP]) {
+        const uint32_t c = item >> MK_C_SHIFT;
+        const unsigned long long more1 = __ballot(c > (uint32_t)GROUP);
+        uint2 wd[GROUP];
+        if (more1) group_load(item + (uint32_t)GROUP, wd);
+        pair_dispatch(item, x1, y1, w2, c);
+        if (more1) {
+            pair_dispatch(item, x1, y1, wd, c > (uint32_t)GROUP ? c - (uint32_t)GROUP : 0u);
+            ring_push(__ballot(c > 2u * GROUP), item, x1, y1, 2u * GROUP);
+        }
+    };
+    // One batch from the ring (up to 64 items). The ring must be empty before the next range is staged, and its
+    // last batches are thin -- 50 items, then the 20 of them that go on, then 8, 3, 1: as many passes again as the
+    // full ones, at a quarter of the lanes (C3 clustered: 44 % of the lane slots of a launch held a pair). A batch
+    // of 32 items or fewer is therefore spread over the wave: 2 / 4 / 8 / 16 lanes per item, lane `sub` of an
+    // item taking its column entries from sub * GROUP on -- one pass covers 2 ... 16 x GROUP entries of every
+    // item, and only what is beyond that goes round again (pushed by the item's lane 0).
+    auto drain_one = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t n = min(64u, ring_tail - ring_head);
+        const uint32_t k = n > 32u ? 0u : n > 16u ? 1u : n > 8u ? 2u : n > 4u ? 3u : 4u;  // log2(lanes per item)
+        const uint32_t idx = lane & ((64u >> k) - 1u), sub = lane >> (6u - k);
         uint2 it = make_uint2(0u, 0u);
-        if (lane < n) it = ring[(ring_head + lane) & (RING - 1)];
+        uint32_t y = 0u;
+        if (idx < n) {
+            it = ring[(ring_head + idx) & (RING - 1)];
+            y = ring_y[(ring_head + idx) & (RING - 1)];
+        }
         __builtin_amdgcn_wave_barrier();
         ring_head += n;
+        const uint32_t c0 = it.x >> MK_C_SHIFT, adj = sub * (uint32_t)GROUP;
+        const uint32_t cl = c0 > adj ? c0 - adj : 0u;
+        const uint32_t item_l = ((it.x & ~(0xFFu << MK_C_SHIFT)) + adj) | (cl << MK_C_SHIFT);
         uint2 w2[GROUP];
-        group_load(it.x, w2);
-        group_pair(it.x, it.y, w2);
+        group_load(item_l, w2);
+        const uint32_t adv = (uint32_t)GROUP << k;
+        const unsigned long long more = __ballot(sub == 0u && c0 > adv);
+        pair_dispatch(item_l, it.y, y, w2, cl);
+        ring_push(more, it.x, it.y, y, adv);
     };
 
     for (uint32_t r = r_begin; r < r_end; ++r) {
@@ -1353,16 +1487,18 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
         if (staged) {
             static_assert(JPT * THREADS <= CAPJ && OPT * THREADS <= CAPL + 2, "unconditional staging stores");
 #pragma unroll
-            for (int k = 0; k < JPT; ++k) sJ[tid + k * THREADS] = make_uint2(pJ[k] & 0xFFFFu, pMj[k]);
+            for (int k = 0; k < JPT; ++k)
+                sJ[tid + k * THREADS] = make_uint2(masks_flags(pJ[k], pMj[k]) | ((pJ[k] & C_CELL) << 3),
+                                                   masks_planes(pMj[k]));
 #pragma unroll
             for (int k = 0; k < OPT; ++k) sOff[tid + k * THREADS] = (uint16_t)(pO[k] - jb);
         }
         __syncthreads();
         const uint32_t nI = ie - ib;
         upd_lane = 0;
-        skip_lane = 0;
+        add_lane = 0;
         if (staged) {
-            uint32_t item[JPT], im[JPT];
+            uint32_t item[JPT], ix[JPT], iy[JPT];
             uint32_t any_wide = 0;
 #pragma unroll
             for (int k = 0; k < JPT; ++k) {
@@ -1372,28 +1508,32 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
                 uint32_t j0 = sOff[lrel];
                 const uint32_t j1 = sOff[lrel + 1];
                 if (DIAG) j0 = i + dsh + 1u;  // a diagonal tile: the entries after this one, each pair once
-                const uint32_t c = (i < nI && j1 > j0) ? j1 - j0 : 0u;
+                // (a row entry whose read reaches beyond its windows pairs in wide_pairs only)
+                const uint32_t c = (i < nI && j1 > j0 && (rec & C_WIDE) == 0u) ? j1 - j0 : 0u;
                 any_wide |= c;
-                item[k] = (rec & MK_REC_MASK) | ((j0 & MK_J_MASK) << MK_J_SHIFT) | (c << MK_C_SHIFT);
-                im[k] = pMi[k];
+                item[k] = (j0 & MK_J_MASK) | ((rec & C_CELL) << MK_ROW_SHIFT) | (c << MK_C_SHIFT);
+                ix[k] = masks_flags(rec, pMi[k]) | MX_DEAD | ((pMi[k] >> 8) & 0xFFu);
+                iy[k] = masks_planes(pMi[k]);
             }
-            // wide entries (32 column entries or more): the whole wave pairs one row entry with 64 at a time
+            // wide items (32 column entries or more): the whole wave pairs one row entry with 64 at a time
             if (__ballot(any_wide >= IT_WIDE)) {
 #pragma unroll
                 for (int k = 0; k < JPT; ++k) {
+                    // (the count again, in full: an item holds 8 bits of it)
                     const uint32_t i = tid + k * THREADS;
                     const uint32_t rec = pI[k];
                     const uint32_t lrel = rec >> 16;
                     uint32_t j0 = sOff[lrel];
                     const uint32_t j1 = sOff[lrel + 1];
                     if (DIAG) j0 = i + dsh + 1u;
-                    const uint32_t c = (i < nI && j1 > j0) ? j1 - j0 : 0u;
+                    const uint32_t c = (i < nI && j1 > j0 && (rec & C_WIDE) == 0u) ? j1 - j0 : 0u;
                     unsigned long long todo = __ballot(c >= IT_WIDE);
                     while (todo) {
                         const int src = __builtin_ctzll(todo);
                         todo &= todo - 1ull;
-                        const uint32_t recw = __builtin_amdgcn_readlane(rec, src) & MK_REC_MASK;
-                        const uint32_t m1w = __builtin_amdgcn_readlane(pMi[k], src);
+                        const uint32_t itw = __builtin_amdgcn_readlane(item[k], src);
+                        const uint32_t xw = __builtin_amdgcn_readlane(ix[k], src);
+                        const uint32_t yw = __builtin_amdgcn_readlane(iy[k], src);
                         const uint32_t cw = __builtin_amdgcn_readlane(c, src);
                         const uint32_t j0w = __builtin_amdgcn_readlane(j0, src);
                         for (uint32_t base = 0; base < cw; base += 64u) {
@@ -1401,7 +1541,9 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
                             w2[0] = sJ[min(j0w + base + lane, (uint32_t)CAPJ - 1u)];
 #pragma unroll
                             for (int u = 1; u < GROUP; ++u) w2[u] = w2[0];
-                            pair_group(recw, m1w, w2, base + lane < cw ? 1u : 0u);  // slot 0 only
+                            const uint32_t c1 = base + lane < cw ? 1u : 0u;  // slot 0 only
+                            if (DIAG) pair_group(std::true_type{}, itw, xw, yw, w2, c1);
+                            else pair_group(std::false_type{}, itw, xw, yw, w2, c1);
                         }
                     }
                     if (c >= IT_WIDE) item[k] = 0u;  // done
@@ -1415,7 +1557,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
                 for (int k = 0; k < JPT; ++k) {
                     if (k + 1 < JPT) group_load(item[k + 1], wn);
                     while (ring_tail - ring_head > (uint32_t)(RING - 64)) drain_one();  // room for 64 continuations
-                    group_pair(item[k], im[k], wc);
+                    group_pair(item[k], ix[k], iy[k], wc);
 #pragma unroll
                     for (int u = 0; u < GROUP; ++u) wc[u] = wn[u];
                 }
@@ -1459,15 +1601,14 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
             n_pairs += (unsigned long long)upd - skipped;
         }
         n_updates += upd_lane;
-        n_pairs += (unsigned long long)upd_lane - skip_lane;
+        n_pairs += add_lane;
     }
     __syncthreads();
 
     // flush: the tile goes to the workgroup's own slab with plain coalesced stores; reduce_slabs adds up
     {
-        uint4 *out = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned long long *>(a.slab) + (size_t)blockIdx.x * B * B);
-        const uint4 *src = reinterpret_cast<const uint4 *>(tile64);
-        for (uint32_t i = tid; i < B * B / 2; i += THREADS) out[i] = src[i];
+        unsigned long long *out = reinterpret_cast<unsigned long long *>(a.slab) + (size_t)blockIdx.x * B * B;
+        for (uint32_t i = tid; i < B * B; i += THREADS) out[i] = tile64[(i / B) * ROW_Q + (i % B)];  // dense rows
     }
     // work counters: wave reduction, then one atomic pair per workgroup (see accumulate_tiles)
     for (int off = 32; off > 0; off >>= 1) {
@@ -2130,8 +2271,8 @@ hipError_t launch_correct(const AccumulateArgs &args, hipStream_t stream, const 
 
 template <int B, int THREADS, int CAPJ, int CAPL, int GROUP>
 hipError_t launch_masks(const AccumulateArgs &args, uint32_t grid, hipStream_t stream) {
-    constexpr size_t lds = (size_t)B * B * 8 + (size_t)CAPJ * 8 + ((size_t)CAPL + 2) * 2 + SLUT_DIM * SLUT_DIM * 8
-            + (size_t)(THREADS / 64) * MASKS_RING * 8;
+    constexpr size_t lds = (size_t)B * MASKS_ROW_Q(B) * 8 + (size_t)CAPJ * 8 + ((size_t)CAPL + 2) * 2
+            + MLUT_WORDS * 8 + (size_t)(THREADS / 64) * MASKS_RING * 12;
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     static_assert((CAPL + 2) % 4 == 0 && CAPJ % 8 == 0, "alignment of the LDS carve-up");
     auto kern = &accumulate_masks<B, THREADS, CAPJ, CAPL, GROUP>;
@@ -2145,7 +2286,10 @@ hipError_t launch_masks(const AccumulateArgs &args, uint32_t grid, hipStream_t s
         if (e != hipSuccess) return e;
         configured_device = dev;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, args);
+    static const bool slot_asm = [] { const char *v = std::getenv("SECEDO_MASKS_SLOT_ASM"); return !(v && std::atoi(v) == 0); }();
+    AccumulateArgs with_flag = args;
+    with_flag.masks_slot_asm = slot_asm ? 1u : 0u;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, stream, with_flag);
     hipLaunchKernelGGL((reduce_slabs<B, false>), dim3(args.n_tiles * (B * B / 256)), dim3(256), 0, stream, args.slab,
                        args.tile_wg_begin, args.tile_begin, args.tile_ids, args.lut,
                        reinterpret_cast<long long *>(args.acc));

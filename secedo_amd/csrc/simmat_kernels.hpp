@@ -36,7 +36,7 @@ struct SlowPathArgs {
     const uint32_t *read_off;
     const uint32_t *read_locus;
     const uint8_t *read_base;
-    const long long *lut;      // 65 x 65, row = x_s
+    const long long *lut;      // 129 x 129 (LUT_DIM), row = x_s
     LlrModelDev model;
     int scale_log2;
 };
@@ -62,7 +62,7 @@ struct AccumulateArgs {
     const uint32_t *tile_wg_begin;  // n_tiles + 1: first workgroup of each tile (its chunks follow)
     uint32_t debug;            // ablation switches for profiling (0 in production)
     // log-likelihood ratios, fixed point
-    const long long *lut;      // 65 x 65, row = x_s
+    const long long *lut;      // 129 x 129 (LUT_DIM), row = x_s
     // outputs
     int64_t *acc;              // tile-major: [tile][B*B]
     void *slab;                // one B*B tile (u32 counts or int64) per workgroup of the launch
@@ -74,6 +74,7 @@ struct AccumulateArgs {
     int group_hint = 4;                     // GROUP of accumulate_counts by the entries per (cell block, locus)
     bool overwrite = false;                 // acc[tiles of the launch] = result (no need to zero them first)
     bool masks_kernel = false;              // staged masks: accumulate_masks (+ wide_pairs) instead of accumulate_tiles
+    uint32_t masks_slot_asm = 1;            // accumulate_masks: the hand-written pair slots (SECEDO_MASKS_SLOT_ASM=0: off)
     const uint32_t *wide_off = nullptr;     // num_blocks + 1: the C_WIDE entries per cell block ...
     const uint32_t *wide_list = nullptr;    // ... their entry indices (null: none)
     // counts path, one workgroup per tile (counts_split(n_tiles) == 1), all tiles in one launch: max(0, max D) of

@@ -22,6 +22,21 @@ from __future__ import annotations
 from typing import Tuple
 
 
+def _exchanges(world: int) -> bool:
+    """Whether the collectives are issued: always with more than one rank; with ONE rank only when a process
+    group exists and SECEDO_DIST_EXCHANGE_ALWAYS=1 -- a world-size-1 RCCL group on one GPU then runs every
+    collective branch of this module (in-place all-gather, side-stream chunks, all-reduces) as the N-rank job
+    does, so the one-GPU test box executes the RCCL code paths before an 8-GPU run does
+    (tests/test_gpu_distributed.py::test_rccl_world_size_1_runs_every_collective_branch)."""
+    if world > 1:
+        return True
+    import os
+    if os.environ.get("SECEDO_DIST_EXCHANGE_ALWAYS", "") not in ("", "0"):
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    return False
+
+
 def tiles_per_rank(num_tiles: int, world: int) -> int:
     return -(-num_tiles // world)
 
@@ -50,7 +65,7 @@ def sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate
     plan.accumulate(acc, mutation_rate, homozygous_rate, seq_error_rate, lo, hi, overwrite=True)
     if hi - lo < per:
         acc[hi * b2:(rank + 1) * per * b2].zero_()  # the padding tiles of the last ranks' slices
-    if world > 1:
+    if _exchanges(world):
         if acc.is_cuda and dist.get_backend(group) != "nccl":
             # rehearsal backends (gloo) move host memory: stage the slices through the CPU
             gathered = acc.new_empty(acc.shape, device="cpu")
@@ -81,7 +96,8 @@ def sharded_accumulate_overlapped(plan, acc, mutation_rate, homozygous_rate, seq
     n_mine = hi - lo
     chunks = max(1, min(chunks, per))
     step = -(-per // chunks)
-    direct = world > 1 and acc.is_cuda and dist.get_backend(group) == "nccl"
+    exchange = _exchanges(world)
+    direct = exchange and acc.is_cuda and dist.get_backend(group) == "nccl"
     main = torch.cuda.current_stream(acc.device) if acc.is_cuda else None
     if direct and comm_stream is None:
         comm_stream = torch.cuda.Stream(acc.device)
@@ -92,7 +108,7 @@ def sharded_accumulate_overlapped(plan, acc, mutation_rate, homozygous_rate, seq
             plan.accumulate(acc, mutation_rate, homozygous_rate, seq_error_rate, t_lo, t_hi, overwrite=True)
         if c_hi > n_mine:  # padding tiles of the last ranks' slices
             acc[(rank * per + max(c_lo, n_mine)) * b2:(rank * per + c_hi) * b2].zero_()
-        if world == 1:
+        if not exchange:
             continue
         outs = [acc[(r * per + c_lo) * b2:(r * per + c_hi) * b2] for r in range(world)]
         if direct:
@@ -155,7 +171,7 @@ def agree_on_shard_geometry(plan, prepare, world, device="cpu", group=None):
     Returns (block_cells, pair_bound)."""
     import torch
     import torch.distributed as dist
-    if world <= 1:
+    if not _exchanges(world):
         return plan.block_cells, plan.pair_bound
     b = torch.tensor([plan.block_cells, -plan.max_read_entries], dtype=torch.int64, device=device)
     dist.all_reduce(b, op=dist.ReduceOp.MIN, group=group)
@@ -169,16 +185,36 @@ def agree_on_shard_geometry(plan, prepare, world, device="cpu", group=None):
     return block_cells, bound
 
 
-def chromosome_sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate, world, group=None):
+def chromosome_sharded_accumulate(plan, acc, mutation_rate, homozygous_rate, seq_error_rate, world, group=None,
+                                  verify_scale=False):
     """`plan` holds this rank's chromosomes (chromosome_shard; the same block_cells and pair bound on every
     rank: agree_on_shard_geometry): compute all tiles over them into `acc` (overwritten), then sum the
     accumulators of all ranks. A rank with an empty shard still calls accumulate (it sets up the table and
-    the scale that finalize needs)."""
+    the scale that finalize needs). Raises when the shared bounds are not in force on this rank (never set, or
+    dropped by a prepare from other arrays); verify_scale=True also all-reduces MIN / MAX of the scale the ranks
+    used and raises on a mismatch (one small collective and a host synchronisation per call: tests, debugging)."""
     import torch.distributed as dist
 
     n = plan.acc_elems
+    if world > 1 and plan.scale_bounds_state != 1:
+        # (ADVICE r03) accumulators that are added must be quantised at ONE scale: without the shared bounds in
+        # force this rank would sum at its shard's own scale -- silently wrong by a power of two when the union
+        # crosses a threshold the shard does not
+        raise RuntimeError(
+            "chromosome_sharded_accumulate: the shared scale bounds are not in force on this rank (%s); call "
+            "agree_on_shard_geometry after every prepare from new arrays" % (
+                "they were set and a later prepare from other arrays dropped them"
+                if plan.scale_bounds_state == 2 else "they were never set"))
     plan.accumulate(acc, mutation_rate, homozygous_rate, seq_error_rate, overwrite=True)
-    if world > 1:
+    if verify_scale and _exchanges(world):
+        import torch
+        dev = acc.device if (acc.is_cuda and dist.get_backend(group) == "nccl") else "cpu"
+        chk = torch.tensor([plan.scale_log2, -plan.scale_log2], dtype=torch.int64, device=dev)
+        dist.all_reduce(chk, op=dist.ReduceOp.MAX, group=group)
+        if int(chk[0].item()) != -int(chk[1].item()):
+            raise RuntimeError("chromosome_sharded_accumulate: ranks quantised at different scales (2^%d .. 2^%d)"
+                               % (-int(chk[1].item()), int(chk[0].item())))
+    if _exchanges(world):
         if acc.is_cuda and dist.get_backend(group) != "nccl":
             summed = acc[:n].cpu()  # rehearsal backends (gloo) move host memory
             dist.all_reduce(summed, op=dist.ReduceOp.SUM, group=group)
@@ -213,7 +249,7 @@ def sharded_rows(plan, acc, mutation_rate, homozygous_rate, seq_error_rate, rank
     ids = plan.tiles_of_rows(lo, hi)
     plan.accumulate_list(acc, mutation_rate, homozygous_rate, seq_error_rate, ids, overwrite=True)
     local_max = plan.max_of_tiles(acc, ids)
-    if world > 1:
+    if _exchanges(world):
         t = torch.tensor([local_max], dtype=torch.float64,
                          device=acc.device if dist.get_backend(group) == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)

@@ -246,6 +246,12 @@ class SimilarityMatrixPlan:
         return self
 
     @property
+    def scale_bounds_state(self) -> int:
+        """0: no shared bounds set; 1: in force for the pileup held; 2: they were set and a later pileup (other
+        sizes or other arrays) took them away -- accumulators of such a handle must not be added to other ranks'."""
+        return int(_lib.lib().secedo_simmat_scale_bounds_state(self._h))
+
+    @property
     def scale_log2(self) -> int:
         """log2 of the fixed-point scale of the last accumulate()."""
         return int(_lib.lib().secedo_simmat_scale_log2(self._h))

@@ -131,8 +131,9 @@ def test_chromosome_shards_sum_to_the_whole_matrix():
 class FakeShardPlan:
     """accumulate() gives rank + 1 in every element: the all-reduce must leave 1 + 2 + ... + world."""
 
-    def __init__(self, rank, n):
+    def __init__(self, rank, n, scale_bounds_state=1, scale_log2=44):
         self.rank, self.acc_elems, self.num_entries = rank, n, 1
+        self.scale_bounds_state, self.scale_log2 = scale_bounds_state, scale_log2
 
     def accumulate(self, acc, eps, h, theta, overwrite=False):
         if overwrite:
@@ -147,8 +148,23 @@ def _shard_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         acc = torch.full((48,), -3, dtype=torch.int64)  # garbage that must disappear; 8 elements of padding
-        sd.chromosome_sharded_accumulate(FakeShardPlan(rank, 40), acc, 0.01, 0.5, 0.01, world)
+        sd.chromosome_sharded_accumulate(FakeShardPlan(rank, 40), acc, 0.01, 0.5, 0.01, world, verify_scale=True)
         ok = bool(torch.all(acc[:40] == world * (world + 1) // 2))
+        #  a rank whose shared bounds are not in force -- never set, or dropped by a prepare from a
+        # re-created array -- must not add its accumulator to the others': refused locally, before any collective
+        for state in (0, 2):
+            try:
+                sd.chromosome_sharded_accumulate(FakeShardPlan(rank, 40, state), acc.clone(), 0.01, 0.5, 0.01, world)
+                ok = False
+            except RuntimeError as e:
+                ok = ok and "scale bounds" in str(e)
+        # ... and ranks that DID quantise at different scales are found out by verify_scale
+        try:
+            sd.chromosome_sharded_accumulate(FakeShardPlan(rank, 40, 1, 44 - rank), acc.clone(), 0.01, 0.5, 0.01, world,
+                                             verify_scale=True)
+            ok = False
+        except RuntimeError as e:
+            ok = ok and "different scales" in str(e)
         flags = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(flags, torch.tensor([int(ok)], dtype=torch.int64))
         if rank == 0:

@@ -1,6 +1,7 @@
 """Two ranks on the one GPU of the test box (gloo rendezvous, both on cuda:0): the sharded path -- tile
 ranges per rank, gather of the int64 accumulator, local normalisation -- must reproduce the
-single-process matrix bit for bit. (RCCL itself needs one GPU per rank; the driver exercises it.)"""
+single-process matrix bit for bit. RCCL itself needs one GPU per rank: its code paths run here at world size 1
+(test_rccl_world_size_1_runs_every_collective_branch)."""
 import os
 import socket
 
@@ -285,3 +286,123 @@ def test_more_ranks_than_chromosomes_leave_empty_shards():
         torch.cuda.synchronize()
         assert empty == 5
         assert torch.equal(total, full)
+
+
+def _rccl_world1_worker(port, out_dir):
+    """ONE rank, backend nccl (= RCCL) on cuda:0, SECEDO_DIST_EXCHANGE_ALWAYS=1: every collective branch of
+    secedo_amd.distributed runs through RCCL exactly as it does with N ranks (in-place all-gather, the chunked
+    all-gather into list views on a side stream with record_stream, the geometry all-reduces on the device, the
+    all-reduce of the accumulator, the scalar max, the spectral step's partial-product all-reduce)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SECEDO_DIST_EXCHANGE_ALWAYS"] = "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import secedo_amd
+        from secedo_amd import distributed as sd
+        from secedo_amd.synth import synth_config
+        from tests.pileup_gen import random_pileup
+
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1 and sd._exchanges(1)
+        n = 400
+        p = random_pileup(601, n, 3, 500, 60, 1500, dup_frac=0.02)
+        rates = (0.01, 0.5, 0.01)
+        with secedo_amd.SimilarityMatrixPlan(0) as plan:
+            plan.prepare(p, n, 1000, None, 8, block_cells=64)  # 7 blocks -> 28 tiles
+            full = plan.new_acc()
+            plan.accumulate(full, *rates)
+            want = plan.finalize(full, "ADD_MIN").clone()
+            # tiles + in-place all_gather_into_tensor
+            acc = plan.new_acc(pad_tiles_to=1)
+            acc.fill_(-123)
+            sd.sharded_accumulate(plan, acc, *rates, 0, 1)
+            assert torch.equal(acc, full)
+            # tiles, the exchange in chunks on a second stream (all_gather into a list of views)
+            for chunks in (2, 3, 5):
+                acc.fill_(-7)
+                sd.sharded_accumulate_overlapped(plan, acc, *rates, 0, 1, chunks=chunks)
+                torch.cuda.synchronize()
+                assert torch.equal(acc, full), chunks
+            assert torch.equal(plan.finalize(acc, "ADD_MIN"), want)
+            # chromosomes: geometry agreed over RCCL (device tensors), all-reduce of the accumulator
+            shard = sd.chromosome_shard(p, 0, 1)
+            plan.prepare(shard, n, 1000, None, 8, block_cells=64)
+            b, bound = sd.agree_on_shard_geometry(
+                plan, lambda bc: plan.prepare(shard, n, 1000, None, 8, block_cells=bc), 1, "cuda")
+            assert (b, bound) == (64, plan.pair_bound) and plan.scale_bounds_state == 1
+            acc.fill_(-5)
+            sd.chromosome_sharded_accumulate(plan, acc, *rates, 1, verify_scale=True)
+            assert torch.equal(acc, full)
+            # rows kept sharded (scalar max all-reduce on the device) + the distributed spectral step
+            rows, lo = sd.sharded_rows(plan, plan.new_acc(), *rates, 0, 1, "ADD_MIN")
+            assert lo == 0 and torch.equal(rows, want)
+        p1 = synth_config("C1")
+        with secedo_amd.SimilarityMatrixPlan(0) as plan:
+            plan.prepare(p1, 64, 1000, None, 8)
+            rows, lo = sd.sharded_rows(plan, plan.new_acc(), *rates, 0, 1, "ADD_MIN")
+            vals, vecs, info = sd.sharded_eigenpairs(rows, lo, 64, 20, 7)
+            v1, w1, _ = secedo_amd.smallest_eigenpairs(rows, 20, 7)
+            assert info["converged"] and np.max(np.abs(vals - v1)) <= 1e-9
+        with open(os.path.join(out_dir, "ok"), "w") as fh:
+            fh.write("rccl world %d backend %s\n" % (dist.get_world_size(), dist.get_backend()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world_size_1_runs_every_collective_branch(tmp_path):
+    """no line of the RCCL code had ever executed. A world-size-1 RCCL group on the box's one GPU
+    (a child process, so that the test process never initialises RCCL) drives sharded_accumulate,
+    sharded_accumulate_overlapped, agree_on_shard_geometry(device="cuda") + chromosome_sharded_accumulate,
+    sharded_rows and sharded_eigenpairs through their `direct` (nccl) branches, each bitwise equal to the
+    single-process result."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    proc = ctx.Process(target=_rccl_world1_worker, args=(port, str(tmp_path)))
+    proc.start()
+    proc.join(600)
+    assert proc.exitcode == 0
+    assert (tmp_path / "ok").read_text().startswith("rccl world 1 backend nccl")
+
+
+def test_bounds_dropped_by_a_prepare_from_copied_arrays_are_refused():
+    """the shared scale bounds belong to the pileup held when they were set; a prepare from a
+    re-created (equal) array drops them, and setting them before the pileup is set loses them too. Neither may pass
+    silently: scale_bounds_state says so and chromosome_sharded_accumulate refuses to add such an accumulator."""
+    import copy
+
+    import secedo_amd
+    from secedo_amd import distributed as sd
+    from tests.pileup_gen import random_pileup
+
+    n = 120
+    p = random_pileup(613, n, 3, 150, 30, 800)
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        assert plan.scale_bounds_state == 0
+        plan.prepare(p, n, 1000, None, 4, block_cells=64)
+        plan.set_scale_bounds(1 << 30, 4)
+        assert plan.scale_bounds_state == 1
+        plan.prepare(p, n, 1000, None, 4, block_cells=64)       # the same arrays again: kept
+        assert plan.scale_bounds_state == 1
+        acc = plan.new_acc()
+        plan.accumulate(acc, 0.01, 0.5, 0.01)
+        shared_scale = plan.scale_log2
+        assert shared_scale < 44
+        q = copy.deepcopy(p)                                    # equal data, other arrays
+        plan.prepare(q, n, 1000, None, 4, block_cells=64)
+        assert plan.scale_bounds_state == 2
+        with pytest.raises(RuntimeError, match="scale bounds"):
+            sd.chromosome_sharded_accumulate(plan, acc, 0.01, 0.5, 0.01, world=2)
+        plan.set_scale_bounds(1 << 30, 4)                       # set again after the prepare: in force
+        assert plan.scale_bounds_state == 1
+        plan.accumulate(acc, 0.01, 0.5, 0.01)
+        assert plan.scale_log2 == shared_scale
+        plan.set_scale_bounds(0, 0)
+        assert plan.scale_bounds_state == 0
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:            # bounds before the pileup: taken away by set_pileup
+        plan.set_scale_bounds(1 << 30, 4)
+        plan.prepare(p, n, 1000, None, 4, block_cells=64)
+        assert plan.scale_bounds_state == 2

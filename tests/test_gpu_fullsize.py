@@ -112,6 +112,48 @@ def test_c3_against_the_compiled_reference():
     assert digest_errors(z, got[ii, jj], ref_max)[0] <= 1e-9
 
 
+@pytest.mark.parametrize("name", ["C2", "C3"])
+def test_clustered_loci_against_the_compiled_reference(name):
+    """SURVEY.md 8d "also run each with gap_max=300": the clustered-loci variants (about 2.8 loci per read, nine
+    entries per cell block and locus: accumulate_masks + wide_pairs, the general packing path) held against the
+    REFERENCE itself at full size: tests/golden/c{2,3}_clustered_reference_digest.npz are single runs of the
+    compiled, unmodified reference (oracle/gen_golden.py c2_clustered_reference_run / c3_clustered_reference_run;
+    5.4e8 and 2.5e10 updates) -- sampled entries (uniform, inside diagonal 64- and 128-cell tiles, last and first
+    cell block), maximum, sum, 128-row block sums. Checked: the sequence `bench.py --clustered` times and the
+    one-shot drop-in call, norm-wise 1e-9."""
+    path = gu.GOLDEN + "/%s_clustered_reference_digest.npz" % name.lower()
+    import os
+    if not os.path.exists(path):
+        pytest.skip("no digest of the reference for %s clustered" % name)
+    z = np.load(path)
+    n, mfl, eps, h, theta, T, _ = z["params"]
+    n, mfl, T = int(n), int(mfl), int(T)
+    p = synth_config(name, clustered=True)
+    assert p.n_entries == int(z["n_entries"]) and p.n_loci == int(z["n_loci"])
+    ref_max, ii, jj = float(z["max_abs"]), z["sample_i"].astype(np.int64), z["sample_j"].astype(np.int64)
+    ti, tj = torch.from_numpy(ii).cuda(), torch.from_numpy(jj).cuda()
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        resident = plan.upload(p, None, n)
+        plan.prepare_resident(resident, n, mfl, T)
+        acc = plan.new_acc()
+        out = plan.assign_finalize(acc, eps, h, theta, "ADD_MIN")
+        torch.cuda.synchronize()
+        assert plan.pair_kernel == "accumulate_masks"
+        normwise, rel_max, rel_999 = digest_errors(z, out[ti, tj].cpu().numpy(), ref_max)
+        print("\n%s clustered assign_finalize vs compiled reference, %d sampled entries: norm-wise %.2e, "
+              "element-wise relative max %.2e, 99.9-percentile %.2e" % (name, len(ii), normwise, rel_max, rel_999))
+        assert normwise <= 1e-9
+        assert abs(float(out.abs().max()) - ref_max) <= 1e-9 * ref_max
+        assert abs(float(out.sum()) - float(z["total"])) <= 1e-9 * abs(float(z["total"]))
+        blocks = torch.stack([out[lo:lo + 128].sum() for lo in range(0, n, 128)]).cpu().numpy()
+        assert np.max(np.abs(blocks - z["row_block_sums"])) <= 1e-9 * np.max(np.abs(z["row_block_sums"]))
+        assert torch.equal(out, out.T) and not torch.any(torch.diagonal(out))
+        kept = out.clone()
+    got = secedo_amd.compute_similarity_matrix(p, n, mfl, None, eps, h, theta, T, "", "ADD_MIN")
+    assert np.array_equal(got, kept.cpu().numpy())  # the drop-in call returns the same bits
+    assert digest_errors(z, got[ii, jj], ref_max)[0] <= 1e-9
+
+
 def test_c5_full_size_properties():
     """C5 (32000 cells x 200 K loci, 1.05e10 updates; cell ids beyond the reference's 14 bits, so the
     32-bit id_base variant): GPU packing against the host emulation in counters and in every bit of the
