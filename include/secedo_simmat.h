@@ -62,7 +62,13 @@ int secedo_simmat_device_count(void);
  * Mat<double>, util/mat.hpp:17-37). num_threads is the reference's num_threads: it does not
  * set any parallelism here, it is the semantic input of the flush rule (similarity_matrix.cpp:
  * 354-356: a batch of completed reads is compared once 4*num_threads of them are complete).
- * Uses device SECEDO_DEVICE (env, default 0).
+ * Devices: secedo_simmat_set_devices() below, else the environment's SECEDO_GPUS, else SECEDO_DEVICE
+ * (default: device 0). With more than one device the N x N output is block-partitioned across them
+ * behind this same call (north_star): one host thread per device, every device packs the
+ * pileup, takes a contiguous range of upper-triangular tiles, pulls the others' tiles over xGMI
+ * (hipMemcpyPeerAsync, chunk by chunk behind the accumulation), normalises its block of rows and
+ * downloads it into its rows of `out`. Integer accumulators: the matrix is bit-identical for any
+ * number of devices.
  * ---------------------------------------------------------------------------------------- */
 int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const uint32_t *locus_pos,
                           const uint64_t *locus_entry_off, const uint32_t *read_ids,
@@ -71,6 +77,15 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
                           uint32_t max_fragment_length, double mutation_rate,
                           double homozygous_rate, double seq_error_rate, uint32_t num_threads,
                           int normalization, double *out);
+/* The devices secedo_simmat_compute (and so the C++ shim with the reference's signature, whose argument list
+ * has no room for them) spreads one matrix over: device_ids[0 .. n_devices), each < device_count(); a device
+ * may be listed more than once (rehearsal of the N-device path on fewer GPUs: every entry is a lane of its
+ * own). n_devices = 0 returns to the environment: SECEDO_GPUS = a count N (devices 0 .. N - 1) or a
+ * comma-separated list of ids; else SECEDO_DEVICE; else device 0. Process-wide; at most 16 devices.
+ * get_devices writes up to `capacity` ids and returns how many devices the next call would use (< 0: error). */
+int secedo_simmat_set_devices(const int *device_ids, uint32_t n_devices);
+int secedo_simmat_get_devices(int *device_ids, uint32_t capacity);
+
 /* Pinned host staging for callers that assemble the flat pileup themselves (the C++ shim flattens the
  * reference's vector<vector<PosData>> straight into it, several threads at a time): five buffers of at least
  * bytes[0..4] bytes -- for chr_locus_off, locus_pos, locus_entry_off, read_ids, id_base in this order --

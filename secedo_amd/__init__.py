@@ -5,7 +5,8 @@ host-side mirror of the reference interface (similarity_matrix.py).
 """
 from .pileup import FlatPileup, PosData, flatten  # noqa: F401
 from .similarity_matrix import (InvalidNormalization, NORMALIZATIONS, SecedoError,  # noqa: F401
-                                SimilarityMatrixPlan, compute_similarity_matrix, llr, llr_closed_form, to_enum)
+                                SimilarityMatrixPlan, compute_similarity_matrix, get_devices, llr, llr_closed_form,
+                                set_devices, to_enum)
 from .filter import Filter, NO_POS, filter_resident  # noqa: F401,E402
 from .pileup_reader import get_grouping, read_pileup  # noqa: F401,E402
 from .spectral import laplacian, smallest_eigenpairs  # noqa: F401,E402

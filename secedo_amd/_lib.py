@@ -106,6 +106,8 @@ SIGNATURES = {
     "secedo_simmat_set_scale_bounds": (C.c_int, [_vp, C.c_uint64, C.c_uint32]),
     "secedo_simmat_scale_log2": (C.c_int, [_vp]),
     "secedo_simmat_scale_bounds_state": (C.c_int, [_vp]),
+    "secedo_simmat_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_uint32]),
+    "secedo_simmat_get_devices": (C.c_int, [C.POINTER(C.c_int), C.c_uint32]),
     "secedo_is_significant": (C.c_int, [_vp, C.c_double, C.c_uint32]),
     "secedo_filter": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_double,
                                 C.c_uint32, _vp, _vp, _vp, _vp, _vp, _u64p, _u64p, _f64p]),

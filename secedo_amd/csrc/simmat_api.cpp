@@ -18,6 +18,8 @@
 #endif
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -77,6 +79,42 @@ struct DevBuf {
     T *as() const { return static_cast<T *>(p); }
 };
 
+// Small host -> device uploads in the ORDER OF A STREAM (tables, workgroup plans, tile lists of accumulate): the
+// bytes are copied into one of four host slots of the handle first, so that the caller's / the builder's memory
+// is free at once and the copy may execute whenever the stream gets to it; a slot is taken again only after the
+// copy that used it last has executed (its event), which blocks the host only when five uploads are in flight.
+struct StagedUploads {
+    static constexpr int kSlots = 4;
+    std::vector<unsigned char> host[kSlots];
+    hipEvent_t done[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool used[kSlots] = {false, false, false, false};
+    int next = 0;
+    hipError_t put(void *dst, const void *src, size_t bytes, hipStream_t s) {
+        if (bytes == 0) return hipSuccess;
+        const int k = next;
+        next = (next + 1) % kSlots;
+        hipError_t e = hipSuccess;
+        if (!done[k]) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
+        if (e == hipSuccess && used[k]) e = hipEventSynchronize(done[k]);
+        if (e != hipSuccess) return e;
+        host[k].assign(static_cast<const unsigned char *>(src), static_cast<const unsigned char *>(src) + bytes);
+        e = hipMemcpyAsync(dst, host[k].data(), bytes, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipEventRecord(done[k], s);
+        used[k] = (e == hipSuccess);
+        return e;
+    }
+    void destroy() {
+        for (int k = 0; k < kSlots; ++k) {
+            if (done[k]) {
+                if (used[k]) (void)hipEventSynchronize(done[k]);
+                (void)hipEventDestroy(done[k]);
+            }
+            done[k] = nullptr;
+            used[k] = false;
+        }
+    }
+};
+
 }  // namespace
 
 struct secedo_simmat {
@@ -106,6 +144,7 @@ struct secedo_simmat {
     DevBuf own_acc, own_out;  // used by the one-shot entry point only
     DevBuf tile_ids;          // tile list of accumulate_list / max_of_tiles
     std::vector<uint16_t> host_tile_row, host_tile_col;
+    StagedUploads uploads;    // tables, plans and tile lists of accumulate, in the order of its stream
     uint64_t plan_list_hash = 0;  // 0: the cached workgroup plan belongs to a contiguous tile range
 
     // LLR table of the last accumulate()
@@ -163,10 +202,12 @@ bool pool_enabled() {
     return !(env && std::atoi(env) == 0);
 }
 
-int one_shot_acquire(int device, secedo_simmat_t **h) {
+// key: the device, or -- for the lanes of a multi-device call -- a number of its own per lane (kLaneKey)
+constexpr int kLaneKey = 1 << 16;
+int one_shot_acquire(int key, int device, secedo_simmat_t **h) {
     if (pool_enabled()) {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
-        auto it = g_pool.find(device);
+        auto it = g_pool.find(key);
         if (it != g_pool.end() && it->second) {
             *h = it->second;
             it->second = nullptr;
@@ -176,11 +217,11 @@ int one_shot_acquire(int device, secedo_simmat_t **h) {
     return secedo_simmat_create(h, device);
 }
 
-void one_shot_release(int device, secedo_simmat_t *h, bool ok) {
+void one_shot_release(int key, secedo_simmat_t *h, bool ok) {
     if (!h) return;
     if (ok && pool_enabled()) {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
-        secedo_simmat_t *&slot = g_pool[device];
+        secedo_simmat_t *&slot = g_pool[key];
         if (!slot) {
             slot = h;
             return;
@@ -222,17 +263,24 @@ struct PinnedBuf {
 std::mutex g_staging_mutex;
 bool g_staging_busy = false;
 PinnedBuf g_staging[5];
-PinnedBuf g_bounce;  // guarded by g_bounce_mutex for the duration of a download
-std::mutex g_bounce_mutex;
+// page-locked rings of the matrix download: [0] the single-device call's, [1 + k] lane k's of a multi-device call;
+// each guarded by its mutex for the duration of a download
+constexpr int kMaxLanes = 16;
+struct Bounce {
+    PinnedBuf buf;
+    std::mutex mutex;
+};
+Bounce g_bounce[1 + kMaxLanes];
 
 // d_src (device) -> dst (pageable host memory, typically the fresh pages of the caller's matrix): chunks go
 // through a page-locked ring by DMA while `threads` host threads copy the chunk before out of the ring, each
 // its own slice -- touching the destination's fresh pages in parallel is what a single-threaded copy into
 // pageable memory cannot do (12-20 GB/s for hipMemcpy on the 512 MB of C3).
-hipError_t download_pipelined(const void *d_src, void *dst, size_t bytes, unsigned threads) {
+hipError_t download_pipelined(const void *d_src, void *dst, size_t bytes, unsigned threads, int ring = 0) {
     constexpr size_t kChunk = 32u << 20;
     constexpr int kSlots = 3;
-    std::lock_guard<std::mutex> lock(g_bounce_mutex);
+    std::lock_guard<std::mutex> lock(g_bounce[ring].mutex);
+    PinnedBuf &g_bounce = ::g_bounce[ring].buf;
     hipError_t e = g_bounce.ensure(kChunk * kSlots);
     if (e != hipSuccess) {  // no pinned memory to be had: the plain copy
         (void)hipGetLastError();
@@ -361,6 +409,7 @@ void secedo_simmat_destroy(secedo_simmat_t *h) {
     if (h->side.fork) (void)hipEventDestroy(h->side.fork);
     if (h->side.join) (void)hipEventDestroy(h->side.join);
     if (h->side.stream) (void)hipStreamDestroy(h->side.stream);
+    h->uploads.destroy();
     delete h;
 }
 
@@ -731,8 +780,10 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         if (!h->have_lut || want_scale != h->scale_log2) {
             secedo::requantize(&h->table, want_scale);
             HIP_TRY(h->lut.ensure(h->table.fixed.size() * sizeof(int64_t)));
-            HIP_TRY(hipMemcpy(h->lut.p, h->table.fixed.data(), h->table.fixed.size() * sizeof(int64_t),
-                              hipMemcpyHostToDevice));
+            // (in the order of the caller's stream, as every upload of accumulate: a launch still running on a
+            // non-blocking stream reads the tables and the workgroup plan of ITS call -- a plain hipMemcpy runs on the
+            // null stream, which such streams do not wait for; the host sources stay alive in the handle)
+            HIP_TRY(h->uploads.put(h->lut.p, h->table.fixed.data(), h->table.fixed.size() * sizeof(int64_t), s));
             h->scale_log2 = want_scale;
             h->model = h->table.model;
             h->have_lut = true;
@@ -750,8 +801,8 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         sp.scale_log2 = h->scale_log2;
         if (!h->have_slow || std::memcmp(&sp, &h->slow_host, sizeof(sp)) != 0) {
             HIP_TRY(h->slow_args.ensure(sizeof(sp)));
-            HIP_TRY(hipMemcpy(h->slow_args.p, &sp, sizeof(sp), hipMemcpyHostToDevice));
             h->slow_host = sp;
+            HIP_TRY(h->uploads.put(h->slow_args.p, &sp, sizeof(sp), s));
             h->have_slow = true;
         }
     }
@@ -790,7 +841,7 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
     if (list) {
         if (h->plan_list_hash != list_hash) {
             HIP_TRY(h->tile_ids.ensure((size_t)std::max(n_list, 1u) * 4));
-            if (n_list) HIP_TRY(hipMemcpy(h->tile_ids.p, list, (size_t)n_list * 4, hipMemcpyHostToDevice));
+            HIP_TRY(h->uploads.put(h->tile_ids.p, list, (size_t)n_list * 4, s));
         }
         a.tile_ids = h->tile_ids.as<uint32_t>();
     }
@@ -843,8 +894,12 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
             wg_begin[t + 1] = wg_begin[t] + chunks[t];
             for (uint32_t k = 0; k < chunks[t]; ++k) wg_tile.push_back(t);
         }
-        HIP_TRY(h->plan_wg_tile.upload(wg_tile));
-        HIP_TRY(h->plan_wg_begin.upload(wg_begin));
+        // (a larger plan than any before: the buffers grow, and hipFree waits for the device; otherwise the new plan
+        // follows the launches that read the old one in stream order)
+        HIP_TRY(h->plan_wg_tile.ensure(wg_tile.size() * 4));
+        HIP_TRY(h->plan_wg_begin.ensure(wg_begin.size() * 4));
+        HIP_TRY(h->uploads.put(h->plan_wg_tile.p, wg_tile.data(), wg_tile.size() * 4, s));
+        HIP_TRY(h->uploads.put(h->plan_wg_begin.p, wg_begin.data(), wg_begin.size() * 4, s));
         h->plan_workgroups = wg_begin[n_tiles];
         h->plan_tile_begin = tile_begin;
         h->plan_tile_end = tile_end;
@@ -944,7 +999,8 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
                 build.stream = s;
                 if (FlagBuild::run(&build) != hipSuccess) return fail(SECEDO_E_HIP, "building the flagged entries' lists failed");
             }
-            h->flags_ready = true;
+            // (flags_ready is set once the lists' kernels have been ISSUED without an error, below: a launch that
+            // fails in between must not leave the next accumulate reading lists nobody built -- ADVICE r03)
         }
         a.flag_grp = h->flag_grp.as<uint32_t>();
         a.flag_rec = h->flag_rec.as<uint4>();
@@ -967,6 +1023,7 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         if (FlagBuild::run(&build) != hipSuccess) return fail(SECEDO_E_HIP, "building the flagged entries' lists failed");
         HIP_TRY(hipStreamWaitEvent(s, h->side.join, 0));
     }
+    if (build.h && build.done) h->flags_ready = true;
     h->timed_mid = h->timed_mid && n_tiles > 0;
     HIP_TRY(hipEventRecord(h->ev_end, s));
     h->timed = true;
@@ -1194,6 +1251,277 @@ int secedo_simmat_last_pair_kernel_ms(secedo_simmat_t *h, float *ms) {
     return SECEDO_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Several GPUs behind the one-shot call (north_star: "the N x N output is block-partitioned across the 8 GPUs of
+// one node"; SURVEY.md 8b set_devices, section 5 SECEDO_GPUS). The reference's caller (spectral_clustering.cpp:
+// 354-356) keeps calling computeSimilarityMatrix() with the same signature; ONE process drives N devices, a host
+// thread ("lane") per device:
+//   1. every lane uploads the flat pileup to its device and packs it there (the packing is replicated, the
+//      lanes run side by side: nothing travels between devices before the accumulators exist);
+//   2. lane k stores its contiguous range of upper-triangular tiles into its own tile-major int64 accumulator,
+//      in kChunks launches with an event behind each;
+//   3. every lane pulls the other lanes' tiles into its accumulator chunk by chunk as their events fire
+//      (hipMemcpyPeerAsync over xGMI on a copy stream of its own: the all-gather of SURVEY 8e as N x (N - 1)
+//      direct copies, which point-to-point links serve better than a ring), so that the exchange of a lane's
+//      first chunks runs behind the accumulation of its later ones;
+//   4. every lane normalises ITS block of rows from the complete accumulator (the maximum ADD_MIN / SCALE_MAX_1
+//      need is taken over all tiles on every device: no scalar exchange) and downloads it straight into its
+//      rows of the caller's matrix -- N downloads over N PCIe links instead of one.
+// Integer accumulators make the result bit-identical to the single-device call whatever N is; a device may be
+// listed more than once (that is how the one-GPU test box runs this code: tests/test_gpu_multi_device.py).
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+std::mutex g_devices_mutex;
+std::vector<int> g_devices;     // secedo_simmat_set_devices; empty: SECEDO_GPUS, else SECEDO_DEVICE, else 0
+std::mutex g_multi_mutex;       // one multi-device call at a time (the lanes' rings and pool slots are per lane)
+
+int parse_device_list(const char *text, std::vector<int> *out) {
+    out->clear();
+    const std::string t(text);
+    if (t.find(',') == std::string::npos) {  // a count: devices 0 .. N - 1
+        char *end = nullptr;
+        const long n = std::strtol(t.c_str(), &end, 10);
+        if (end == t.c_str() || *end != '\0' || n < 1 || n > kMaxLanes)
+            return fail(SECEDO_E_INVALID_ARG, "SECEDO_GPUS must be a count 1.." + std::to_string(kMaxLanes) + " or a comma-separated list of device ids");
+        for (long i = 0; i < n; ++i) out->push_back(static_cast<int>(i));
+        return SECEDO_OK;
+    }
+    size_t pos = 0;
+    while (pos <= t.size()) {
+        const size_t comma = std::min(t.find(',', pos), t.size());
+        const std::string item = t.substr(pos, comma - pos);
+        char *end = nullptr;
+        const long v = std::strtol(item.c_str(), &end, 10);
+        if (item.empty() || *end != '\0' || v < 0) return fail(SECEDO_E_INVALID_ARG, "SECEDO_GPUS: bad device id '" + item + "'");
+        out->push_back(static_cast<int>(v));
+        pos = comma + 1;
+    }
+    if (out->empty() || out->size() > static_cast<size_t>(kMaxLanes)) return fail(SECEDO_E_INVALID_ARG, "SECEDO_GPUS: 1.." + std::to_string(kMaxLanes) + " devices");
+    return SECEDO_OK;
+}
+
+int check_devices(const std::vector<int> &ids) {
+    const int n = secedo_simmat_device_count();
+    if (n <= 0) return fail(SECEDO_E_NO_DEVICE, "no HIP device is visible: the similarity-matrix path has no CPU fallback");
+    for (int d : ids)
+        if (d < 0 || d >= n) return fail(SECEDO_E_NO_DEVICE, "device id " + std::to_string(d) + " out of range (" + std::to_string(n) + " visible)");
+    return SECEDO_OK;
+}
+
+// the devices of the one-shot call
+int one_shot_devices(std::vector<int> *out) {
+    {
+        std::lock_guard<std::mutex> lock(g_devices_mutex);
+        *out = g_devices;
+    }
+    if (out->empty()) {
+        if (const char *env = std::getenv("SECEDO_GPUS")) {
+            const int rc = parse_device_list(env, out);
+            if (rc != SECEDO_OK) return rc;
+        } else {
+            int device = 0;
+            if (const char *env = std::getenv("SECEDO_DEVICE")) device = std::atoi(env);
+            out->assign(1, device);
+        }
+    }
+    if (out->size() > 1) return check_devices(*out);
+    return SECEDO_OK;  // (one device: secedo_simmat_create checks it)
+}
+
+class HostBarrier {
+public:
+    explicit HostBarrier(unsigned n) : n_(n) {}
+    void wait() {
+        std::unique_lock<std::mutex> lock(m_);
+        const unsigned gen = gen_;
+        if (++count_ == n_) {
+            count_ = 0;
+            ++gen_;
+            cv_.notify_all();
+        } else {
+            cv_.wait(lock, [&] { return gen_ != gen; });
+        }
+    }
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    unsigned n_, count_ = 0, gen_ = 0;
+};
+
+struct Lane {
+    int device = 0;
+    secedo_simmat_t *h = nullptr;
+    hipStream_t s = nullptr, sc = nullptr;   // accumulation / exchange + normalisation
+    std::vector<hipEvent_t> done;            // behind each chunk of the lane's tiles
+    uint32_t lo = 0, hi = 0;                 // its tiles
+    int rc = SECEDO_OK;
+    std::string err;
+};
+
+constexpr uint32_t kChunks = 4;
+
+int compute_on_devices(const std::vector<int> &devices, const uint32_t *chr_locus_off, uint32_t n_chr,
+                       const uint32_t *locus_pos, const uint64_t *locus_entry_off, const uint32_t *read_ids,
+                       const uint16_t *id_base16, const uint32_t *id_base32, const uint32_t *group_id_to_pos,
+                       uint32_t n_groups, uint32_t num_cells, uint32_t mfl, double eps, double hr, double theta,
+                       uint32_t num_threads, int normalization, double *out) {
+    std::lock_guard<std::mutex> serial(g_multi_mutex);
+    const uint32_t n = static_cast<uint32_t>(devices.size());
+    std::vector<Lane> lanes(n);
+    HostBarrier barrier(n);
+    std::atomic<bool> failed{false};
+    static const bool trace = std::getenv("SECEDO_ONE_SHOT_TRACE") != nullptr;
+    using clock = std::chrono::steady_clock;
+    const auto t0 = clock::now();
+    std::vector<double> t_ms(static_cast<size_t>(n) * 4, 0.0);
+
+    auto lane_main = [&](uint32_t k) {
+        Lane &me = lanes[k];
+        me.device = devices[k];
+        auto fail_lane = [&](int rc) {  // (the message is this thread's: keep it for the caller's thread)
+            me.rc = rc;
+            me.err = g_last_error;
+            failed.store(true);
+        };
+#define LANE_HIP(expr)                                                         \
+        do {                                                                   \
+            hipError_t e__ = (expr);                                           \
+            if (e__ != hipSuccess && me.rc == SECEDO_OK) fail_lane(hip_fail(e__, #expr)); \
+        } while (0)
+#define LANE_RC(expr)                                                          \
+        do {                                                                   \
+            if (me.rc == SECEDO_OK) {                                          \
+                const int rc__ = (expr);                                       \
+                if (rc__ != SECEDO_OK) fail_lane(rc__);                        \
+            }                                                                  \
+        } while (0)
+        auto now_ms = [&] { return std::chrono::duration<double, std::milli>(clock::now() - t0).count(); };
+        // ---- 1 + 2: pack, accumulate the lane's tiles chunk by chunk
+        LANE_HIP(hipSetDevice(me.device));
+        for (uint32_t j = 0; j < n && me.rc == SECEDO_OK; ++j) {
+            if (devices[j] == me.device) continue;
+            const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);  // direct xGMI copies where the link exists
+            if (e != hipSuccess) (void)hipGetLastError();                   // (already enabled / not possible: staged copies)
+        }
+        LANE_RC(one_shot_acquire(kLaneKey + static_cast<int>(k), me.device, &me.h));
+        LANE_HIP(hipStreamCreateWithFlags(&me.s, hipStreamNonBlocking));
+        LANE_HIP(hipStreamCreateWithFlags(&me.sc, hipStreamNonBlocking));
+        me.done.assign(kChunks, nullptr);
+        for (uint32_t c = 0; c < kChunks; ++c) LANE_HIP(hipEventCreateWithFlags(&me.done[c], hipEventDisableTiming));
+        LANE_RC(secedo_simmat_set_pileup(me.h, chr_locus_off, n_chr, locus_pos, locus_entry_off, read_ids, id_base16,
+                                         id_base32, group_id_to_pos, n_groups));
+        LANE_RC(secedo_simmat_prepare(me.h, num_cells, mfl, num_threads, 0, me.s));
+        t_ms[k * 4 + 0] = now_ms();
+        uint32_t tiles = 0, per = 0, step = 0;
+        if (me.rc == SECEDO_OK) {
+            tiles = me.h->num_tiles;
+            per = (tiles + n - 1) / n;
+            me.lo = std::min(k * per, tiles);
+            me.hi = std::min((k + 1) * per, tiles);
+            step = std::max(1u, (per + kChunks - 1) / kChunks);
+            LANE_HIP(me.h->own_acc.ensure(std::max<uint64_t>(secedo_simmat_acc_elems(me.h), 1) * sizeof(int64_t)));
+        }
+        for (uint32_t c = 0; c < kChunks; ++c) {
+            const uint32_t a = std::min(me.lo + c * step, me.hi), b = std::min(me.lo + (c + 1) * step, me.hi);
+            // (an empty chunk still goes through accumulate once: it sets up the table and the scale finalize needs)
+            if (b > a || c == 0) LANE_RC(secedo_simmat_assign(me.h, eps, hr, theta, a, b, me.h->own_acc.as<int64_t>(), me.s));
+            if (me.rc == SECEDO_OK) LANE_HIP(hipEventRecord(me.done[c], me.s));
+        }
+        barrier.wait();  // every lane's events are recorded (a wait on an event not yet recorded would not wait)
+        // ---- 3: the other lanes' tiles, chunk by chunk as their events fire
+        if (!failed.load()) {
+            const size_t b2 = static_cast<size_t>(me.h->pk.block_cells) * me.h->pk.block_cells;
+            for (uint32_t d = 1; d < n; ++d) {  // (lane k starts with lane k + 1: the pulls spread over the links)
+                const Lane &src = lanes[(k + d) % n];
+                if (src.h->num_tiles != tiles || src.h->pk.block_cells != me.h->pk.block_cells) {
+                    fail_lane(fail(SECEDO_E_STATE, "the lanes packed the same pileup into different geometries"));
+                    break;
+                }
+                for (uint32_t c = 0; c < kChunks; ++c) {
+                    const uint32_t a = std::min(src.lo + c * step, src.hi), b = std::min(src.lo + (c + 1) * step, src.hi);
+                    if (b <= a) continue;
+                    LANE_HIP(hipStreamWaitEvent(me.sc, src.done[c], 0));
+                    LANE_HIP(hipMemcpyPeerAsync(me.h->own_acc.as<int64_t>() + a * b2, me.device,
+                                                src.h->own_acc.as<int64_t>() + a * b2, src.device, (b - a) * b2 * sizeof(int64_t),
+                                                me.sc));
+                }
+            }
+            LANE_HIP(hipStreamWaitEvent(me.sc, me.done[kChunks - 1], 0));  // its own tiles
+        }
+        t_ms[k * 4 + 1] = now_ms();
+        // ---- 4: this lane's rows, normalised here, downloaded from here
+        if (!failed.load() && me.rc == SECEDO_OK) {
+            const uint32_t row_lo = static_cast<uint32_t>(static_cast<uint64_t>(num_cells) * k / n);
+            const uint32_t row_hi = static_cast<uint32_t>(static_cast<uint64_t>(num_cells) * (k + 1) / n);
+            const size_t row_bytes = static_cast<size_t>(row_hi - row_lo) * num_cells * sizeof(double);
+            if (me.h->scale_log2 != lanes[0].h->scale_log2)
+                fail_lane(fail(SECEDO_E_STATE, "the lanes quantised the same pileup at different scales"));
+            LANE_HIP(me.h->own_out.ensure(std::max<size_t>(row_bytes, 16)));
+            LANE_RC(secedo_simmat_finalize_rows(me.h, normalization, me.h->own_acc.as<int64_t>(), row_lo, row_hi,
+                                                me.h->own_out.as<double>(), me.sc));
+            LANE_HIP(hipStreamSynchronize(me.sc));
+            t_ms[k * 4 + 2] = now_ms();
+            if (me.rc == SECEDO_OK && row_bytes) {
+                double *dst = out + static_cast<size_t>(row_lo) * num_cells;
+                if (row_bytes >= (8u << 20))
+                    LANE_HIP(download_pipelined(me.h->own_out.p, dst, row_bytes, std::max(1u, num_threads / n), 1 + static_cast<int>(k)));
+                else
+                    LANE_HIP(hipMemcpy(dst, me.h->own_out.p, row_bytes, hipMemcpyDeviceToHost));
+            }
+        } else if (me.sc) {
+            (void)hipStreamSynchronize(me.sc);
+        }
+        t_ms[k * 4 + 3] = now_ms();
+        barrier.wait();  // nobody reads this lane's accumulator any more
+        if (me.s) (void)hipStreamSynchronize(me.s);
+        for (hipEvent_t ev : me.done)
+            if (ev) (void)hipEventDestroy(ev);
+        if (me.s) (void)hipStreamDestroy(me.s);
+        if (me.sc) (void)hipStreamDestroy(me.sc);
+        one_shot_release(kLaneKey + static_cast<int>(k), me.h, me.rc == SECEDO_OK && !failed.load());
+        me.h = nullptr;
+#undef LANE_HIP
+#undef LANE_RC
+    };
+
+    std::vector<std::thread> threads;
+    for (uint32_t k = 1; k < n; ++k) threads.emplace_back(lane_main, k);
+    lane_main(0);
+    for (std::thread &t : threads) t.join();
+    if (trace)
+        for (uint32_t k = 0; k < n; ++k)
+            std::fprintf(stderr, "[one-shot, lane %u on device %d] packed at %.2f ms, exchange issued at %.2f, rows normalised at "
+                                 "%.2f, downloaded at %.2f\n", k, lanes[k].device, t_ms[k * 4], t_ms[k * 4 + 1], t_ms[k * 4 + 2], t_ms[k * 4 + 3]);
+    for (const Lane &lane : lanes)
+        if (lane.rc != SECEDO_OK) return fail(lane.rc, lane.err);
+    return SECEDO_OK;
+}
+
+}  // namespace
+
+int secedo_simmat_set_devices(const int *device_ids, uint32_t n_devices) {
+    if (n_devices && !device_ids) return fail(SECEDO_E_INVALID_ARG, "device_ids is null");
+    if (n_devices > static_cast<uint32_t>(kMaxLanes)) return fail(SECEDO_E_LIMIT, "at most " + std::to_string(kMaxLanes) + " devices");
+    std::vector<int> ids(device_ids, device_ids + n_devices);
+    if (!ids.empty()) {
+        const int rc = check_devices(ids);
+        if (rc != SECEDO_OK) return rc;
+    }
+    std::lock_guard<std::mutex> lock(g_devices_mutex);
+    g_devices = std::move(ids);
+    return SECEDO_OK;
+}
+
+int secedo_simmat_get_devices(int *device_ids, uint32_t capacity) {
+    std::vector<int> ids;
+    const int rc = one_shot_devices(&ids);
+    if (rc != SECEDO_OK) return rc;
+    for (uint32_t i = 0; i < capacity && i < ids.size() && device_ids; ++i) device_ids[i] = ids[i];
+    return static_cast<int>(ids.size());
+}
+
 int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const uint32_t *locus_pos,
                           const uint64_t *locus_entry_off, const uint32_t *read_ids,
                           const uint16_t *id_base16, const uint32_t *id_base32,
@@ -1203,13 +1531,19 @@ int secedo_simmat_compute(const uint32_t *chr_locus_off, uint32_t n_chr, const u
     if (normalization < 0 || normalization > 2)
         return fail(SECEDO_E_INVALID_NORMALIZATION, "Invalid normalization: " + std::to_string(normalization));
     if (!out) return fail(SECEDO_E_INVALID_ARG, "out is null");
-    int device = 0;
-    if (const char *env = std::getenv("SECEDO_DEVICE")) device = std::atoi(env);
+    std::vector<int> devices;
+    int rc = one_shot_devices(&devices);
+    if (rc != SECEDO_OK) return rc;
+    if (devices.size() > 1)
+        return compute_on_devices(devices, chr_locus_off, n_chr, locus_pos, locus_entry_off, read_ids, id_base16, id_base32,
+                                  group_id_to_pos, n_groups, num_cells, max_fragment_length, mutation_rate, homozygous_rate,
+                                  seq_error_rate, num_threads, normalization, out);
+    const int device = devices[0];
     // The caller of the reference's signature calls this once per sub-cluster of the recursion
     // (spectral_clustering.cpp:354-356): the handle with its device arenas, streams and tables is kept
     // between calls (two thirds of a first call on C2 is allocation). A failed call drops its handle.
     secedo_simmat_t *h = nullptr;
-    int rc = one_shot_acquire(device, &h);
+    rc = one_shot_acquire(device, device, &h);
     if (rc != SECEDO_OK) return rc;
     struct Guard {
         secedo_simmat_t *h;
@@ -1277,9 +1611,9 @@ void secedo_simmat_release_cache(void) {
         if (!g_staging_busy)
             for (PinnedBuf &b : g_staging) b.release();
     }
-    {
-        std::lock_guard<std::mutex> lock(g_bounce_mutex);
-        g_bounce.release();
+    for (Bounce &b : g_bounce) {
+        std::lock_guard<std::mutex> lock(b.mutex);
+        b.buf.release();
     }
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (auto &slot : g_pool) {

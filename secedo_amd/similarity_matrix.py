@@ -76,6 +76,25 @@ def compute_similarity_matrix(pos_data: Union[FlatPileup, Sequence[Sequence[PosD
     return out
 
 
+def set_devices(device_ids: Optional[Sequence[int]] = None) -> None:
+    """The devices compute_similarity_matrix (secedo_simmat_compute) spreads one matrix over: a list of HIP
+    device ids -- a device may be listed more than once, every entry is a lane of its own (how the N-device path
+    is rehearsed on fewer GPUs); None / [] returns to the environment (SECEDO_GPUS, else SECEDO_DEVICE, else 0).
+    The matrix is bit-identical for any number of devices (secedo_simmat_set_devices)."""
+    ids = [int(d) for d in (device_ids or [])]
+    arr = (C.c_int * max(len(ids), 1))(*ids)
+    _lib.check(_lib.lib().secedo_simmat_set_devices(arr if ids else None, len(ids)))
+
+
+def get_devices():
+    """The devices the next compute_similarity_matrix call uses (secedo_simmat_get_devices)."""
+    arr = (C.c_int * 16)()
+    n = _lib.lib().secedo_simmat_get_devices(arr, 16)
+    if n < 0:
+        _lib.check(n)
+    return [int(arr[i]) for i in range(min(n, 16))]
+
+
 def llr(x_s: int, x_d: int, mutation_rate: float, homozygous_rate: float,
         seq_error_rate: float) -> float:
     """D(x_s, x_d) = log P_diff - log P_same as the device tables hold it (host-only): what the

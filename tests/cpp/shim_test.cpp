@@ -104,6 +104,7 @@ static int run_synth(int argc, char **argv) {
     std::vector<uint32_t> identity(spec.num_cells);
     for (uint32_t i = 0; i < spec.num_cells; ++i) identity[i] = i;
     double first = 0, best = 1e30, sum = 0;
+    unsigned long long hash = 0;
     for (int k = 0; k < 1 + repeats; ++k) {
         const double t0 = now_s();
         Mat m = secedo_amd::computeSimilarityMatrix<Mat, PosData>(pos_data, spec.num_cells, 1000, identity, 0.01, 0.5,
@@ -113,15 +114,36 @@ static int run_synth(int argc, char **argv) {
         else best = dt < best ? dt : best;
         sum = 0;
         for (uint32_t i = 0; i < spec.num_cells; i += 97) sum += m(i, (i * 31 + 7) % spec.num_cells);
+        if (k == repeats) {  // every bit of the matrix (FNV-1a over its 8-byte words)
+            hash = 0xcbf29ce484222325ull;
+            for (uint32_t i = 0; i < spec.num_cells; ++i)
+                for (uint32_t j = 0; j < spec.num_cells; ++j) {
+                    unsigned long long w;
+                    const double v = m(i, j);
+                    std::memcpy(&w, &v, 8);
+                    hash = (hash ^ w) * 0x100000001b3ull;
+                }
+        }
     }
+    int ids[16];
+    const int n_dev = secedo_simmat_get_devices(ids, 16);
     std::printf("{\"cells\": %u, \"loci\": %llu, \"entries\": %llu, \"first_call_s\": %.6f, \"repeated_call_s\": %.6f, "
-                "\"matrix_bytes\": %llu, \"checksum\": %.12g}\n",
+                "\"matrix_bytes\": %llu, \"checksum\": %.12g, \"matrix_hash\": \"%016llx\", \"devices\": %d}\n",
                 spec.num_cells, (unsigned long long)L, (unsigned long long)E, first, best,
-                (unsigned long long)spec.num_cells * spec.num_cells * 8ull, sum);
+                (unsigned long long)spec.num_cells * spec.num_cells * 8ull, sum, hash, n_dev);
     return 0;
 }
 
 int main(int argc, char **argv) {
+    // --gpus N | --gpus a,b,c in front of everything else: the devices the (unchanged) computeSimilarityMatrix()
+    // call spreads its matrix over, handed to the library the way a deployment does it -- the environment's
+    // SECEDO_GPUS (secedo_simmat_set_devices() is the programmatic form, tests/test_gpu_multi_device.py)
+    if (argc >= 3 && std::strcmp(argv[1], "--gpus") == 0) {
+        setenv("SECEDO_GPUS", argv[2], 1);
+        argv[2] = argv[0];
+        argv += 2;
+        argc -= 2;
+    }
     if (argc >= 7 && std::strcmp(argv[1], "--synth") == 0) {
         try {
             return run_synth(argc, argv);

@@ -69,6 +69,31 @@ def test_no_silent_cpu_fallback():
     assert _lib.lib().secedo_simmat_create(C.byref(h), 0) == _lib.E_NO_DEVICE
 
 
+def test_multi_device_entry_points_without_a_gpu(monkeypatch):
+    """secedo_simmat_set_devices / SECEDO_GPUS (the N-GPU partition behind secedo_simmat_compute): without a
+    device a list is refused with SECEDO_E_NO_DEVICE, and so is the call when the environment asks for several
+    devices -- never a silent single-device or CPU run; malformed lists are SECEDO_E_INVALID_ARG."""
+    with pytest.raises(secedo_amd.SecedoError) as e:
+        secedo_amd.set_devices([0, 0])
+    assert e.value.code == _lib.E_NO_DEVICE
+    secedo_amd.set_devices(None)  # back to the environment: always allowed
+    assert secedo_amd.get_devices() == [0]
+    p = from_rows([[(10, [(1, 0, 0), (2, 1, 1)])]])
+    monkeypatch.setenv("SECEDO_GPUS", "2")
+    with pytest.raises(secedo_amd.SecedoError) as e:
+        secedo_amd.compute_similarity_matrix(p, 2, 1000, None, 0.01, 0.5, 0.01, 1, "", "ADD_MIN")
+    assert e.value.code == _lib.E_NO_DEVICE
+    for bad in ("0,x", "0,,1", "-1", "0", "17", "1,2,"):
+        monkeypatch.setenv("SECEDO_GPUS", bad)
+        with pytest.raises(secedo_amd.SecedoError) as e:
+            secedo_amd.compute_similarity_matrix(p, 2, 1000, None, 0.01, 0.5, 0.01, 1, "", "ADD_MIN")
+        assert e.value.code == (_lib.E_INVALID_ARG if bad != "0" else _lib.E_INVALID_ARG), bad
+    monkeypatch.setenv("SECEDO_GPUS", "1")  # one device: the ordinary path (which then finds no device)
+    with pytest.raises(secedo_amd.SecedoError) as e:
+        secedo_amd.compute_similarity_matrix(p, 2, 1000, None, 0.01, 0.5, 0.01, 1, "", "ADD_MIN")
+    assert e.value.code == _lib.E_NO_DEVICE
+
+
 def test_product_does_not_import_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "secedo_amd")):
         for f in files:
