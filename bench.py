@@ -43,7 +43,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUND = "r03"   # profiles/<round>_*.json: the counter-derived inputs of the roofline record
+PROFILE_ROUND = "r04"   # profiles/<round>_*.json: the counter-derived inputs of the roofline record
+LIVE_COUNTERS_BUDGET_S = 240.0  # all rocprofv3 --pmc child passes of a default run together
 
 
 def _pmc_pass(counters, program, out_dir, timeout):
@@ -76,15 +77,24 @@ def live_counters(args, kernel_needle, kernel_ms):
     child = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "3", "--warmup", "1",
              "--repeats", "1", "--no-cpu-baseline"] + (["--clustered"] if args.clustered else [])
     tmp = tempfile.mkdtemp(prefix="secedo_pmc_", dir="/tmp")
+    #  six child runs: ONE budget for all of them (LIVE_COUNTERS_BUDGET_S, about 60 s are used on C3), a
+    # pass gets what is left of it -- the default command must stay within minutes even when a pass hangs
+    deadline = time.monotonic() + LIVE_COUNTERS_BUDGET_S
+
+    def left(cap):
+        remaining = deadline - time.monotonic()
+        if remaining < 5:
+            raise subprocess.TimeoutExpired("rocprofv3 --pmc passes", LIVE_COUNTERS_BUDGET_S)
+        return min(cap, remaining)
     try:
         GIB_KIB = float(1 << 20)
         pick = lambda table, needle: next(v for k, v in table.items() if needle in k)
-        cal_f = _pmc_pass(["FETCH_SIZE"], [calib], os.path.join(tmp, "cf"), 60)
-        cal_w = _pmc_pass(["WRITE_SIZE"], [calib], os.path.join(tmp, "cw"), 60)
+        cal_f = _pmc_pass(["FETCH_SIZE"], [calib], os.path.join(tmp, "cf"), left(60))
+        cal_w = _pmc_pass(["WRITE_SIZE"], [calib], os.path.join(tmp, "cw"), left(60))
         f4 = pick(cal_f, "read4")["FETCH_SIZE"] / GIB_KIB
         w16 = pick(cal_w, "write16")["WRITE_SIZE"] / GIB_KIB
-        fetch = pick(_pmc_pass(["FETCH_SIZE"], child, os.path.join(tmp, "f"), 180), kernel_needle)["FETCH_SIZE"]
-        write = pick(_pmc_pass(["WRITE_SIZE"], child, os.path.join(tmp, "w"), 180), kernel_needle)["WRITE_SIZE"]
+        fetch = pick(_pmc_pass(["FETCH_SIZE"], child, os.path.join(tmp, "f"), left(120)), kernel_needle)["FETCH_SIZE"]
+        write = pick(_pmc_pass(["WRITE_SIZE"], child, os.path.join(tmp, "w"), left(120)), kernel_needle)["WRITE_SIZE"]
         traffic = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
                    "hbm_bytes_per_launch": (fetch / f4 + write / w16) * 1024.0,
                    "calibration": {"FETCH_SIZE_per_true_KiB_read_4B_per_lane": f4,
@@ -95,7 +105,7 @@ def live_counters(args, kernel_needle, kernel_ms):
                        "SQ_INSTS_VALU", "SQ_INSTS_SALU"],
                       ["SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS",
                        "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_VALU"]):
-            counters.update(pick(_pmc_pass(group, child, os.path.join(tmp, "s" + group[0]), 180), kernel_needle))
+            counters.update(pick(_pmc_pass(group, child, os.path.join(tmp, "s" + group[0]), left(120)), kernel_needle))
         counters["kernel_cycles"] = kernel_ms * 1e-3 * 2.4e9  # this run's HIP-event duration x the shader clock
         counters["source"] = "rocprofv3 --pmc, two passes of this run"
         return traffic, counters
@@ -202,6 +212,10 @@ def parse_args(argv=None):
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 "
                          "flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--group", action="store_true",
+                    help="N = 1 only: run the step of the N > 1 job -- process group (world size 1), the three "
+                         "partitionings, every collective issued (SECEDO_DIST_EXCHANGE_ALWAYS) -- so that the RCCL code "
+                         "paths execute on a one-GPU box; the line's rccl_world_size then comes from a real group")
     ap.add_argument("--only", default="both", choices=["both", "tiles", "chromosomes"],
                     help="N > 1: time only one of the two partitionings")
     ap.add_argument("--chunks", type=int, default=4,
@@ -234,7 +248,7 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def dry_run(args, rank, world):
+def dry_run(args, rank, world, emit):
     """What the ranks do before any GPU work, on the CPU: rendezvous, shard, exchange. Used by the tests to
     check that `python bench.py --gpus N` starts N ranks that find each other and cover the work once."""
     import torch
@@ -255,13 +269,13 @@ def dry_run(args, rank, world):
     else:
         parts = [mine]
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "world_size": world,
-                          "backend": "gloo" if world > 1 else "none",
-                          "entries": int(p.n_entries), "chromosomes": int(p.n_chr),
-                          "tiles": n_blocks * (n_blocks + 1) // 2,
-                          "shard_entries": [int(t[0]) for t in parts],
-                          "shard_chromosomes": [int(t[1]) for t in parts],
-                          "shard_tiles": [int(t[2]) for t in parts]}), flush=True)
+        emit({"dry_run": True, "n_gpus": world, "world_size": world,
+              "backend": "gloo" if world > 1 else "none",
+              "entries": int(p.n_entries), "chromosomes": int(p.n_chr),
+              "tiles": n_blocks * (n_blocks + 1) // 2,
+              "shard_entries": [int(t[0]) for t in parts],
+              "shard_chromosomes": [int(t[1]) for t in parts],
+              "shard_tiles": [int(t[2]) for t in parts]})
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -280,19 +294,35 @@ def main():
     from secedo_amd import distributed as sd
     from secedo_amd.synth import CONFIGS, synth_config
 
+    # ONE JSON line on stdout: libraries that write banners to file descriptor 1 (RCCL prints its version there when
+    # the first communicator is made) get stderr instead; the line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(record):
+        os.write(json_fd, (json.dumps(record) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     if args.dry_run:
-        return dry_run(args, rank, world)
+        return dry_run(args, rank, world, emit)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.group  # a process group exists and the collectives are issued
+    if dist_on:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            os.environ["SECEDO_DIST_EXCHANGE_ALWAYS"] = "1"
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     n_cells, n_loci, n_chr, gap, prob = CONFIGS[args.workload]
@@ -301,7 +331,7 @@ def main():
     out = torch.empty((n_cells, n_cells), dtype=torch.float64, device="cuda:%d" % local_rank)
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -327,7 +357,7 @@ def main():
         def step():
             if not args.packed_resident:
                 plan.prepare_resident(resident, n_cells, mfl, threads, block_cells)
-            if world == 1:
+            if not dist_on:
                 plan.assign_finalize(acc, *rates, norm, out)  # one rank: every tile, then the normalisation
                 return
             if by_chromosome:
@@ -358,7 +388,7 @@ def main():
             blocks.append(time.perf_counter() - t0)
         last_ms = plan.last_accumulate_ms()  # HIP events recorded by the library on the launch stream
         bt = torch.tensor(blocks, dtype=torch.float64, device=red_dev)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(bt, op=dist.ReduceOp.MAX)
         blocks = sorted(float(v) for v in bt)
         elapsed = blocks[len(blocks) // 2]
@@ -367,7 +397,7 @@ def main():
         own = by_chromosome or rank == 0
         cnt = torch.tensor([local_updates, local_pairs, plan.num_entries if own else 0,
                             plan.num_reads if own else 0], dtype=torch.int64, device=red_dev)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         updates, pairs, kept_entries, reads = (int(v.item()) for v in cnt)
@@ -442,7 +472,7 @@ def main():
             vals, _, info = state["eig"]
             step_s = elapsed / args.steps
             updates = int(cnt[0].item())
-            print(json.dumps({
+            emit({
                 "metric": "cell-pair x locus updates/sec (similarity matrix)", "value": updates / step_s,
                 "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -461,10 +491,10 @@ def main():
                 "spectral": {"smallest_eigenvalues": [float(v) for v in vals[:4]], **info},
                 "first_prepare_s": prepare_s, "step_includes_packing": not args.packed_resident,
                 "roofline": None, "cpu_baseline": None,
-            }), flush=True)
+            })
 
-    backend_name = "none" if world == 1 else ("RCCL (nccl)" if args.backend == "nccl" else args.backend)
-    pg_world = dist.get_world_size() if world > 1 else 1   # read back from the process group, not from argv
+    backend_name = "none" if not dist_on else ("RCCL (nccl)" if args.backend == "nccl" else args.backend)
+    pg_world = dist.get_world_size() if dist_on else 1   # read back from the process group, not from argv
     if world > 1 and args.workload == "C5" and not args.gathered:
         run_config5()
         dist.barrier()
@@ -473,18 +503,26 @@ def main():
 
     modes = []
     overlap_error = None
-    if world == 1:
+    if not dist_on:
         modes.append(run_mode(False))
     else:
         if args.only in ("both", "tiles"):
             modes.append(run_mode(False))
             if args.chunks > 1:
-                # (the side-stream exchange is the one branch the one-GPU box cannot rehearse under RCCL: if it
-                # raises -- on every rank alike -- the line is still made from the other partitionings)
+                # (the side-stream exchange runs under RCCL at world size 1 in tests/test_gpu_distributed.py; should it
+                # raise here the line is still made from the other partitionings -- the ranks agree on that first: an
+                # exception on ONE rank must not leave the others inside a collective of the next partitioning)
+                mode_o = None
                 try:
-                    modes.append(run_mode(False, overlapped=True))
+                    mode_o = run_mode(False, overlapped=True)
                 except Exception as exc:  # noqa: BLE001
                     overlap_error = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+                ok = torch.tensor([0 if mode_o is None else 1], dtype=torch.int64, device=red_dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 1:
+                    modes.append(mode_o)
+                elif overlap_error is None:
+                    overlap_error = "another rank failed in the overlapped exchange"
         if args.only in ("both", "chromosomes") and p.n_chr >= 2:
             modes.append(run_mode(True))
     best = min(modes, key=lambda m: m["elapsed"])
@@ -636,7 +674,7 @@ def main():
                 "updates_per_step": updates, "read_pairs_per_step": best["pairs"],
                 "block_cells": plan.block_cells, "tiles": plan.num_tiles,
                 "normalization": norm, "max_fragment_length": mfl, "num_threads": threads,
-                "parallelism": ("single GPU" if world == 1 else
+                "parallelism": ("single GPU" if not dist_on else
                                 "chromosomes/%d (packing + accumulation) + all-reduce of the int64 accumulator" % world
                                 if by_chromosome else "tiles/%d (replicated packing) + all-gather of the int64 "
                                                       "accumulator%s" % (world, " in %d chunks on a second stream behind "
@@ -690,8 +728,8 @@ def main():
                 except (subprocess.SubprocessError, ValueError, IndexError) as e:
                     line["cpp_dropin_call"] = {"error": str(e)[:300]}
             line["cpu_baseline"] = cpu_baseline(p, n_cells, mfl, rates, threads, 5e8)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        emit(line)
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -86,6 +86,7 @@ struct Scalars {
     uint32_t caps_wrong;        // the locus ranges were cut for the count tile, and the pair bound forbids it
     uint32_t n_multi_id;        // entries whose read id occurs more than once in its chromosome (k_compact_m)
     uint32_t reads_total;       // reads of the whole pileup (k_arank_m)
+    uint32_t n_wide;            // kept entries whose read reaches beyond their 8-locus windows (k_m_records / k_records)
     unsigned long long id_space;  // sum over chromosomes of (largest - smallest read id + 1)
     unsigned long long multi_entries;
     unsigned long long pair_bound;
@@ -1427,7 +1428,8 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
                           const uint8_t *read_base, const uint32_t *krank, const uint8_t *kflags, const uint32_t *rbeg,
                           const uint32_t *flushed, const uint32_t *locus_chr, const uint32_t *locus_rel, uint32_t B,
                           uint32_t lbits, uint4 *entry, uint32_t *entry32, uint32_t *mask32,
-                          uint32_t *entry_read) {
+                          uint32_t *entry_read, Scalars *sc) {
+    uint32_t n_wide = 0;
     for (uint32_t d = blockIdx.x * TPB + threadIdx.x; d < n; d += gridDim.x * TPB) {
         const unsigned long long key = skey2[d];
         const uint32_t k = sval2[d];
@@ -1481,7 +1483,9 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
         if (mask32)  // staged by the clustered-loci tile variant only
             mask32[d] = (masks & 0xFFu) | (((masks >> 16) & 0xFFu) << 8) | ((bases & 0xFFu) << 16)
                     | (((bases >> 16) & 0xFFu) << 24);
+        n_wide += wide ? 1u : 0u;
     }
+    if (n_wide) atomicAdd(&sc->n_wide, n_wide);
 }
 
 // ---- counting path: k_bin_rank + k_records in one pass ------------------------------------------------
@@ -1501,7 +1505,9 @@ __global__ void k_records(Raw in, const unsigned long long *skey2, const uint32_
 constexpr uint32_t kRecMulti = 1u << 30, kRecWide = 1u << 31;
 __global__ void k_m_records(Raw in, uint32_t n_kept_m, const uint32_t *t_read, const uint32_t *read_off,
                             const uint32_t *read_locus, const uint8_t *read_base, const uint32_t *krank,
-                            const uint8_t *kflags, const uint32_t *rbeg, const uint32_t *flushed, uint4 *m_rec) {
+                            const uint8_t *kflags, const uint32_t *rbeg, const uint32_t *flushed, uint4 *m_rec,
+                            Scalars *sc) {
+    uint32_t n_wide = 0;  // (rare: an atomic per thread that met one; the count rides on the packing's last read-back)
     for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_kept_m; k += gridDim.x * TPB) {
         const uint32_t fl = kflags[k], l = read_locus[k];
         const bool multi = (fl & 4u) != 0u;
@@ -1537,7 +1543,9 @@ __global__ void k_m_records(Raw in, uint32_t n_kept_m, const uint32_t *t_read, c
             bases |= (uint32_t)((read_base[j] >> 1) & 1u) << (16 + dist - 1);
         }
         m_rec[k] = make_uint4(meta, masks, bases, r);
+        n_wide += (meta & kRecWide) ? 1u : 0u;
     }
+    if (n_wide) atomicAdd(&sc->n_wide, n_wide);
 }
 
 struct RecordTables {  // by value: what a record needs beside the group's own entries
@@ -2205,7 +2213,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
         if (!err.empty()) return err;
         if (kept_m) {  // behind the flush chain and the range cutting, beside the placing pass
             hipLaunchKernelGGL(k_m_records, dim3(blocks_for(kept_m)), dim3(TPB), 0, pk.side, raw, kept_m, t_read, read_off,
-                               read_locus, read_base, krank, kflags, rbeg, flushed, m_rec);
+                               read_locus, read_base, krank, kflags, rbeg, flushed, m_rec, sc);
             HIP_OK(hipEventRecord(pk.ev_join, pk.side));
         }
         if (n_kept) {
@@ -2231,7 +2239,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             hipLaunchKernelGGL(k_records, dim3(blocks_for(n_kept)), dim3(TPB), 0, stream, raw, key2_b, val2_b, n_kept,
                                t_read, read_off, read_locus, read_base, krank, kflags, rbeg, flushed, locus_chr,
                                locus_rel, B, lbits, pk.entry.as<uint4>(), pk.entry32.as<uint32_t>(),
-                               pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr, pk.entry_read.as<uint32_t>());
+                               pk.stage_masks ? pk.mask32.as<uint32_t>() : nullptr, pk.entry_read.as<uint32_t>(), sc);
         }
     } else {
         // Counting path: the entries stay in k_bin_place's order and one pass, a thread per (block, locus)
@@ -2284,6 +2292,7 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
     pk.cap_entries = pk.count_tile ? caps.entries_counts : caps.entries_plain;
     pk.cap_loci = pk.count_tile ? caps.loci_counts : caps.loci_plain;
     pk.num_ranges = hsc.num_ranges;
+    pk.n_wide = hsc.n_wide;
     HIP_OK(hipGetLastError());
     return std::string();
 }

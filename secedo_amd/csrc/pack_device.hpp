@@ -51,6 +51,7 @@ struct DevicePacked {
     uint32_t num_cells = 0, block_cells = 0, num_blocks = 0, num_loci = 0, num_ranges = 0;
     uint64_t num_entries = 0, num_reads = 0, pair_bound = 0, multi_entries = 0;
     uint32_t max_read_entries = 0;  // kept entries of the longest read (before flush splits: an upper bound)
+    uint32_t n_wide = 0;            // kept entries whose read reaches beyond their 8-locus windows (C_WIDE in entry32)
     // per matrix row: sum over loci of (kept entries of the row at the locus)^2 -- pair_bound is its maximum.
     // Device packing: a pointer into the packing's scratch, valid until the next packing of this handle;
     // host packing: cell_sq_host. secedo_simmat_cell_squares() hands it out (shards that are added up

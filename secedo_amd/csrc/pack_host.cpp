@@ -261,6 +261,7 @@ std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t m
 
     pk.entry.resize(n_kept);
     pk.entry32.resize(n_kept);
+    pk.n_wide = 0;
     pk.mask32.resize(n_kept);
     pk.entry_read.resize(n_kept);
     std::vector<uint32_t> cursor(pk.blk_off);  // next free index per (block, locus)
@@ -303,6 +304,7 @@ std::string pack_pileup(const FlatPileupView &in, uint32_t num_cells, uint32_t m
             const uint32_t dst = cursor[static_cast<size_t>(blk) * stride + l]++;
             pk.entry[dst] = a;
             pk.entry_read[dst] = r;
+            pk.n_wide += wide ? 1u : 0u;
             pk.entry32[dst] = (sg.cell - blk * B) | (base << kC_BaseShift) | (sg.tail ? kC_Tail : 0u)
                     | (hi - lo > 1 ? kC_Multi : 0u) | (wide ? kC_Wide : 0u)
                     | ((l - range_begin_of[l]) << 16);

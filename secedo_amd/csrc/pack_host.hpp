@@ -89,6 +89,7 @@ struct PackedPileup {
     uint64_t pair_bound = 0;    // max over cells of sum_l n_cell(l)^2 (Cauchy-Schwarz bound)
     std::vector<uint64_t> cell_sq;  // the per-cell sums themselves
     uint64_t multi_entries = 0; // entries of reads with more than one kept entry
+    uint32_t n_wide = 0;        // kept entries whose read reaches beyond their 8-locus windows (kC_Wide in entry32)
     uint32_t max_read_entries = 0; // kept entries of the longest read: no read pair shares more loci
     bool any_window_overflow = false;
     bool stage_masks = false;

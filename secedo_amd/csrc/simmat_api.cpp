@@ -94,14 +94,27 @@ struct StagedUploads {
         const int k = next;
         next = (next + 1) % kSlots;
         hipError_t e = hipSuccess;
+        if (done[k] && used[k] && hipEventSynchronize(done[k]) != hipSuccess) {
+            // (the stream it was recorded on is gone -- destroyed streams finish their work first: a fresh event)
+            (void)hipGetLastError();
+            (void)hipEventDestroy(done[k]);
+            done[k] = nullptr;
+        }
+        used[k] = false;
         if (!done[k]) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
-        if (e == hipSuccess && used[k]) e = hipEventSynchronize(done[k]);
         if (e != hipSuccess) return e;
         host[k].assign(static_cast<const unsigned char *>(src), static_cast<const unsigned char *>(src) + bytes);
         e = hipMemcpyAsync(dst, host[k].data(), bytes, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipEventRecord(done[k], s);
         used[k] = (e == hipSuccess);
         return e;
+    }
+    // every upload so far has executed: called before the stream they were ordered on is destroyed
+    void settle() {
+        for (int k = 0; k < kSlots; ++k) {
+            if (done[k] && used[k] && hipEventSynchronize(done[k]) != hipSuccess) (void)hipGetLastError();
+            used[k] = false;
+        }
     }
     void destroy() {
         for (int k = 0; k < kSlots; ++k) {
@@ -608,6 +621,7 @@ int secedo_simmat_prepare(secedo_simmat_t *h, uint32_t num_cells, uint32_t max_f
         pk.cell_sq_host = std::move(hp_pk.cell_sq);
         pk.multi_entries = hp_pk.multi_entries;
         pk.max_read_entries = hp_pk.max_read_entries;
+        pk.n_wide = hp_pk.n_wide;
         pk.stage_masks = hp_pk.stage_masks;
         pk.count_tile = hp_pk.count_tile;
         pk.cap_entries = hp_pk.cap_entries;
@@ -929,18 +943,20 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
     if (h->pk.stage_masks && h->pk.block_cells == 64) {
         // accumulate_masks pairs from the 8-locus windows alone; the entries of reads that reach beyond them are
         // listed per cell block once per prepare for its second kernel (SECEDO_MASKS_KERNEL=0: accumulate_tiles)
-        static const bool allowed = [] { const char *e = std::getenv("SECEDO_MASKS_KERNEL"); return !(e && std::atoi(e) == 0); }();
+        static const bool allowed_env = [] { const char *e = std::getenv("SECEDO_MASKS_KERNEL"); return !(e && std::atoi(e) == 0); }();
+        // (the list's scan is one workgroup: beyond 1024 cell blocks -- more than num_cells allows today -- the pileup
+        // keeps to accumulate_tiles instead of failing the call)
+        const bool allowed = allowed_env && h->pk.num_blocks <= 1024u;
         if (allowed && !h->wide_known) {
+            // how many there are came with the packing's last read-back (DevicePacked::n_wide): count per block, scan
+            // and fill are enqueued behind each other, nothing waits for the device here
             const uint32_t nb = h->pk.num_blocks;
-            HIP_TRY(h->wide_tab.ensure(((size_t)3 * nb + 2) * 4));
-            uint32_t *cnt = h->wide_tab.as<uint32_t>(), *off = cnt + nb, *cur = off + nb + 1;
-            HIP_TRY(secedo::wide_count(a.entry32, a.blk_off, a.stride, nb, cnt, off, cur, s));
-            uint32_t total = 0;
-            HIP_TRY(hipMemcpyAsync(&total, off + nb, 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            h->n_wide = total;
-            if (total) {
-                HIP_TRY(h->wide_list.ensure((size_t)total * 4));
+            h->n_wide = h->pk.n_wide;
+            if (h->n_wide) {
+                HIP_TRY(h->wide_tab.ensure(((size_t)3 * nb + 2) * 4));
+                uint32_t *cnt = h->wide_tab.as<uint32_t>(), *off = cnt + nb, *cur = off + nb + 1;
+                HIP_TRY(secedo::wide_count(a.entry32, a.blk_off, a.stride, nb, cnt, off, cur, s));
+                HIP_TRY(h->wide_list.ensure((size_t)h->n_wide * 4));
                 HIP_TRY(secedo::wide_fill(a.entry32, a.blk_off, a.stride, nb, cur, h->wide_list.as<uint32_t>(), s));
             }
             h->wide_known = true;
@@ -1235,7 +1251,7 @@ int secedo_simmat_last_accumulate_ms(secedo_simmat_t *h, float *ms) {
 const char *secedo_simmat_pair_kernel(const secedo_simmat_t *h) {
     if (!h || !h->prepared) return "";
     if (h->pk.count_tile && !h->pk.stage_masks && secedo::counts_path_enabled()) return "accumulate_counts";
-    if (h->pk.stage_masks && h->pk.block_cells == 64) {
+    if (h->pk.stage_masks && h->pk.block_cells == 64 && h->pk.num_blocks <= 1024u) {
         const char *e = std::getenv("SECEDO_MASKS_KERNEL");
         if (!(e && std::atoi(e) == 0)) return "accumulate_masks";
     }
@@ -1476,6 +1492,7 @@ int compute_on_devices(const std::vector<int> &devices, const uint32_t *chr_locu
         t_ms[k * 4 + 3] = now_ms();
         barrier.wait();  // nobody reads this lane's accumulator any more
         if (me.s) (void)hipStreamSynchronize(me.s);
+        if (me.h) me.h->uploads.settle();  // (their events were recorded on streams that end here)
         for (hipEvent_t ev : me.done)
             if (ev) (void)hipEventDestroy(ev);
         if (me.s) (void)hipStreamDestroy(me.s);

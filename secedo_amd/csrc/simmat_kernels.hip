@@ -2454,7 +2454,7 @@ hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint
 
 hipError_t wide_count(const uint32_t *entry32, const uint32_t *blk_off, uint32_t stride, uint32_t num_blocks,
                       uint32_t *cnt, uint32_t *off, uint32_t *cur, hipStream_t stream) {
-    if (num_blocks == 0 || num_blocks > 1024) return hipErrorInvalidValue;
+    if (num_blocks == 0 || num_blocks > 1024) return hipErrorInvalidValue;  // (the caller keeps such pileups off this path)
     hipError_t e = hipMemsetAsync(cnt, 0, (size_t)num_blocks * 4, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_wide_count, dim3(16, num_blocks), dim3(256), 0, stream, entry32, blk_off, stride, cnt);

@@ -68,7 +68,34 @@ __global__ __launch_bounds__(1024) void k32(uint32_t iters, uint32_t mask, uint3
     if (threadIdx.x == 0) sink[blockIdx.x] = t32[1];
 }
 
+// The same instruction with NOTHING else in the loop (the generator above spends a quarter-rate multiply
+// and half a dozen other vector instructions per atomic, so its rate might be the vector pipes' and not the LDS
+// pipeline's): sixteen random addresses per lane, made before the loop and kept in registers, added to over and over
+// -- every wave instruction still has 64 different random addresses, the bank pattern differs between the sixteen.
 template <int CONFLICT_FREE>
+__global__ __launch_bounds__(1024) void k32r(uint32_t iters, uint32_t mask, uint32_t *sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    uint32_t *t32 = reinterpret_cast<uint32_t *>(raw);
+    for (uint32_t i = threadIdx.x; i <= mask; i += blockDim.x) t32[i] = 0;
+    __syncthreads();
+    uint32_t x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    uint32_t *p[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        x = x * 1664525u + 1013904223u;
+        uint32_t idx = (x >> 8) & mask;
+        if (CONFLICT_FREE) idx = (idx & ~31u) | (threadIdx.x & 31u);
+        p[j] = t32 + idx;
+    }
+    for (uint32_t it = 0; it < iters; it += 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) atomicAdd(p[j], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sink[blockIdx.x] = t32[1];
+}
+
+template <int CONFLICT_FREE, bool REGISTER_ADDRESSES = false>
 double run32(int threads, uint32_t cells, int blocks) {
     uint32_t *sink;
     hipMalloc(&sink, blocks * 4);
@@ -76,11 +103,12 @@ double run32(int threads, uint32_t cells, int blocks) {
     const size_t lds = (size_t)cells * 4;
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k32<CONFLICT_FREE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kern = REGISTER_ADDRESSES ? &k32r<CONFLICT_FREE> : &k32<CONFLICT_FREE>;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(a);
-        hipLaunchKernelGGL(k32<CONFLICT_FREE>, dim3(blocks), dim3(threads), lds, 0, iters, cells - 1, sink);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, 0, iters, cells - 1, sink);
         hipEventRecord(b);
         hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
@@ -96,20 +124,31 @@ int json_main() {
     struct Cfg { int threads; uint32_t cells; int per_cu; };
     const Cfg cfgs[] = {{256, 8192, 4}, {256, 8192, 8}, {512, 16384, 2}, {512, 16384, 4}, {1024, 16384, 1},
                         {1024, 16384, 2}, {1024, 32768, 1}};
-    double peak = 0, peak_cf = 0;
+    double peak = 0, peak_cf = 0, peak_reg = 0, peak_reg_cf = 0;
     printf("{\"device\": \"%s\", \"compute_units\": %d, \"clock_mhz\": %d, \"instruction\": \"ds_add_u32, 64 random addresses per "
            "wave instruction\", \"configs\": [", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000);
     bool first = true;
     for (const Cfg &c : cfgs) {
         const int blocks = prop.multiProcessorCount * c.per_cu * 4;  // four rounds of resident workgroups
         const double r = run32<0>(c.threads, c.cells, blocks), f = run32<1>(c.threads, c.cells, blocks);
+        const double rr = run32<0, true>(c.threads, c.cells, blocks), rf = run32<1, true>(c.threads, c.cells, blocks);
         peak = r > peak ? r : peak;
         peak_cf = f > peak_cf ? f : peak_cf;
+        peak_reg = rr > peak_reg ? rr : peak_reg;
+        peak_reg_cf = rf > peak_reg_cf ? rf : peak_reg_cf;
         printf("%s{\"threads\": %d, \"tile_bytes\": %u, \"workgroups_per_cu\": %d, \"random_gatomic_per_s\": %.1f, "
-               "\"bank_conflict_free_gatomic_per_s\": %.1f}", first ? "" : ", ", c.threads, c.cells * 4, c.per_cu, r * 1e-9, f * 1e-9);
+               "\"bank_conflict_free_gatomic_per_s\": %.1f, \"register_addresses_random_gatomic_per_s\": %.1f, "
+               "\"register_addresses_bank_conflict_free_gatomic_per_s\": %.1f}", first ? "" : ", ", c.threads, c.cells * 4,
+               c.per_cu, r * 1e-9, f * 1e-9, rr * 1e-9, rf * 1e-9);
         first = false;
     }
-    printf("], \"peak_random_gatomic_per_s\": %.1f, \"peak_bank_conflict_free_gatomic_per_s\": %.1f}\n", peak * 1e-9, peak_cf * 1e-9);
+    // the roofline's peak: the faster of the two generators at random addresses (what the LDS pipeline gives when the
+    // vector pipes ask nothing of the wave)
+    printf("], \"peak_generated_addresses_gatomic_per_s\": %.1f, \"peak_register_addresses_gatomic_per_s\": %.1f, "
+           "\"peak_register_addresses_bank_conflict_free_gatomic_per_s\": %.1f, "
+           "\"peak_random_gatomic_per_s\": %.1f, \"peak_bank_conflict_free_gatomic_per_s\": %.1f}\n", peak * 1e-9,
+           peak_reg * 1e-9, peak_reg_cf * 1e-9, (peak_reg > peak ? peak_reg : peak) * 1e-9,
+           (peak_reg_cf > peak_cf ? peak_reg_cf : peak_cf) * 1e-9);
     return 0;
 }
 
