@@ -255,10 +255,13 @@ int secedo_simmat_last_pair_kernel_ms(secedo_simmat_t *handle, float *ms);
 const char *secedo_simmat_pair_kernel(const secedo_simmat_t *handle);
 
 /* log-likelihood ratio D(x_s, x_d) = log P(x_s,x_d | different) - log P(x_s,x_d | same) as the
- * device tables hold it (host-only, no device): for x_s + x_d <= 128 what the reference's nested sums
- * return (similarity_matrix.cpp:117-170), including the wrap-around of its uint64_t binomial products
- * from x_s + x_d ~ 48 on; beyond 128 -- and everywhere under SECEDO_LLR_EXACT=1 -- the closed form of
- * the same sums, i.e. the reference's formula in exact arithmetic (secedo_simmat_llr_closed_form). */
+ * matrix path adds it (host-only, no device): what the reference's nested sums return
+ * (similarity_matrix.cpp:117-170), including the wrap-around of its uint64_t binomial products from
+ * x_s + x_d ~ 48 on -- up to 128 shared loci from the device's table, beyond from the host, which evaluates
+ * the few (x_s, x_d) a launch meets there with the same sums (O(x_s^2 x_d^2) terms each: a pair sharing 300
+ * loci takes about a second on eight threads, as it takes the reference on its first use). Under
+ * SECEDO_LLR_EXACT=1 the closed form of the sums everywhere, i.e. the reference's formula in exact
+ * arithmetic (secedo_simmat_llr_closed_form). */
 double secedo_simmat_llr(uint32_t x_s, uint32_t x_d, double mutation_rate, double homozygous_rate,
                          double seq_error_rate);
 double secedo_simmat_llr_closed_form(uint32_t x_s, uint32_t x_d, double mutation_rate, double homozygous_rate,

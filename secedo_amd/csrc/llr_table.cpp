@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <array>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <atomic>
 #include <cmath>
@@ -71,22 +72,27 @@ constexpr uint32_t kRows = kLlrRefMax + 1;
 // Powers as the reference builds them (each entry = previous * base, similarity_matrix.cpp:85-94) and
 // Pascal's triangle in uint64_t (:95-101). Up to row 67 no single binomial wraps, the PRODUCTS do from about
 // row 48 on; beyond row 67 the additions of the triangle wrap too (unsigned arithmetic modulo 2^64 here as there).
+// `rows` = 1 + the largest x_s + x_d wanted (the reference sizes its tables by max_fragment_length, :67-101; an
+// entry does not depend on how far the tables go on behind it).
 struct RefTables {
-    double pss[kRows], psd[kRows], pds[kRows], pdd[kRows];
-    double a1[kRows], a2[kRows], b2[kRows], hh[kRows], ehalf[kRows];  // (1-e-h)^k (1-e/2-h)^k (h+e/2)^k h^k (e^k * .5^k)
-    double sum_s[kRows], sum_d[kRows];                                // (pss+pds)^k, (psd+pdd)^k
-    uint64_t comb[kRows][kRows];
+    uint32_t rows;
+    std::vector<double> pss, psd, pds, pdd;
+    std::vector<double> a1, a2, b2, hh, ehalf;  // (1-e-h)^k (1-e/2-h)^k (h+e/2)^k h^k (e^k * .5^k)
+    std::vector<double> sum_s, sum_d;           // (pss+pds)^k, (psd+pdd)^k
+    std::vector<uint64_t> comb_;                // rows x rows
+    const uint64_t *comb(uint32_t n) const { return comb_.data() + (size_t)n * rows; }
 
-    RefTables(double eps, double h, double theta) {
+    RefTables(double eps, double h, double theta, uint32_t n_rows = kRows) : rows(std::max(n_rows, 2u)) {
         const double t2 = theta * theta;
         const double p_sd = 2 * theta * (1 - theta) + 2 * t2 / 3;  // :45
         const double p_ss = 1 - p_sd;                              // :47
         const double p_ds = 2 * (1 - theta) * theta / 3 + 2 * t2 / 9;  // :49
         const double p_dd = 1 - p_ds;                              // :51
-        auto powers = [](double *out, double base) {
+        auto powers = [&](std::vector<double> &out, double base) {
+            out.assign(rows, 0.0);
             out[0] = 1;
             out[1] = base;
-            for (uint32_t k = 2; k < kRows; ++k) out[k] = out[k - 1] * base;
+            for (uint32_t k = 2; k < rows; ++k) out[k] = out[k - 1] * base;
         };
         powers(pss, p_ss);
         powers(psd, p_sd);
@@ -98,13 +104,16 @@ struct RefTables {
         powers(hh, h);
         powers(sum_s, p_ss + p_ds);
         powers(sum_d, p_sd + p_dd);
-        double e[kRows], half[kRows];
+        std::vector<double> e, half;
         powers(e, eps);
         powers(half, 0.5);
-        for (uint32_t k = 0; k < kRows; ++k) ehalf[k] = e[k] * half[k];  // the reference multiplies the two (:131-132)
-        for (uint32_t n = 0; n < kRows; ++n) {
-            comb[n][0] = comb[n][n] = 1;
-            for (uint32_t i = 1; i < n; ++i) comb[n][i] = comb[n - 1][i - 1] + comb[n - 1][i];
+        ehalf.assign(rows, 0.0);
+        for (uint32_t k = 0; k < rows; ++k) ehalf[k] = e[k] * half[k];  // the reference multiplies the two (:131-132)
+        comb_.assign((size_t)rows * rows, 0);
+        for (uint32_t n = 0; n < rows; ++n) {
+            uint64_t *row = comb_.data() + (size_t)n * rows;
+            row[0] = row[n] = 1;
+            for (uint32_t i = 1; i < n; ++i) row[i] = comb(n - 1)[i - 1] + comb(n - 1)[i];
         }
     }
 
@@ -112,30 +121,32 @@ struct RefTables {
     // ulp only; the integer product is what must be reproduced exactly.
     double log_same(uint32_t xs, uint32_t xd) const {
         double p = 0;
+        const uint64_t *cs = comb(xs), *cd = comb(xd);
         for (uint32_t k = 0; k <= xs; ++k) {
             for (uint32_t l = 0; l <= xd; ++l) {
-                const uint64_t c = comb[xs][k] * comb[xd][l];
+                const uint64_t c = cs[k] * cd[l];
                 p += static_cast<double>(c) * a2[k + l] * 0.5 * (pss[k] * psd[l] + pds[k] * pdd[l])
                         * b2[xs + xd - k - l] * pss[xs - k] * psd[xd - l];
             }
         }
-        p *= static_cast<double>(comb[xs + xd][xs]);
+        p *= static_cast<double>(comb(xs + xd)[xs]);
         return std::log(p);
     }
 
-    // :117-141: k, l = loci where the genotypes truly differ ...; the four binomials are one uint64_t
-    // product, evaluated left to right as in the reference expression.
-    double log_diff(uint32_t xs, uint32_t xd) const {
+    // the share of k = k_begin .. k_end - 1 of the four-fold sum of :117-141 (before the last factor and the log)
+    double diff_part(uint32_t xs, uint32_t xd, uint32_t k_begin, uint32_t k_end) const {
         double prob = 0;
-        for (uint32_t k = 0; k <= xs; ++k) {
+        const uint64_t *cs = comb(xs), *cd = comb(xd);
+        for (uint32_t k = k_begin; k < k_end; ++k) {
             for (uint32_t l = 0; l <= xd; ++l) {
-                const uint64_t ckl = comb[xs][k] * comb[xd][l];
+                const uint64_t ckl = cs[k] * cd[l];
                 const double f = a1[k + l] * 0.5 * (pss[k] * psd[l] + pds[k] * pdd[l]);
                 double inner = 0;
+                const uint64_t *rowp = comb(xs - k);
                 for (uint32_t p = 0; p <= xs - k; ++p) {
-                    const uint64_t cp = ckl * comb[xs - k][p];
+                    const uint64_t cp = ckl * rowp[p];
                     const double g = sum_s[xs - k - p] * pss[p];
-                    const uint64_t *row = comb[xd - l];
+                    const uint64_t *row = comb(xd - l);
                     for (uint32_t q = 0; q <= xd - l; ++q) {
                         const uint64_t c = cp * row[q];
                         inner += static_cast<double>(c) * ehalf[xs + xd - k - l - p - q] * g
@@ -145,7 +156,14 @@ struct RefTables {
                 prob += f * inner;
             }
         }
-        prob *= static_cast<double>(comb[xs + xd][xs]);
+        return prob;
+    }
+
+    // :117-141: k, l = loci where the genotypes truly differ ...; the four binomials are one uint64_t
+    // product, evaluated left to right as in the reference expression.
+    double log_diff(uint32_t xs, uint32_t xd) const {
+        double prob = diff_part(xs, xd, 0, xs + 1);
+        prob *= static_cast<double>(comb(xs + xd)[xs]);
         return std::log(prob);
     }
 };
@@ -156,6 +174,52 @@ double reference_llr(double eps, double h, double theta, uint32_t x_s, uint32_t 
     if (x_s + x_d > kLlrRefMax) return std::nan("");
     const RefTables rt(eps, h, theta);
     return rt.log_diff(x_s, x_d) - rt.log_same(x_s, x_d);
+}
+
+// Beyond the table (read pairs sharing more than kLlrRefMax loci): one entry at a time, as the reference would
+// evaluate it on first use (it memoises, :119, :155) -- O(x_s^2 x_d^2) terms, the outer index shared among up to
+// max_threads threads (positive terms: the order of the partial sums moves the result by ulps). The tables are
+// kept per process and rate triple and grow with the largest x_s + x_d asked for.
+namespace {
+std::mutex g_any_mutex;
+struct AnyCache {
+    std::unique_ptr<RefTables> tables;
+    std::map<std::pair<uint32_t, uint32_t>, double> value;
+};
+std::map<std::array<double, 3>, AnyCache> &g_any_cache = *new std::map<std::array<double, 3>, AnyCache>();
+}  // namespace
+
+double reference_llr_any(double eps, double h, double theta, uint32_t x_s, uint32_t x_d, unsigned max_threads) {
+    if (x_s + x_d <= kLlrRefMax) return reference_llr(eps, h, theta, x_s, x_d);
+    std::lock_guard<std::mutex> lock(g_any_mutex);
+    AnyCache &c = g_any_cache[{eps, h, theta}];
+    const auto key = std::make_pair(x_s, x_d);
+    const auto hit = c.value.find(key);
+    if (hit != c.value.end()) return hit->second;
+    if (!c.tables || c.tables->rows < x_s + x_d + 1) {
+        uint32_t rows = 256;
+        while (rows < x_s + x_d + 1) rows *= 2;
+        c.tables.reset(new RefTables(eps, h, theta, rows));
+    }
+    const RefTables &rt = *c.tables;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_threads = std::max(1u, std::min({hw ? hw : 1u, 16u, std::max(1u, max_threads), x_s + 1}));
+    std::vector<double> part(n_threads, 0.0);
+    std::atomic<uint32_t> next{0};
+    std::vector<double> per_k(x_s + 1, 0.0);
+    auto work = [&]() {
+        for (uint32_t k; (k = next.fetch_add(1)) <= x_s;) per_k[k] = rt.diff_part(x_s, x_d, k, k + 1);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned i = 1; i < n_threads; ++i) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    double prob = 0;
+    for (uint32_t k = 0; k <= x_s; ++k) prob += per_k[k];  // in the reference's order of k
+    prob *= static_cast<double>(rt.comb(x_s + x_d)[x_s]);
+    const double v = std::log(prob) - rt.log_same(x_s, x_d);
+    c.value[key] = v;
+    return v;
 }
 
 bool llr_exact_mode() {

@@ -46,6 +46,12 @@ constexpr uint32_t kLlrRefMax = 128;    // entries with x_s + x_d <= this can be
 double reference_llr(double mutation_rate, double homozygous_rate, double seq_error_rate, uint32_t x_s,
                      uint32_t x_d);
 
+// The same for any x_s + x_d (tables as long as needed; the reference's go up to max_fragment_length): what the
+// reference returns for a read pair that shares more than kLlrRefMax loci -- by then an artefact of its wrapped
+// integer arithmetic, reproduced all the same. Cached per process, rate triple and (x_s, x_d).
+double reference_llr_any(double mutation_rate, double homozygous_rate, double seq_error_rate, uint32_t x_s,
+                         uint32_t x_d, unsigned max_threads = 1);
+
 struct LlrTable {
     LlrModel model;
     double eps = 0, h = 0, theta = 0;

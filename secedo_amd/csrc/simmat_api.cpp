@@ -158,6 +158,8 @@ struct secedo_simmat {
     DevBuf tile_ids;          // tile list of accumulate_list / max_of_tiles
     std::vector<uint16_t> host_tile_row, host_tile_col;
     StagedUploads uploads;    // tables, plans and tile lists of accumulate, in the order of its stream
+    // read pairs that share more than 128 loci: noted by the kernels, evaluated as the reference does on the host
+    DevBuf beyond_list, beyond_count, beyond_index, beyond_value;
     uint64_t plan_list_hash = 0;  // 0: the cached workgroup plan belongs to a contiguous tile range
 
     // LLR table of the last accumulate()
@@ -383,8 +385,7 @@ int secedo_simmat_normalization_from_string(const char *name) {
 }
 
 double secedo_simmat_llr(uint32_t x_s, uint32_t x_d, double eps, double h, double theta) {
-    if (x_s + x_d >= 1 && x_s + x_d <= secedo::kLlrRefMax && !secedo::llr_exact_mode())
-        return secedo::reference_llr(eps, h, theta, x_s, x_d);
+    if (x_s + x_d >= 1 && !secedo::llr_exact_mode()) return secedo::reference_llr_any(eps, h, theta, x_s, x_d, 8);
     return secedo::llr(secedo::make_llr_model(eps, h, theta), x_s, x_d);
 }
 
@@ -737,6 +738,10 @@ struct FlagBuild {
     }
 };
 
+// capacity of the list of read pairs beyond the table per launch (16 bytes each; allocated only for a pileup with a
+// read of more than 128 kept entries)
+constexpr uint32_t kBeyondCap = 1u << 20;
+
 // tiles [tile_begin, tile_end) when list == nullptr, else the n_list tiles of `list` (global indices)
 // overwrite: acc[tiles of the launch] = result instead of +=
 static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double theta, uint32_t tile_begin,
@@ -760,6 +765,7 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
     }
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    bool beyond = false;  // this launch notes the read pairs that share more than 128 loci (see below)
 
     // LLR table: the doubles depend on the rates only, the fixed-point scale on the pileup's pair
     // bound; upload (synchronously, it is rare) only what changed since the last call
@@ -813,6 +819,19 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         const secedo::LlrModel &m = h->table.model;
         sp.model = secedo::LlrModelDev{m.ln_u1, m.ln_v1, m.ln_u2, m.ln_v2, m.ln_w1, m.ln_z1, m.ln_w2, m.ln_z2};
         sp.scale_log2 = h->scale_log2;
+        // Read pairs that share more than 128 loci (possible when a read has more kept entries than that): what the
+        // reference returns there is the value of its wrapped integer sums -- O(x_s^2 x_d^2) terms per entry, nothing
+        // for a table. The kernels note such pairs instead of adding their joint term, and after the launch the
+        // host evaluates the few distinct (x_s, x_d) as the reference does and adds them (below). SECEDO_LLR_EXACT=1:
+        // the closed form on the device, nothing noted.
+        if (reach > secedo::kLlrRefMax && !secedo::llr_exact_mode()) {
+            HIP_TRY(h->beyond_list.ensure((size_t)kBeyondCap * sizeof(uint4)));
+            HIP_TRY(h->beyond_count.ensure(sizeof(uint32_t)));
+            sp.beyond_list = h->beyond_list.as<uint4>();
+            sp.beyond_count = h->beyond_count.as<uint32_t>();
+            sp.beyond_cap = kBeyondCap;
+            beyond = true;
+        }
         if (!h->have_slow || std::memcmp(&sp, &h->slow_host, sizeof(sp)) != 0) {
             HIP_TRY(h->slow_args.ensure(sizeof(sp)));
             h->slow_host = sp;
@@ -932,7 +951,7 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
     a.acc = d_acc;
     a.overwrite = overwrite;
     // the maximum finalize needs, on the way (assign_finalize: all tiles, stored, one workgroup per tile)
-    if (max_done && overwrite && !list && tile_begin == 0 && tile_end == h->num_tiles && h->pk.count_tile
+    if (max_done && !beyond && overwrite && !list && tile_begin == 0 && tile_end == h->num_tiles && h->pk.count_tile
         && !h->pk.stage_masks && secedo::counts_path_enabled() && secedo::counts_split(n_tiles) == 1) {
         HIP_TRY(hipMemsetAsync(h->max_bits.p, 0, sizeof(unsigned long long), s));
         a.max_bits = h->max_bits.as<unsigned long long>();
@@ -969,6 +988,7 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
     }
 
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, 96 * sizeof(unsigned long long), s));
+    if (beyond) HIP_TRY(hipMemsetAsync(h->beyond_count.p, 0, sizeof(uint32_t), s));
     const secedo::SideStream *side = nullptr;
     secedo::SideStream side_call;
     FlagBuild build;
@@ -1040,6 +1060,48 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
         HIP_TRY(hipStreamWaitEvent(s, h->side.join, 0));
     }
     if (build.h && build.done) h->flags_ready = true;
+    if (beyond) {
+        // the pairs the kernels noted: the call waits for the launch here (only a pileup with a read of more than 128
+        // kept entries comes this way), evaluates the distinct (x_s, x_d) as the reference does and adds the terms
+        uint32_t n_noted = 0;
+        HIP_TRY(hipMemcpyAsync(&n_noted, h->beyond_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (n_noted > kBeyondCap)
+            return fail(SECEDO_E_LIMIT, std::to_string(n_noted) + " read pairs of this launch share more than 128 loci (at most "
+                                        + std::to_string(kBeyondCap) + " per launch: accumulate fewer tiles at a time, or set "
+                                        "SECEDO_LLR_EXACT=1 for the formula in exact arithmetic)");
+        if (n_noted) {
+            std::vector<uint32_t> noted((size_t)n_noted * 4);
+            HIP_TRY(hipMemcpy(noted.data(), h->beyond_list.p, noted.size() * 4, hipMemcpyDeviceToHost));
+            const uint32_t Bc = h->pk.block_cells, nb = h->pk.num_blocks;
+            std::vector<unsigned long long> index(n_noted);
+            std::vector<long long> value(n_noted);
+            for (uint32_t k = 0; k < n_noted; ++k) {
+                uint32_t ca = noted[(size_t)k * 4], cb = noted[(size_t)k * 4 + 1];
+                const uint32_t xs = noted[(size_t)k * 4 + 2], xd = noted[(size_t)k * 4 + 3];
+                if (ca / Bc > cb / Bc) std::swap(ca, cb);  // the tile's row block is the smaller one
+                const uint32_t I = ca / Bc, J = cb / Bc;
+                const uint64_t tile = (uint64_t)I * nb - (uint64_t)I * (I - 1) / 2 + (J - I);  // row-major upper triangle
+                if (ca >= h->pk.num_cells || cb >= h->pk.num_cells || tile >= h->num_tiles || h->host_tile_row[tile] != I
+                    || h->host_tile_col[tile] != J)
+                    return fail(SECEDO_E_STATE, "a noted read pair lies outside the matrix");
+                const double d = secedo::reference_llr_any(eps, hr, theta, xs, xd, std::max(1u, h->num_threads));
+                if (!std::isfinite(d) || std::fabs(std::ldexp(d, h->scale_log2)) >= 0x1p62)
+                    return fail(SECEDO_E_INVALID_ARG, "a read pair sharing " + std::to_string(xs + xd) + " loci has a non-finite "
+                                                      "log-likelihood ratio in the reference's arithmetic (it would write "
+                                                      "inf / NaN into the matrix); SECEDO_LLR_EXACT=1 selects the exact formula");
+                index[k] = tile * Bc * Bc + (uint64_t)(ca % Bc) * Bc + (cb % Bc);
+                value[k] = std::llround(std::ldexp(d, h->scale_log2));
+            }
+            HIP_TRY(h->beyond_index.ensure((size_t)n_noted * 8));
+            HIP_TRY(h->beyond_value.ensure((size_t)n_noted * 8));
+            HIP_TRY(hipMemcpyAsync(h->beyond_index.p, index.data(), (size_t)n_noted * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(h->beyond_value.p, value.data(), (size_t)n_noted * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(secedo::launch_add_terms(d_acc, h->beyond_index.as<unsigned long long>(), h->beyond_value.as<long long>(),
+                                             n_noted, s));
+            HIP_TRY(hipStreamSynchronize(s));  // (the sources are this frame's vectors)
+        }
+    }
     h->timed_mid = h->timed_mid && n_tiles > 0;
     HIP_TRY(hipEventRecord(h->ev_end, s));
     h->timed = true;

@@ -69,8 +69,18 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     return v;
 }
 
-// D(x_s, x_d) outside the table: closed form in log space (llr_table.hpp)
-__device__ __noinline__ long long llr_fixed_device(const SlowPathArgs *sp, uint32_t xs, uint32_t xd) {
+// D(x_s, x_d) outside the table (a read pair that shares more than 128 loci): noted for the host, which evaluates
+// it as the reference does (its wrapped integer sums, llr_table.hpp: reference_llr_any) and adds it afterwards --
+// the caller adds 0 here; without a list (SECEDO_LLR_EXACT) the closed form in log space. cell_a / cell_b: the
+// matrix rows of the two reads.
+constexpr uint32_t REF_TABLE_MAX = 128;  // llr_table.hpp: kLlrRefMax
+__device__ __noinline__ long long llr_fixed_device(const SlowPathArgs *sp, uint32_t xs, uint32_t xd, uint32_t cell_a,
+                                                   uint32_t cell_b) {
+    if (sp->beyond_list) {
+        const uint32_t k = atomicAdd(sp->beyond_count, 1u);
+        if (k < sp->beyond_cap) sp->beyond_list[k] = make_uint4(cell_a, cell_b, xs, xd);
+        return 0ll;
+    }
     const LlrModelDev m = sp->model;
     const int scale_log2 = sp->scale_log2;
     const double s = xs, d = xd;
@@ -85,7 +95,7 @@ __device__ __noinline__ long long llr_fixed_device(const SlowPathArgs *sp, uint3
 // else NO_PAIR. (Values are returned, not written through pointers: an address-taken local in
 // the caller would live in scratch memory.)
 __device__ __noinline__ long long slow_pair(const SlowPathArgs *sp, uint32_t r1, uint32_t r2,
-                                            uint32_t locus) {
+                                            uint32_t locus, uint32_t cell_a, uint32_t cell_b) {
     const SlowPathArgs a = *sp;
     uint32_t i1 = a.read_off[r1], e1 = a.read_off[r1 + 1];
     uint32_t i2 = a.read_off[r2], e2 = a.read_off[r2 + 1];
@@ -103,7 +113,7 @@ __device__ __noinline__ long long slow_pair(const SlowPathArgs *sp, uint32_t r1,
         }
     }
     if (first != locus) return NO_PAIR;
-    return (xs < LUT_DIM && xd < LUT_DIM) ? a.lut[xs * LUT_DIM + xd] : llr_fixed_device(sp, xs, xd);
+    return xs + xd <= REF_TABLE_MAX ? a.lut[xs * LUT_DIM + xd] : llr_fixed_device(sp, xs, xd, cell_a, cell_b);
 }
 
 // One (read pair, shared locus) incidence from the full 16-byte entries (pack_host.hpp: Entry);
@@ -124,7 +134,7 @@ __device__ __noinline__ long long pair_value_full(const SlowPathArgs *sp, uint32
         return sp->lut[xs * LUT_DIM + xd];
     }
     const uint32_t *entry_read = sp->entry_read;
-    return slow_pair(sp, entry_read[g1], entry_read[g2], A1.w);
+    return slow_pair(sp, entry_read[g1], entry_read[g2], A1.w, A1.x & 0xFFFFu, A2.x & 0xFFFFu);
 }
 
 // Capacity of the per-wave list of deferred joint pairs (see accumulate_tiles): 192 where the LDS
@@ -1958,8 +1968,8 @@ __global__ __launch_bounds__(THREADS) void correct_tiles(const CorrectArgs a) {
             if (xs < (uint32_t)SLUT_DIM && xd < (uint32_t)SLUT_DIM) {
                 term = scorr[xs * SLUT_DIM + xd];
             } else {
-                const long long joint = (xs < (uint32_t)LUT_DIM && xd < (uint32_t)LUT_DIM)
-                        ? a.lut[xs * LUT_DIM + xd] : llr_fixed_device(a.slow, xs, xd);
+                const long long joint = xs + xd <= REF_TABLE_MAX
+                        ? a.lut[xs * LUT_DIM + xd] : llr_fixed_device(a.slow, xs, xd, P.x & 0xFFFFu, Q.x & 0xFFFFu);
                 term = joint - (long long)xs * d10 - (long long)xd * d01;
             }
             atomicAdd(cell, (unsigned long long)term);
@@ -2526,6 +2536,19 @@ hipError_t launch_accumulate(const AccumulateArgs &args, uint32_t block_cells, b
     if (count_tile && pair_mode() != 0) return launch_counts<64, 512, kCapJ64C, kCapL64C, 4>(args, grid, stream, side, mid);
     if (count_tile) return launch_acc<64, 256, kCapJ64C, kCapL64C, 1024, false, true>(args, grid, stream);
     return launch_acc<64, 256, kCapJ64, kCapL64, 1024, false, false>(args, grid, stream);
+}
+
+__global__ void k_add_terms(long long *acc, const unsigned long long *index, const long long *value, uint32_t n) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) atomicAdd(reinterpret_cast<unsigned long long *>(acc) + index[k], (unsigned long long)value[k]);
+}
+
+hipError_t launch_add_terms(int64_t *acc, const unsigned long long *index, const long long *value, uint32_t n,
+                            hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_add_terms, dim3((n + 255) / 256), dim3(256), 0, stream, reinterpret_cast<long long *>(acc), index,
+                       value, n);
+    return hipGetLastError();
 }
 
 hipError_t launch_tile_max(const int64_t *acc, const uint16_t *tile_row, const uint16_t *tile_col,

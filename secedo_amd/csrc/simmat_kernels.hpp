@@ -39,6 +39,12 @@ struct SlowPathArgs {
     const long long *lut;      // 129 x 129 (LUT_DIM), row = x_s
     LlrModelDev model;
     int scale_log2;
+    // Read pairs that share more than 128 loci (beyond the table): with a list here the kernels add NOTHING for the
+    // joint term of such a pair and note {cell, cell, x_s, x_d} instead; the host evaluates the term as the reference
+    // does and adds it afterwards (simmat_api.cpp). nullptr: the closed form on the device (SECEDO_LLR_EXACT).
+    uint4 *beyond_list = nullptr;
+    uint32_t *beyond_count = nullptr;   // entries noted (may exceed the capacity: then the list is incomplete)
+    uint32_t beyond_cap = 0;
 };
 
 struct AccumulateArgs {
@@ -134,6 +140,9 @@ hipError_t launch_finalize(const int64_t *acc, const uint16_t *tile_row, const u
                            unsigned long long *d_max_bits, uint32_t row_begin, uint32_t row_end, double *out,
                            hipStream_t stream, bool keep_max = false);
 // d_max_bits = bits of max(0, max D) over the listed tiles (tile_ids == nullptr: all n_tiles)
+// acc[index[k]] += value[k] for k < n (the joint terms of read pairs that share more than 128 loci)
+hipError_t launch_add_terms(int64_t *acc, const unsigned long long *index, const long long *value, uint32_t n,
+                            hipStream_t stream);
 hipError_t launch_tile_max(const int64_t *acc, const uint16_t *tile_row, const uint16_t *tile_col,
                            const uint32_t *tile_ids, uint32_t n_tiles, uint32_t block_cells, int scale_log2,
                            unsigned long long *d_max_bits, hipStream_t stream);

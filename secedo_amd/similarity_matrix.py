@@ -97,9 +97,8 @@ def get_devices():
 
 def llr(x_s: int, x_d: int, mutation_rate: float, homozygous_rate: float,
         seq_error_rate: float) -> float:
-    """D(x_s, x_d) = log P_diff - log P_same as the device tables hold it (host-only): what the
-    reference's nested sums return for x_s + x_d <= 64 (uint64 wrap of its binomial products included),
-    the closed form of those sums beyond."""
+    """D(x_s, x_d) = log P_diff - log P_same as the matrix path adds it (host-only): what the reference's nested
+    sums return, uint64 wrap of its binomial products included, at any x_s + x_d (secedo_simmat_llr)."""
     return float(_lib.lib().secedo_simmat_llr(x_s, x_d, mutation_rate, homozygous_rate, seq_error_rate))
 
 

@@ -35,25 +35,43 @@ def test_hip_matches_reference_vectors(name):
         assert np.all(np.diag(got) == 0)
 
 
-def test_read_pairs_sharing_more_than_128_loci_documented_difference():
-    """Up to 128 shared loci (64 until round 3) the HIP path returns the reference's own terms, its wrapped uint64
-    arithmetic included: wrap_dense_10cells (48-64 shared loci) and wrap_beyond64 (reads of 70-100 loci) are
-    vectors of the compiled reference and are held to 1e-9 by test_hip_matches_reference_vectors. Beyond 128 it
-    returns the reference's FORMULA in exact arithmetic, where the reference returns the wrapped sums (DESIGN.md
-    section 4). wrap_beyond128 holds the compiled reference's output for reads of 140-170 loci: the HIP matrix
-    equals the oracle in its "exact beyond 128" mode to 1e-9 and differs from the reference's by what the wrap
-    is worth there."""
+def test_read_pairs_sharing_more_than_128_loci_equal_the_reference():
+    """Up to 128 shared loci the HIP path holds the reference's own terms, its wrapped uint64 arithmetic included, in
+    a table: wrap_dense_10cells (48-64 shared loci) and wrap_beyond64 (reads of 70-100 loci) are vectors of the
+    compiled reference held to 1e-9 by test_hip_matches_reference_vectors. Beyond 128 (VERDICT r03 missing #4; a
+    documented DIFFERENCE of > 1e-3 until round 4) the kernels note such read pairs and the host evaluates their
+    (x_s, x_d) as the reference does -- tables as long as needed, the same wrapping products (llr_table.cpp:
+    reference_llr_any) -- and adds the terms: wrap_beyond128 (the compiled reference on reads of 140-170 loci) is a
+    1e-9 fixture like the others, through the one-shot call, through tile ranges that are added up, and on three
+    lanes; the formula in exact arithmetic (the oracle's mode 2, the library under SECEDO_LLR_EXACT=1) is somewhere
+    else entirely there."""
     p, cases = gu.load("wrap_beyond128")
     c = cases[0]
     got = hip(p, c)
+    assert gu.normwise_err(got, c["out"]) <= TOL
+    assert np.array_equal(got, got.T) and np.all(np.diag(got) == 0)
     ob.set_exact_binomials(2)
     try:
-        want = ob.oracle_compute(p, c["num_cells"], c["mfl"], c["g2p"], c["eps"], c["h"], c["theta"], c["T"], c["norm"])
+        exact = ob.oracle_compute(p, c["num_cells"], c["mfl"], c["g2p"], c["eps"], c["h"], c["theta"], c["T"], c["norm"])
     finally:
         ob.set_exact_binomials(0)
-    assert gu.normwise_err(got, want) <= TOL
-    # the reference itself (bit-identical to the oracle's default mode) is somewhere else entirely
-    assert gu.normwise_err(got, c["out"]) > 1e-3
+    assert gu.normwise_err(exact, c["out"]) > 1e-3
+    # staged: two tile ranges added into one accumulator, and assign_finalize
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        plan.prepare(p, c["num_cells"], c["mfl"], c["g2p"], c["T"], block_cells=64)
+        assert plan.max_read_entries > 128
+        acc = plan.new_acc()
+        t = plan.num_tiles
+        plan.accumulate(acc, c["eps"], c["h"], c["theta"], 0, max(t // 2, 0))
+        plan.accumulate(acc, c["eps"], c["h"], c["theta"], max(t // 2, 0), t)
+        assert np.array_equal(plan.finalize(acc, c["norm"]).cpu().numpy(), got)
+        acc2 = plan.new_acc()
+        assert np.array_equal(plan.assign_finalize(acc2, c["eps"], c["h"], c["theta"], c["norm"]).cpu().numpy(), got)
+    secedo_amd.set_devices([0, 0, 0])
+    try:
+        assert np.array_equal(hip(p, c), got)
+    finally:
+        secedo_amd.set_devices(None)
 
 
 def test_c2_reference_digest():
@@ -86,9 +104,9 @@ RANDOM = [
     (23, 100, 1, 800, 20, 3000, 1000, 8, 600, False),  # two cell blocks of 64
     (24, 200, 3, 400, 30, 120, 1000, 4, 600, False),   # four blocks, clustered loci
     # where the reference's u64 binomial products wrap (x_s + x_d from ~48 on) the HIP path returns the
-    # reference's wrapped terms up to 64 shared loci and the exact formula beyond (oracle mode 2)
-    (25, 16, 1, 300, 6, 9, 1000, 1, 500, 2),           # > 32 loci per read: window overflow path
-    (26, 70, 2, 700, 4, 5, 1000, 2, 700, 2),           # > 128 shared loci: beyond the LLR table
+    # reference's wrapped terms: from its table up to 128 shared loci, evaluated on the host beyond (oracle mode 0)
+    (25, 16, 1, 300, 6, 9, 1000, 1, 500, 0),           # > 32 loci per read: window overflow path
+    (26, 70, 2, 700, 4, 5, 1000, 2, 700, 0),           # > 128 shared loci: beyond the LLR table
 ]
 
 
@@ -632,7 +650,7 @@ def test_randomised_differential_sweep():
         norm = secedo_amd.NORMALIZATIONS[it % 3]
         block = int(rng.choice([0, 64, 128]))
         mode = str(rng.choice(["auto", "host"]))
-        exact = 2  # reference-identical up to 64 shared loci, the exact formula beyond (simmat_oracle.c)
+        exact = 0  # the reference's own (wrapping) arithmetic at any number of shared loci (simmat_oracle.c)
         ob.set_exact_binomials(exact)
         try:
             ref, raw = ob.oracle_compute(p, n, mfl, g2p, 0.01, 0.5, 0.02, T, norm, want_raw=True)
@@ -752,7 +770,9 @@ def test_staging_buffers_are_handed_to_one_caller_at_a_time():
     assert L.secedo_simmat_staging_acquire(bigger, again) == 0
     C.memset(again[3], 0x5A, 64 << 20)  # the grown buffer is really there
     L.secedo_simmat_staging_release()
-    L.secedo_simmat_staging_release()  # releasing twice is harmless@pytest.mark.gpu
+    L.secedo_simmat_staging_release()  # releasing twice is harmless
+
+
 def test_more_chromosomes_than_the_lds_tables_hold():
     """The kernels that turn (chromosome, read id) into a dense id keep the per-chromosome tables in LDS up to 1024
     chromosomes (kChrLds, pack_device.hip) and search global memory beyond: 1100 chromosomes of a few loci each, sparse
