@@ -154,6 +154,7 @@ struct secedo_simmat {
     bool wide_known = false;                                  // clustered loci: the reads that reach beyond their windows ...
     uint32_t n_wide = 0;                                      // ... their entries, listed per cell block
     DevBuf wide_tab, wide_list;
+    DevBuf mk_words;                                          // ... the entries' words for accumulate_masks (y | xcol | xrow)
     DevBuf own_acc, own_out;  // used by the one-shot entry point only
     DevBuf tile_ids;          // tile list of accumulate_list / max_of_tiles
     std::vector<uint16_t> host_tile_row, host_tile_col;
@@ -978,7 +979,18 @@ static int accumulate_impl(secedo_simmat_t *h, double eps, double hr, double the
                 HIP_TRY(h->wide_list.ensure((size_t)h->n_wide * 4));
                 HIP_TRY(secedo::wide_fill(a.entry32, a.blk_off, a.stride, nb, cur, h->wide_list.as<uint32_t>(), s));
             }
+            // ... and the words the kernel pairs from, once per prepare
+            const size_t ne = (size_t)h->pk.num_entries;
+            HIP_TRY(h->mk_words.ensure(std::max<size_t>(ne, 1) * 12));
+            HIP_TRY(secedo::masks_words(a.entry32, a.mask32, (uint32_t)ne, h->mk_words.as<uint32_t>(),
+                                        h->mk_words.as<uint32_t>() + ne, h->mk_words.as<uint32_t>() + 2 * ne, s));
             h->wide_known = true;
+        }
+        if (allowed) {
+            const size_t ne = (size_t)h->pk.num_entries;
+            a.mk_y = h->mk_words.as<uint32_t>();
+            a.mk_xcol = a.mk_y + ne;
+            a.mk_xrow = a.mk_y + 2 * ne;
         }
         a.masks_kernel = allowed;
         if (allowed && h->n_wide) {

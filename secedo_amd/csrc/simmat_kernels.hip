@@ -1260,7 +1260,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
     uint32_t ring_head = 0, ring_tail = 0;          // wave-uniform, free-running
 
     // the next range, in flight in registers while the current one is paired
-    uint32_t pJ[JPT], pMj[JPT], pI[JPT], pMi[JPT], pO[OPT];
+    uint32_t pJ[JPT], pMj[JPT], pI[JPT], pXi[JPT], pMi[JPT], pO[OPT];
     uint32_t n_la = 0, n_lb = 0, n_ib = 0, n_ie = 0, n_jb = 0, n_je = 0, n_dsh = 0;
     bool n_staged = false;
     uint32_t q_la = 0, q_lb = 0;  // locus span of the range `ahead` holds the offsets of
@@ -1287,9 +1287,10 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
                 && (n_lb - n_la) <= (uint32_t)CAPL;
         // buffer loads: the descriptor bounds the slice, a lane past the end gets 0 (see accumulate_counts)
         if (n_staged) {
+            // (the column entries' words as masks_words() made them once per prepare: x with the cell's byte offset, y)
             const int nj = (int)((n_je - n_jb) * 4u);
-            const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.entry32 + n_jb), 0, nj, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.mask32 + n_jb), 0, nj, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rj = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.mk_xcol + n_jb), 0, nj, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.mk_y + n_jb), 0, nj, 0x00020000);
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<uint32_t *>(offJ + n_la), 0, (int)((n_lb - n_la + 1u) * 4u), 0x00020000);
 #pragma unroll
@@ -1304,12 +1305,15 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
     };
     auto prefetch_rows = [&]() {
         if (n_staged) {
+            // (the row entries: entry32 for the locus, the cell and the wide flag, and their two words in the row form)
             const int ni = (int)((n_ie - n_ib) * 4u);
             const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.entry32 + n_ib), 0, ni, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.mask32 + n_ib), 0, ni, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.mk_xrow + n_ib), 0, ni, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.mk_y + n_ib), 0, ni, 0x00020000);
 #pragma unroll
             for (int k = 0; k < JPT; ++k) {
                 pI[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, (int)(tid * 4u), k * THREADS * 4, 0);
+                pXi[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rx, (int)(tid * 4u), k * THREADS * 4, 0);
                 pMi[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rm, (int)(tid * 4u), k * THREADS * 4, 0);
             }
         }
@@ -1498,8 +1502,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
             static_assert(JPT * THREADS <= CAPJ && OPT * THREADS <= CAPL + 2, "unconditional staging stores");
 #pragma unroll
             for (int k = 0; k < JPT; ++k)
-                sJ[tid + k * THREADS] = make_uint2(masks_flags(pJ[k], pMj[k]) | ((pJ[k] & C_CELL) << 3),
-                                                   masks_planes(pMj[k]));
+                sJ[tid + k * THREADS] = make_uint2(pJ[k], pMj[k]);
 #pragma unroll
             for (int k = 0; k < OPT; ++k) sOff[tid + k * THREADS] = (uint16_t)(pO[k] - jb);
         }
@@ -1522,8 +1525,8 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
                 const uint32_t c = (i < nI && j1 > j0 && (rec & C_WIDE) == 0u) ? j1 - j0 : 0u;
                 any_wide |= c;
                 item[k] = (j0 & MK_J_MASK) | ((rec & C_CELL) << MK_ROW_SHIFT) | (c << MK_C_SHIFT);
-                ix[k] = masks_flags(rec, pMi[k]) | MX_DEAD | ((pMi[k] >> 8) & 0xFFu);
-                iy[k] = masks_planes(pMi[k]);
+                ix[k] = pXi[k];
+                iy[k] = pMi[k];
             }
             // wide items (32 column entries or more): the whole wave pairs one row entry with 64 at a time
             if (__ballot(any_wide >= IT_WIDE)) {
@@ -1641,6 +1644,22 @@ __global__ __launch_bounds__(THREADS) void accumulate_masks(const AccumulateArgs
             atomicAdd(&a.counters[0], u);
             atomicAdd(&a.counters[1], q);
         }
+    }
+}
+
+// The two words of every packed entry as accumulate_masks pairs from them, made ONCE per prepare (a pass over the
+// packed entries: 8 bytes read, 12 written) instead of by every workgroup for every entry of its row and of its column
+// block -- 125 times each on C3 clustered, a tenth of the kernel's vector instructions: y = the base planes, x in
+// the column form (low half: the cell's byte offset in a tile row; dead = the read reaches beyond its windows) and
+// in the row form (low half: next8; dead set).
+__global__ __launch_bounds__(256) void k_masks_words(const uint32_t *entry32, const uint32_t *mask32, uint32_t n,
+                                                    uint32_t *y, uint32_t *xcol, uint32_t *xrow) {
+    for (uint32_t d = blockIdx.x * 256 + threadIdx.x; d < n; d += gridDim.x * 256) {
+        const uint32_t e = entry32[d], m = mask32[d];
+        const uint32_t f = masks_flags(e, m);
+        y[d] = masks_planes(m);
+        xcol[d] = f | ((e & C_CELL) << 3);
+        xrow[d] = f | MX_DEAD | ((m >> 8) & 0xFFu);
     }
 }
 
@@ -2459,6 +2478,14 @@ hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint
         const uint32_t blocks = (uint32_t)std::min<size_t>((n_off + 255) / 256, 256 * 32);
         hipLaunchKernelGGL(flagged_groups, dim3(blocks), dim3(256), 0, stream, blk_off, n_off, pre, grp);
     }
+    return hipGetLastError();
+}
+
+hipError_t masks_words(const uint32_t *entry32, const uint32_t *mask32, uint32_t n_entries, uint32_t *y, uint32_t *xcol,
+                       uint32_t *xrow, hipStream_t stream) {
+    if (n_entries == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<size_t>(((size_t)n_entries + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_masks_words, dim3(blocks), dim3(256), 0, stream, entry32, mask32, n_entries, y, xcol, xrow);
     return hipGetLastError();
 }
 

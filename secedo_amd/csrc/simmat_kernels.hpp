@@ -81,6 +81,7 @@ struct AccumulateArgs {
     bool overwrite = false;                 // acc[tiles of the launch] = result (no need to zero them first)
     bool masks_kernel = false;              // staged masks: accumulate_masks (+ wide_pairs) instead of accumulate_tiles
     uint32_t masks_slot_asm = 1;            // accumulate_masks: the hand-written pair slots (SECEDO_MASKS_SLOT_ASM=0: off)
+    const uint32_t *mk_y = nullptr, *mk_xcol = nullptr, *mk_xrow = nullptr;  // ... the entries' words (masks_words)
     const uint32_t *wide_off = nullptr;     // num_blocks + 1: the C_WIDE entries per cell block ...
     const uint32_t *wide_list = nullptr;    // ... their entry indices (null: none)
     // counts path, one workgroup per tile (counts_split(n_tiles) == 1), all tiles in one launch: max(0, max D) of
@@ -106,6 +107,10 @@ hipError_t build_flagged_lists(const uint32_t *entry32, const uint4 *entry, uint
 
 StageGeometry stage_geometry(uint32_t block_cells);
 // The entries flagged C_WIDE (their read reaches beyond the 8-locus windows), listed per cell block for
+// accumulate_masks' operands: per packed entry the base planes and the flag word in column and in row form, made once
+// per prepare from entry32 / mask32
+hipError_t masks_words(const uint32_t *entry32, const uint32_t *mask32, uint32_t n_entries, uint32_t *y, uint32_t *xcol,
+                       uint32_t *xrow, hipStream_t stream);
 // accumulate_masks' second kernel: wide_count leaves cnt[num_blocks], off[num_blocks + 1] (exclusive scan; the total
 // in off[num_blocks]) and the fill cursors cur[num_blocks]; wide_fill writes the entry indices (room for the total).
 hipError_t wide_count(const uint32_t *entry32, const uint32_t *blk_off, uint32_t stride, uint32_t num_blocks,
