@@ -1507,11 +1507,19 @@ __global__ void k_m_records(Raw in, uint32_t n_kept_m, const uint32_t *t_read, c
                             const uint32_t *read_locus, const uint8_t *read_base, const uint32_t *krank,
                             const uint8_t *kflags, const uint32_t *rbeg, const uint32_t *flushed, uint4 *m_rec,
                             Scalars *sc) {
+    // the chromosomes' first loci from LDS (up to 1024 of them): searched in global memory the chromosome of an entry
+    // was a chain of dependent loads in front of everything else the thread does (C3 clustered: 68 M entries)
+    __shared__ uint32_t s_chr[1025];
+    const bool chr_lds = in.n_chr <= 1024u;
+    if (chr_lds)
+        for (uint32_t i = threadIdx.x; i <= in.n_chr; i += TPB) s_chr[i] = in.chr_locus_off[i];
+    __syncthreads();
     uint32_t n_wide = 0;  // (rare: an atomic per thread that met one; the count rides on the packing's last read-back)
     for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_kept_m; k += gridDim.x * TPB) {
         const uint32_t fl = kflags[k], l = read_locus[k];
         const bool multi = (fl & 4u) != 0u;
-        const uint32_t chr = last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
+        const uint32_t chr = chr_lds ? last_le<uint32_t>(s_chr, in.n_chr + 1, l)
+                                     : last_le<uint32_t>(in.chr_locus_off, in.n_chr + 1, l);
         const bool tail = krank[k] - rbeg[chr] >= flushed[chr];
         // the read's list of kept entries: only a multi-locus read has neighbours to look for
         uint32_t r = 0, lo = k, hi = k + 1;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""counters_json.py <dir> -- profiles/r03_counters.json from the SQ counter tables tools/pmc.sh left under <dir>
+"""counters_json.py <dir> -- profiles/r04_counters.json from the SQ counter tables tools/pmc.sh left under <dir>
 (pmc_C3.txt, pmc_C3_clustered.txt): per workload the per-dispatch counters of the dominant accumulate kernel,
 and kernel_cycles = its average duration in the kernel stats of the same run x the shader clock."""
 import csv

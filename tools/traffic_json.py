@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""traffic_json.py <dir> -- profiles/r03_traffic.json from the FETCH_SIZE / WRITE_SIZE passes that
-tools/refresh_profiles_r03.sh left under <dir>: per accumulate_tiles launch, with the counters calibrated
+"""traffic_json.py <dir> -- profiles/r04_traffic.json from the FETCH_SIZE / WRITE_SIZE passes that
+tools/refresh_profiles_r04.sh left under <dir>: per accumulate_tiles launch, with the counters calibrated
 on a known 1 GiB stream in the same run (tools/fetch_calib.hip) as MI355X_MICROARCH.md (HBM) prescribes."""
 import collections
 import csv
