@@ -933,7 +933,69 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
             for (int u = 0; u < GROUP; ++u) in[u] = __ballot(c > (uint32_t)u);
             const unsigned long long more = __ballot(c > (uint32_t)GROUP);
             // (the wave-uniform `diag` flag is tested once per group, not once per slot)
-            if (SLOT_ASM && !DIAG) {
+            if (SLOT_ASM && !DIAG && (GROUP == 4 || GROUP == 2)) {
+                // The slots of a group as ONE block (round 4): the compares, addresses and values of all slots under
+                // the group's exec -- a lane that does not take part computes garbage nobody adds --, each compare
+                // into a scalar pair of its own, and only the ds_add under the slot's lanes. Per slot that is one
+                // s_mov instead of s_and_saveexec + s_nop + s_mov: the scalar unit, which a CU has once, was busy
+                // 47 % of the pair kernel, and the nop sat in front of every value (the SDWA compare's result must
+                // not be read by the next instruction; here four or more instructions lie between).
+                const uint32_t rbase = rec9 >> C_BASE_SHIFT, row_addr = lds_base + row_byte;
+#pragma unroll
+                for (int u = 0; u < GROUP; ++u) upd_w += (uint32_t)__popcll(in[u]);
+                uint32_t a0, a1, a2, a3, v0, v1, v2, v3;
+                unsigned long long saved, q0, q1, q2, q3;
+                if (GROUP == 4) {
+                    asm volatile("v_cmp_eq_u32_sdwa %[q0], %[w0], %[rb] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                                 "v_cmp_eq_u32_sdwa %[q1], %[w1], %[rb] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                                 "v_cmp_eq_u32_sdwa %[q2], %[w2], %[rb] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                                 "v_cmp_eq_u32_sdwa %[q3], %[w3], %[rb] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                                 "v_add_u32_sdwa %[a0], %[row], %[w0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                                 "v_add_u32_sdwa %[a1], %[row], %[w1] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                                 "v_add_u32_sdwa %[a2], %[row], %[w2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                                 "v_add_u32_sdwa %[a3], %[row], %[w3] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                                 "v_cndmask_b32_e64 %[v0], %[k], 1, %[q0]\n\t"
+                                 "v_cndmask_b32_e64 %[v1], %[k], 1, %[q1]\n\t"
+                                 "v_cndmask_b32_e64 %[v2], %[k], 1, %[q2]\n\t"
+                                 "v_cndmask_b32_e64 %[v3], %[k], 1, %[q3]\n\t"
+                                 "s_mov_b64 %[saved], exec\n\t"
+                                 "s_mov_b64 exec, %[in0]\n\t"
+                                 "ds_add_u32 %[a0], %[v0]\n\t"
+                                 "s_mov_b64 exec, %[in1]\n\t"
+                                 "ds_add_u32 %[a1], %[v1]\n\t"
+                                 "s_mov_b64 exec, %[in2]\n\t"
+                                 "ds_add_u32 %[a2], %[v2]\n\t"
+                                 "s_mov_b64 exec, %[in3]\n\t"
+                                 "ds_add_u32 %[a3], %[v3]\n\t"
+                                 "s_mov_b64 exec, %[saved]"
+                                 : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [v0] "=&v"(v0), [v1] "=&v"(v1),
+                                   [v2] "=&v"(v2), [v3] "=&v"(v3), [saved] "=&s"(saved), [q0] "=&s"(q0), [q1] "=&s"(q1),
+                                   [q2] "=&s"(q2), [q3] "=&s"(q3)
+                                 : [w0] "v"(w[0]), [w1] "v"(w[1 % GROUP]), [w2] "v"(w[2 % GROUP]), [w3] "v"(w[3 % GROUP]),
+                                   [rb] "v"(rbase), [row] "v"(row_addr), [k] "v"(0x10000u), [in0] "s"(in[0]),
+                                   [in1] "s"(in[1 % GROUP]), [in2] "s"(in[2 % GROUP]), [in3] "s"(in[3 % GROUP])
+                                 : "memory");
+                } else {
+                    asm volatile("v_cmp_eq_u32_sdwa %[q0], %[w0], %[rb] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                                 "v_cmp_eq_u32_sdwa %[q1], %[w1], %[rb] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                                 "v_add_u32_sdwa %[a0], %[row], %[w0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                                 "v_add_u32_sdwa %[a1], %[row], %[w1] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                                 "s_mov_b64 %[saved], exec\n\t"
+                                 "v_cndmask_b32_e64 %[v0], %[k], 1, %[q0]\n\t"
+                                 "v_cndmask_b32_e64 %[v1], %[k], 1, %[q1]\n\t"
+                                 "s_mov_b64 exec, %[in0]\n\t"
+                                 "ds_add_u32 %[a0], %[v0]\n\t"
+                                 "s_mov_b64 exec, %[in1]\n\t"
+                                 "ds_add_u32 %[a1], %[v1]\n\t"
+                                 "s_mov_b64 exec, %[saved]"
+                                 : [a0] "=&v"(a0), [a1] "=&v"(a1), [v0] "=&v"(v0), [v1] "=&v"(v1), [saved] "=&s"(saved),
+                                   [q0] "=&s"(q0), [q1] "=&s"(q1)
+                                 : [w0] "v"(w[0]), [w1] "v"(w[1 % GROUP]), [rb] "v"(rbase), [row] "v"(row_addr), [k] "v"(0x10000u),
+                                   [in0] "s"(in[0]), [in1] "s"(in[1 % GROUP])
+                                 : "memory");
+                    (void)a2; (void)a3; (void)v2; (void)v3; (void)q2; (void)q3;
+                }
+            } else if (SLOT_ASM && !DIAG) {
                 const uint32_t rbase = rec9 >> C_BASE_SHIFT, row_addr = lds_base + row_byte;
 #pragma unroll
                 for (int u = 0; u < GROUP; ++u) pair_slot_asm(rbase, row_addr, w[u], in[u]);
