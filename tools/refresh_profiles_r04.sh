@@ -58,5 +58,7 @@ for g in "" "--gpus 0,0" "--gpus 0,0,0,0"; do
   tag=$(echo "lanes$g" | tr -d ' ,-' | sed 's/gpus//')
   SECEDO_ONE_SHOT_TRACE=1 secedo_amd/csrc/build/shim_test $g --synth 8000 100000 22 30000 0.03 2 > $R/shim_C3_$tag.json 2> $R/shim_C3_$tag.trace
 done
+python tools/divide_cluster_demo.py C3 > $R/divide_cluster_demo_C3.json 2> /dev/null
+python tools/divide_cluster_demo.py C2 > $R/divide_cluster_demo_C2.json 2> /dev/null
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_r04_* $R/pmc_FETCH_SIZE $R/pmc_WRITE_SIZE $R/calib_FETCH_SIZE $R/calib_WRITE_SIZE 2>/dev/null || true
 echo "all done"
