@@ -294,7 +294,7 @@ Bounce g_bounce[1 + kMaxLanes];
 // pageable memory cannot do (12-20 GB/s for hipMemcpy on the 512 MB of C3).
 hipError_t download_pipelined(const void *d_src, void *dst, size_t bytes, unsigned threads, int ring = 0) {
     constexpr size_t kChunk = 32u << 20;
-    constexpr int kSlots = 3;
+    constexpr int kSlots = 4;
     std::lock_guard<std::mutex> lock(g_bounce[ring].mutex);
     PinnedBuf &g_bounce = ::g_bounce[ring].buf;
     hipError_t e = g_bounce.ensure(kChunk * kSlots);
@@ -309,40 +309,70 @@ hipError_t download_pipelined(const void *d_src, void *dst, size_t bytes, unsign
         if (b > a) (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
     }
 #endif
-    hipStream_t s = nullptr;
-    hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr};
+    // (SECEDO_DOWNLOAD_STREAMS=2: chunks alternate between two streams -- measured SLOWER on the MI355X box, 17-23 ms
+    // against 14-15 for the 512 MB of C3: one stream moves 34-36 GB/s and a second one only gets in its way)
+    static const int n_streams = [] { const char *v = std::getenv("SECEDO_DOWNLOAD_STREAMS"); const int n = v ? std::atoi(v) : 1; return n < 1 ? 1 : n > 2 ? 2 : n; }();
+    hipStream_t s = nullptr, s2 = nullptr;
+    hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
     if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) return e;
+    if (n_streams > 1 && (e = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)) != hipSuccess) {
+        (void)hipStreamDestroy(s);
+        return e;
+    }
     for (int i = 0; i < kSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
     const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
     threads = std::max(1u, std::min(threads, 16u));
     auto issue = [&](size_t c) {
         const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+        hipStream_t sc = (s2 && (c & 1)) ? s2 : s;
         hipError_t r = hipMemcpyAsync(static_cast<char *>(g_bounce.p) + (c % kSlots) * kChunk,
-                                      static_cast<const char *>(d_src) + off, len, hipMemcpyDeviceToHost, s);
-        if (r == hipSuccess) r = hipEventRecord(ev[c % kSlots], s);
+                                      static_cast<const char *>(d_src) + off, len, hipMemcpyDeviceToHost, sc);
+        if (r == hipSuccess) r = hipEventRecord(ev[c % kSlots], sc);
         return r;
     };
+    // The copying threads live for the whole download (round 4: a team per chunk was 16 x 7 thread starts and joins,
+    // a fifth of the 14 ms of a C3 matrix): thread t copies slice t of every chunk as soon as the chunk has landed
+    // (`landed`, published by this thread after the chunk's event), and a ring slot is written again only when every
+    // thread is done with the chunk that used it (`copied`).
+    std::atomic<size_t> landed{0};
+    std::atomic<bool> give_up{false};
+    std::vector<std::atomic<unsigned>> copied(n_chunks);
+    for (auto &c : copied) c.store(0);
+    auto copier = [&](unsigned t) {
+        for (size_t c = 0; c < n_chunks; ++c) {
+            while (landed.load(std::memory_order_acquire) <= c) {
+                if (give_up.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+            const char *src = static_cast<const char *>(g_bounce.p) + (c % kSlots) * kChunk;
+            char *out = static_cast<char *>(dst) + off;
+            const size_t slice = ((len + threads - 1) / threads + 4095) & ~(size_t)4095;
+            const size_t lo = std::min(len, (size_t)t * slice), hi = std::min(len, ((size_t)t + 1) * slice);
+            if (hi > lo) std::memcpy(out + lo, src + lo, hi - lo);
+            copied[c].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) pool.emplace_back(copier, t);
     for (size_t c = 0; c < std::min<size_t>(kSlots - 1, n_chunks) && e == hipSuccess; ++c) e = issue(c);
     for (size_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
-        if (c + kSlots - 1 < n_chunks) e = issue(c + kSlots - 1);  // its slot was emptied by the copy of chunk c - 1
+        if (c + kSlots - 1 < n_chunks) {  // its slot held chunk c - 1
+            while (c > 0 && copied[c - 1].load(std::memory_order_acquire) < threads) std::this_thread::yield();
+            e = issue(c + kSlots - 1);
+        }
         if (e == hipSuccess) e = hipEventSynchronize(ev[c % kSlots]);
         if (e != hipSuccess) break;
-        const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
-        const char *src = static_cast<const char *>(g_bounce.p) + (c % kSlots) * kChunk;
-        char *out = static_cast<char *>(dst) + off;
-        const size_t slice = ((len + threads - 1) / threads + 4095) & ~(size_t)4095;
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < threads; ++t) {
-            const size_t lo = std::min(len, t * slice), hi = std::min(len, (t + 1) * slice);
-            if (hi > lo) pool.emplace_back([=] { std::memcpy(out + lo, src + lo, hi - lo); });
-        }
-        std::memcpy(out, src, std::min(len, slice));
-        for (auto &th : pool) th.join();
+        landed.store(c + 1, std::memory_order_release);
     }
+    if (e != hipSuccess) give_up.store(true);
+    for (auto &th : pool) th.join();
     (void)hipStreamSynchronize(s);
+    if (s2) (void)hipStreamSynchronize(s2);
     for (int i = 0; i < kSlots; ++i)
         if (ev[i]) (void)hipEventDestroy(ev[i]);
     (void)hipStreamDestroy(s);
+    if (s2) (void)hipStreamDestroy(s2);
     return e;
 }
 }  // namespace
