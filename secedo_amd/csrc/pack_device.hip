@@ -2214,15 +2214,34 @@ std::string pack_attempt(const DeviceFlatPileup &in, uint32_t num_cells, uint32_
             hipLaunchKernelGGL(k_bin_hist, dim3(locus_grid), dim3(TPB), lds, stream, raw, nb, TL, entry_kc, nullptr, num_cells,
                                B_log2, blk_cnt, sc, 0u);
         trace.mark("k_bin_hist launched");
-        cub_cap = S[CUB].bytes;
-        HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
-        trace.mark("offset scan launched");
-        const std::string err = cut_ranges_on_side();
-        if (!err.empty()) return err;
-        if (kept_m) {  // behind the flush chain and the range cutting, beside the placing pass
+        // Where most kept entries belong to multi-entry reads (clustered loci) the M entries' records are the longest
+        // kernel of the packing (C3 clustered: 1.5 ms) and nothing but k_keys2 and the flush chain stands before
+        // them: they start on the side stream as soon as k_keys2 is through -- beside the histogram, the offset scan
+        // AND the placing pass, not behind the range cutting (round 4: 0.5 ms of a 7.6 ms packing) --, and the short
+        // range cutting stays on the main stream in front of the placing pass. On sparse loci (few M entries) the
+        // order of round 3: range cutting, then the records, both on the side stream.
+        const bool records_first = kept_m && (uint64_t)kept_m * 4u > (uint64_t)n_kept;
+        if (records_first) {
+            HIP_OK(hipEventRecord(pk.ev_offsets, stream));  // k_keys2 is through
+            HIP_OK(hipStreamWaitEvent(pk.side, pk.ev_offsets, 0));
             hipLaunchKernelGGL(k_m_records, dim3(blocks_for(kept_m)), dim3(TPB), 0, pk.side, raw, kept_m, t_read, read_off,
                                read_locus, read_base, krank, kflags, rbeg, flushed, m_rec, sc);
             HIP_OK(hipEventRecord(pk.ev_join, pk.side));
+        }
+        cub_cap = S[CUB].bytes;
+        HIP_OK(hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_cap, blk_cnt, blk_off, (int)n_off, stream));
+        trace.mark("offset scan launched");
+        if (records_first) {
+            hipLaunchKernelGGL(k_ranges_segment, dim3(n_seg, caps.allow_counts ? 2u : 1u), dim3(TPB), 0, stream, blk_off, nb,
+                               L, caps, seg_ends, seg_count, variant_stride);
+        } else {
+            const std::string err = cut_ranges_on_side();
+            if (!err.empty()) return err;
+            if (kept_m) {  // behind the flush chain and the range cutting, beside the placing pass
+                hipLaunchKernelGGL(k_m_records, dim3(blocks_for(kept_m)), dim3(TPB), 0, pk.side, raw, kept_m, t_read,
+                                   read_off, read_locus, read_base, krank, kflags, rbeg, flushed, m_rec, sc);
+                HIP_OK(hipEventRecord(pk.ev_join, pk.side));
+            }
         }
         if (n_kept) {
             unsigned long long *grouped = key_b;  // the sorted entry keys are dead after k_dup_rule
