@@ -728,6 +728,10 @@ def main():
                 except (subprocess.SubprocessError, ValueError, IndexError) as e:
                     line["cpp_dropin_call"] = {"error": str(e)[:300]}
             line["cpu_baseline"] = cpu_baseline(p, n_cells, mfl, rates, threads, 5e8)
+            if digest is not None and "reference_seconds" in digest.files:
+                # the WHOLE workload through the compiled reference, once, in the build container (8 vCPUs), when
+                # the digest above was made (oracle/gen_golden.py): not a measurement of this run
+                line["cpu_baseline"]["reference_full_workload_s_in_build_container"] = float(digest["reference_seconds"])
         emit(line)
     if dist_on:
         dist.barrier()
