@@ -1211,8 +1211,7 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
 // the current one is paired, and the value comes out of ONE unconditional table read. Longer items go through
 // the wave's ring, 32 or more column entries are paired by the whole wave.
 //
-// Round 4: the words a pair is decided from. Both sides are converted once (the column side on its way into
-// LDS, the row side when the items are built) into
+// Round 4: the words a pair is decided from. Every packed entry is converted once per prepare (masks_words) into
 //   x = prev8 | tail << 8 | dead << 9 | base << 16 | (column: cell << 26; row: next8 << 24)
 //   y = the bases of the read at the 8 next loci as four one-hot planes of 8 bits (plane b, bit d: the read
 //       covers the locus d + 1 behind this one with base b; no bit where it does not cover it)
@@ -1223,7 +1222,8 @@ __global__ __launch_bounds__(THREADS) void accumulate_counts(const AccumulateArg
 // shared locus owns the pair) and the exclusions (both reads never flushed, :407-408; a column entry whose
 // read reaches beyond its windows: wide_pairs has its pairs, a row entry of that kind gets no item) need --
 // masks of single-locus reads are empty, so no "both multi-locus" test is left. The table is indexed by
-// (x_s, shared next loci). 47 -> 19 vector instructions per slot (C3 clustered 47.6 -> see DESIGN.md).
+// (x_s, shared next loci). 47 -> 16 vector instructions per slot (by hand, pair_group3_asm); C3 clustered 47.6 -> 38.0 ms
+// together with masks_words(), the two rounds in line and the spread of thin ring batches.
 // A pair of two multi-locus reads is owned by its first shared locus (prev masks disjoint), as before.
 // ------------------------------------------------------------------------------------------------
 constexpr int MASKS_RING = 128;
