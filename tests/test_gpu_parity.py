@@ -170,6 +170,38 @@ def test_tile_ranges_compose_bitwise():
         assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("clustered", [False, True])
+def test_back_to_back_tile_ranges_on_a_non_blocking_stream(clustered):
+    """Round 4: accumulate's small uploads (table, workgroup plan, tile list) follow the stream it is given. On a
+    NON-BLOCKING stream -- torch's side streams are -- a plain hipMemcpy (null stream) does not wait for the launch
+    still running there: the second range's plan used to overwrite the one the first range's kernels were reading
+    (two lanes of the multi-device call on one GPU gave another matrix). Many ranges enqueued back to back, with
+    and without tile lists, nothing synchronised in between, against one launch of everything."""
+    import torch
+    from secedo_amd.synth import synth_pileup
+    n = 1000
+    p = synth_pileup(n, 20000, 2, 300 if clustered else 3000, 0.05, seed=9)
+    with secedo_amd.SimilarityMatrixPlan(0) as plan:
+        plan.prepare(p, n, 1000, None, 8)
+        nt = plan.num_tiles
+        want, got, lists = plan.new_acc(), plan.new_acc(), plan.new_acc()
+        got.fill_(-3)
+        lists.fill_(-5)
+        plan.accumulate(want, 0.01, 0.5, 0.01)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            cuts = sorted({0, nt} | {int(nt * f) for f in (0.07, 0.1, 0.33, 0.34, 0.5, 0.51, 0.8, 0.97)})
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                plan.accumulate(got, 0.01, 0.5, 0.01, lo, hi, overwrite=True)
+            ids = np.arange(nt, dtype=np.uint32)
+            for part in np.array_split(ids[::-1], 7):  # lists of tiles, from the back
+                plan.accumulate_list(lists, 0.01, 0.5, 0.01, np.ascontiguousarray(part), overwrite=True)
+        side.synchronize()
+        assert torch.equal(got, want)
+        assert torch.equal(lists, want)
+
+
 @pytest.mark.parametrize("clustered,block", [(True, 64), (False, 128), (False, 64)])
 def test_assign_overwrites_whatever_the_tiles_held(clustered, block):
     """secedo_simmat_assign / assign_list: the tiles of the launch end up as after accumulate() into zeroes,
