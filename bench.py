@@ -539,8 +539,8 @@ def main():
         jj = torch.from_numpy(digest["sample_j"].astype(np.int64)).to(out.device)
         err = np.abs(out[ii, jj].cpu().numpy() - digest["sample_v"])
         ref_max = float(digest["max_abs"])
-        parity = {"checked": True, "against": "compiled reference (oracle/_ref), tests/golden/%s_reference_digest.npz"
-                                              % args.workload.lower(),
+        parity = {"checked": True, "against": "compiled reference (oracle/_ref), tests/golden/%s%s_reference_digest.npz"
+                                              % (args.workload.lower(), "_clustered" if args.clustered else ""),
                   "samples": int(len(err)), "normwise_err": float(err.max() / ref_max), "tolerance": 1e-9,
                   "max_abs_matches": bool(abs(float(out.abs().max()) - ref_max) <= 1e-9 * ref_max),
                   "symmetric": bool(torch.equal(out, out.T)), "zero_diagonal": not bool(torch.any(torch.diagonal(out)))}
