@@ -1586,7 +1586,10 @@ int compute_on_devices(const std::vector<int> &devices, const uint32_t *chr_locu
             if (me.rc == SECEDO_OK && row_bytes) {
                 double *dst = out + static_cast<size_t>(row_lo) * num_cells;
                 if (row_bytes >= (8u << 20))
-                    LANE_HIP(download_pipelined(me.h->own_out.p, dst, row_bytes, std::max(1u, num_threads / n), 1 + static_cast<int>(k)));
+                    // (copier threads: the lanes share what one lane alone would use -- at least 16 in all: touching the
+                    // fresh pages of the caller's matrix is what bounds a download, 2 GB/s for one thread)
+                    LANE_HIP(download_pipelined(me.h->own_out.p, dst, row_bytes, std::max(1u, std::max(num_threads, 16u) / n),
+                                                1 + static_cast<int>(k)));
                 else
                     LANE_HIP(hipMemcpy(dst, me.h->own_out.p, row_bytes, hipMemcpyDeviceToHost));
             }
